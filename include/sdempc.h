@@ -1,0 +1,159 @@
+/*
+ * sdempc.h — C ABI of the MI355X-native MPC inner loop (neural-SDE rollout + APG trajectory optimiser).
+ *
+ * This is the drop-in boundary for ONE path of wuwushrek/sde4mbrl_px4: the solver that
+ * `sde4mbrl_px4/mpc_controller/sde_control.py` obtains from
+ * `load_mpc_from_cfgfile(mpc_dir, convert_to_enu=True)` (sde_control.py:685) and calls per control
+ * tick as `m_reset(x=, rng=, xdes=)` (sde_control.py:345-346,389-394,706) and
+ * `m_mpc(x, rng, opt_state, curr_t=, xdes=)` (sde_control.py:349-350,400-416,717).
+ * The reference has no C interface for this path (the arithmetic lives in the un-vendored JAX package
+ * sde4mbrl); this header is what a ctypes binding on the reference side binds.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++ / torch types; every entry point returns 0 on success or a
+ *     negative SDEMPC_E* code, never aborts or throws (an exception would silently kill the
+ *     reference's `mpc_process`, sde_control.py:365-419 has no try/except).
+ *   - state vector f32[13] = [x,y,z, vx,vy,vz, qw,qx,qy,qz, wx,wy,wz] (sde_control.py:246,747).
+ *   - "host" entry points take host pointers (caller owns them) and stage through device buffers
+ *     owned by the handle; "_dev" entry points take device pointers already resident in HBM and a
+ *     hipStream_t passed as void*.
+ *   - canonical tensor layouts (row-major, innermost last):
+ *       x0    f32[B][13]            initial states
+ *       u     f32[B][H][m]          control sequences (normalised PWM)
+ *       xref  f32[B][H+1][13]       reference states at t_0..t_H
+ *       noise f32[B][P][H][6]       N(0,1) draws for the 6 noisy state dims (v, omega)
+ *       traj  f32[B][P][H+1][13]    particle x horizon tensor
+ *       uopt  f32[B][H][m], xevol f32[B][H+1][13] (particle mean), info f32[B][8]
+ *   - a handle is single-threaded; the HIP context is created lazily on the first call that needs
+ *     the device, in the calling process (safe to create the handle before fork()).
+ */
+#ifndef SDEMPC_H
+#define SDEMPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDEMPC_NX 13          /* state dims */
+#define SDEMPC_NNOISE 6       /* noisy state dims: v(3), omega(3) */
+#define SDEMPC_MAX_MOTORS 8
+#define SDEMPC_HID 32         /* hidden width of the residual / density MLPs */
+#define SDEMPC_BLOB_MAGIC 0x31454453 /* "SDE1" */
+#define SDEMPC_BLOB_HEADER_INTS 16
+#define SDEMPC_BLOB_FLOATS 2120
+
+/* error codes */
+#define SDEMPC_OK 0
+#define SDEMPC_EINVAL (-1)    /* bad argument / config */
+#define SDEMPC_EBLOB (-2)     /* malformed model blob */
+#define SDEMPC_EDEVICE (-3)   /* HIP error (message in sdempc_last_error) */
+#define SDEMPC_ENOMEM (-4)
+#define SDEMPC_ECAPACITY (-5) /* batch larger than max_batch given at create */
+
+/* Hyper-parameters: one-to-one with the reference's MPC YAML schema
+ * (launch/iris_sitl_traj_mpc.yaml:8-85, launch/iris_sitl_posctrl_mpc.yaml:6-101). */
+typedef struct sdempc_cfg {
+    int32_t struct_size;              /* sizeof(sdempc_cfg), ABI check */
+    int32_t horizon;                  /* H            (yaml: horizon) */
+    int32_t num_particles;            /* P            (yaml: num_particles) */
+    int32_t num_motors;               /* m            (len(input_constr.input_id)) */
+    const float* time_steps;          /* [H] dt per step (yaml: num_short_dt/short_step_dt/long_step_dt) */
+    float discount;                   /* yaml: discount */
+    /* cost_params */
+    float uref[SDEMPC_MAX_MOTORS];
+    float uerr;
+    float perr[3], verr[3], qerr[3], werr[3];
+    float res_mult;
+    float u_slew_coeff;
+    int32_t has_slew_constr;          /* 1 if cost_params.u_slew_constr present */
+    float u_slew_lo[SDEMPC_MAX_MOTORS], u_slew_hi[SDEMPC_MAX_MOTORS];
+    float u_slew_constr_coeff;
+    /* input_constr.input_bound (enforce_ubound) */
+    float u_lo[SDEMPC_MAX_MOTORS], u_hi[SDEMPC_MAX_MOTORS];
+    /* apg_mpc */
+    int32_t max_iter;
+    int32_t max_no_improvement_iter;
+    int32_t use_moment_scale;         /* 0: yaml moment_scale null */
+    float moment_scale;
+    float beta_init;
+    float atol, rtol;
+    float stepsize;                   /* used when ls_maxls == 0 */
+    float ls_init_stepsize, ls_max_stepsize, ls_coef, ls_decrease_factor, ls_increase_factor;
+    int32_t ls_reset_option;          /* 0 conservative, 1 increase */
+    int32_t ls_maxls;
+} sdempc_cfg;
+
+/* Optimiser telemetry: the 7 scalars the reference reads from opt_state
+ * (sde_control.py:444-450, msg/OptMPCState.msg:6-22) + the line-search trial count. */
+typedef struct sdempc_info {
+    float avg_linesearch;
+    float stepsize;
+    float num_steps;
+    float grad_sqr;
+    float avg_stepsize;
+    float init_cost;
+    float opt_cost;
+    float num_ls_trials;              /* total trial rollouts N_ls (for the roofline accounting) */
+} sdempc_info;
+
+typedef struct sdempc_handle sdempc_handle;
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+/* Replaces: construction inside load_mpc_from_cfgfile (sde_control.py:685). Host-only; no HIP call. */
+int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_bytes,
+                  int32_t max_batch, sdempc_handle** out);
+void sdempc_destroy(sdempc_handle* h);
+const char* sdempc_last_error(const sdempc_handle* h);   /* h may be NULL: last create error */
+int sdempc_abi_version(void);
+
+/* Binds the handle to a HIP device ordinal (default 0). Must precede the first device call. */
+int sdempc_set_device(sdempc_handle* h, int32_t device);
+
+/* ---- m_reset (sde_control.py:702-707,345-346,389-394) -------------------------------------- */
+/* Host-only. Fills yk[H][m] with the hover guess uref and info with the initial telemetry. */
+int sdempc_reset(sdempc_handle* h, const float* x, const float* xdes, float* yk, sdempc_info* info);
+
+/* ---- hot-path pieces, batched, host pointers ----------------------- */
+/* A4+A5: Euler–Maruyama rollout + expected cost. traj/xmean may be NULL. */
+int sdempc_rollout_batch(sdempc_handle* h, int32_t B, const float* x0, const float* u,
+                         const float* xref, const float* noise,
+                         float* cost /*[B]*/, float* traj /*[B][P][H+1][13] or NULL*/,
+                         float* xmean /*[B][H+1][13] or NULL*/);
+/* A6 (gradient): cost and d cost / d u by the adjoint pass. */
+int sdempc_grad_batch(sdempc_handle* h, int32_t B, const float* x0, const float* u,
+                      const float* xref, const float* noise,
+                      float* cost /*[B]*/, float* grad /*[B][H][m]*/);
+/* A3: the solve. u_init = warm start (opt_state.yk), stepsize_in = opt_state.stepsize. */
+int sdempc_solve_batch(sdempc_handle* h, int32_t B, const float* x0, const float* xref,
+                       const float* noise, const float* u_init /*[B][H][m]*/,
+                       const float* stepsize_in /*[B]*/,
+                       float* uopt /*[B][H][m]*/, float* xevol /*[B][H+1][13]*/,
+                       sdempc_info* info /*[B]*/);
+
+/* ---- device-resident variants (benchmarks, multi-instance serving) -------------------------- */
+/* noise_dev uses the device layout produced by sdempc_noise_to_device_layout / _dev:
+ *   f32[B][G][H][6][32] with G = ceil(P/32), particle p -> (g = p/32, lane = p%32). */
+size_t sdempc_noise_dev_floats(const sdempc_handle* h, int32_t B);
+size_t sdempc_traj_dev_floats(const sdempc_handle* h, int32_t B);
+int sdempc_noise_to_device_layout(const sdempc_handle* h, int32_t B, const float* noise_host, float* out_host);
+int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* xref_dev,
+                           const void* noise_dev, const void* u_init_dev, const void* stepsize_dev,
+                           void* uopt_dev, void* xevol_dev, void* info_dev /*f32[B][8]*/,
+                           void* stream);
+int sdempc_rollout_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* u_dev,
+                             const void* xref_dev, const void* noise_dev, void* cost_dev,
+                             void* xmean_dev /*or NULL*/, int32_t store_traj, void* stream);
+int sdempc_grad_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* u_dev,
+                          const void* xref_dev, const void* noise_dev, void* cost_dev,
+                          void* grad_dev, void* stream);
+
+/* Times the last *_dev launch on its own stream with HIP events (ms); <0 if unavailable. */
+float sdempc_last_kernel_ms(const sdempc_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDEMPC_H */

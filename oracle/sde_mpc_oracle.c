@@ -1,0 +1,795 @@
+/*
+ * sde_mpc_oracle.c — CPU restatement ("oracle") of the MPC inner loop. TEST INFRASTRUCTURE ONLY.
+ *
+ *   Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's .so.
+ *   The product path (sde4mbrl_px4_amd/csrc) never includes, links or calls anything in oracle/.
+ *
+ * PARITY UNPINNED.  The reference (wuwushrek/sde4mbrl_px4) does not contain this arithmetic: it
+ * imports it from the un-vendored, un-pinned JAX package `sde4mbrl` / `sde4mbrlExamples`
+ *   sde4mbrl_px4/mpc_controller/sde_control.py:12  from sde4mbrlExamples.rotor_uav.sde_mpc_design import load_mpc_from_cfgfile
+ *   sde4mbrl_px4/mpc_controller/sde_control.py:13  from sde4mbrlExamples.rotor_uav.utils import enu2ned
+ * which is absent from /root/reference and from this image (no jax either), and the reference holds
+ * no tests, golden vectors or fixtures for the path. This file therefore
+ * restates the *published structure* of that algorithm (physics-structured rotor neural SDE,
+ * Euler–Maruyama particles, accelerated proximal gradient with Armijo backtracking; Djeumou et al.,
+ * CoRL 2023) as specified op-by-op in SPEC.md, and is anchored on what the reference does fix:
+ *   - call signatures/shapes at sde_control.py:702,706,713,717,345-350,400-416
+ *   - the hyper-parameter schema launch/iris_sitl_traj_mpc.yaml:8-85, iris_sitl_posctrl_mpc.yaml:6-101
+ *   - telemetry fields sde_control.py:444-450, msg/OptMPCState.msg:6-22
+ *   - post-processing sde_control.py:428-432
+ *
+ * Everything is float32 with an explicit operation order (fmaf where SPEC.md says fma) so that an
+ * independent implementation following SPEC.md is reproducible bit for bit. Compile with
+ *   gcc -O2 -ffp-contract=off [-mfma] -shared -fPIC
+ * Compile with -DORC_DOUBLE for the float64 build (exact libm activations) used by the
+ * finite-difference gradient tests; symbols are then prefixed orcd_.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../include/sdempc.h"
+
+#ifdef ORC_DOUBLE
+typedef double real;
+#define FMA(a, b, c) fma((a), (b), (c))
+#define FABS(a) fabs(a)
+#define NAME(x) orcd_##x
+#else
+typedef float real;
+#define FMA(a, b, c) fmaf((a), (b), (c))
+#define FABS(a) fabsf(a)
+#define NAME(x) orc_##x
+#endif
+#define R(x) ((real)(x))
+
+#define NX 13
+#define NN 6
+#define HID 32
+#define MAXM 8
+#define NSLOT 4 /* particle-group reduction slots (SPEC.md §6) */
+
+/* ------------------------------------------------------------------------------------------- */
+/* SPEC.md §3: elementary functions                                                            */
+/* ------------------------------------------------------------------------------------------- */
+#ifndef ORC_DOUBLE
+static inline float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t as_u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* reciprocal of d > 0: magic-constant seed + 3 Newton steps, every step an fma */
+float NAME(rcp)(float d) {
+    float y = as_f(0x7EF311C7u - as_u(d));
+    for (int i = 0; i < 3; ++i) { float e = fmaf(-d, y, 1.0f); y = fmaf(y, e, y); }
+    return y;
+}
+/* 1/sqrt(a), a > 0: magic seed + 3 Newton steps */
+float NAME(rsqrt)(float a) {
+    float y = as_f(0x5F3759DFu - (as_u(a) >> 1));
+    float h = 0.5f * a;
+    for (int i = 0; i < 3; ++i) { float t = y * y; t = fmaf(-h, t, 1.5f); y = y * t; }
+    return y;
+}
+/* 2^(x*c) for |x*c| <= 64 (SPEC.md §3.3): t2 = fma(x,c,1.5*2^23) holds n = rne(x*c) in its low
+ * mantissa bits; f = fma(x,c,-n) in [-0.5,0.5]; degree-5 polynomial; exponent add by integer shift */
+static inline float exp2_spec(float x, float c) {
+    float t2 = fmaf(x, c, 12582912.0f);
+    float n = t2 - 12582912.0f;
+    float f = fmaf(x, c, -n);
+    float p = 0.001327647129073739f;
+    p = fmaf(p, f, 0.009675540961325169f);
+    p = fmaf(p, f, 0.05550713092088699f);
+    p = fmaf(p, f, 0.24022120237350464f);
+    p = fmaf(p, f, 0.6931469440460205f);
+    p = fmaf(p, f, 1.0000001192092896f);
+    return as_f(as_u(p) + (as_u(t2) << 23));
+}
+/* tanh of 4 values sharing ONE reciprocal (batched inversion, SPEC.md §3.4):
+ * d_i = 1 + exp(2 x_i); r = 1/(d0 d1 d2 d3); 1/d_i recovered by multiplications; tanh = 1 - 2/d_i */
+void NAME(tanh4)(const float* x, float* y) {
+    float d[4];
+    for (int i = 0; i < 4; ++i) {
+        float xc = fminf(fmaxf(x[i], -9.0f), 9.0f);
+        d[i] = 1.0f + exp2_spec(xc, 2.885390043258667f); /* 2*log2(e) */
+    }
+    float p2 = d[0] * d[1], p3 = p2 * d[2], p4 = p3 * d[3];
+    float r = NAME(rcp)(p4);
+    float r3 = r * p3; r = r * d[3];
+    float r2 = r * p2; r = r * d[2];
+    float r1 = r * d[0];
+    float r0 = r * d[1];
+    y[0] = fmaf(-2.0f, r0, 1.0f); y[1] = fmaf(-2.0f, r1, 1.0f); y[2] = fmaf(-2.0f, r2, 1.0f); y[3] = fmaf(-2.0f, r3, 1.0f);
+}
+float NAME(tanh)(float x) { float a[4] = {x, x, x, x}, y[4]; NAME(tanh4)(a, y); return y[0]; }
+float NAME(sigmoid)(float x) {
+    float xc = fminf(fmaxf(x, -30.0f), 30.0f);
+    float E = exp2_spec(xc, -1.4426950216293335f); /* -log2(e) */
+    return NAME(rcp)(1.0f + E);
+}
+#else
+double NAME(rcp)(double d) { return 1.0 / d; }
+double NAME(rsqrt)(double a) { return 1.0 / sqrt(a); }
+double NAME(tanh)(double x) { return tanh(x); }
+void NAME(tanh4)(const double* x, double* y) { for (int i = 0; i < 4; ++i) y[i] = tanh(x[i]); }
+double NAME(sigmoid)(double x) { return 1.0 / (1.0 + exp(-x)); }
+#endif
+
+/* ------------------------------------------------------------------------------------------- */
+/* model blob (SPEC.md §2)                                                                     */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int m;
+    real inv_mass, grav, J[3], iJ[3], ct2, ct1, ct0, cm2, cm1;
+    real rx[MAXM], ry[MAXM], dir[MAXM];
+    real sF[3], sT[3], sigma[NN];
+    real W1z[2 * HID][NN], b1[2 * HID], W1u[HID][MAXM], W2[HID][HID], b2[HID], W3[6][HID], b3[6], w3n[HID], b3n;
+} model_t;
+
+static int parse_blob(const void* blob, model_t* M) {
+    const int32_t* hd = (const int32_t*)blob;
+    if (hd[0] != SDEMPC_BLOB_MAGIC || hd[1] != 1) return -1;
+    M->m = hd[2];
+    if (M->m < 1 || M->m > MAXM || hd[3] != HID || hd[4] != NN || hd[5] != NN) return -1;
+    const float* f = (const float*)(hd + SDEMPC_BLOB_HEADER_INTS);
+    M->inv_mass = f[0]; M->grav = f[1];
+    for (int i = 0; i < 3; ++i) { M->J[i] = f[2 + i]; M->iJ[i] = f[5 + i]; }
+    M->ct2 = f[8]; M->ct1 = f[9]; M->ct0 = f[10]; M->cm2 = f[11]; M->cm1 = f[12];
+    f += 16;
+    for (int j = 0; j < MAXM; ++j) { M->rx[j] = f[j]; M->ry[j] = f[8 + j]; M->dir[j] = f[16 + j]; }
+    f += 24;
+    for (int i = 0; i < 3; ++i) { M->sF[i] = f[i]; M->sT[i] = f[3 + i]; }
+    f += 8;
+    for (int i = 0; i < NN; ++i) M->sigma[i] = f[i];
+    f += 8;
+    for (int r = 0; r < 2 * HID; ++r) for (int k = 0; k < NN; ++k) M->W1z[r][k] = f[r * NN + k];
+    f += 2 * HID * NN;
+    for (int r = 0; r < 2 * HID; ++r) M->b1[r] = f[r];
+    f += 2 * HID;
+    for (int r = 0; r < HID; ++r) for (int j = 0; j < MAXM; ++j) M->W1u[r][j] = f[r * MAXM + j];
+    f += HID * MAXM;
+    for (int r = 0; r < HID; ++r) for (int k = 0; k < HID; ++k) M->W2[r][k] = f[r * HID + k];
+    f += HID * HID;
+    for (int r = 0; r < HID; ++r) M->b2[r] = f[r];
+    f += HID;
+    for (int i = 0; i < 6; ++i) for (int k = 0; k < HID; ++k) M->W3[i][k] = f[i * HID + k];
+    f += 8 * HID;
+    for (int i = 0; i < 6; ++i) M->b3[i] = f[i];
+    f += 8;
+    for (int k = 0; k < HID; ++k) M->w3n[k] = f[k];
+    f += HID;
+    M->b3n = f[0];
+    return 0;
+}
+
+/* hidden-unit visiting order of SPEC.md §4: k(r,h) = (r&3) + 8*(r>>2) + 4*h, r = 0..15, h = 0..1 */
+static inline int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+/* ------------------------------------------------------------------------------------------- */
+/* per-step control-dependent constants (SPEC.md §5.1)                                         */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+    real c[HID];      /* drift layer-1 pre-activation offset b1 + W1u u_t */
+    real Tz, tau[3];  /* total thrust and rotor torques */
+    real dT[MAXM], dM[MAXM];
+} ustep_t;
+
+static void ustep_eval(const model_t* M, const real* u, ustep_t* U) {
+    int m = M->m;
+    for (int r = 0; r < HID; ++r) {
+        real a = M->b1[r];
+        for (int j = 0; j < m; ++j) a = FMA(M->W1u[r][j], u[j], a);
+        U->c[r] = a;
+    }
+    real Tz = 0, t0 = 0, t1 = 0, t2 = 0;
+    for (int j = 0; j < m; ++j) {
+        real T = FMA(FMA(M->ct2, u[j], M->ct1), u[j], M->ct0);
+        real Mq = M->dir[j] * (FMA(M->cm2, u[j], M->cm1) * u[j]);
+        Tz = Tz + T;
+        t0 = FMA(M->ry[j], T, t0);
+        t1 = FMA(-M->rx[j], T, t1);
+        t2 = t2 + Mq;
+        U->dT[j] = FMA(R(2) * M->ct2, u[j], M->ct1);
+        U->dM[j] = M->dir[j] * FMA(R(2) * M->cm2, u[j], M->cm1);
+    }
+    U->Tz = Tz; U->tau[0] = t0; U->tau[1] = t1; U->tau[2] = t2;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* one Euler–Maruyama step (SPEC.md §5.2) and its vector-Jacobian product (§5.4)               */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct { /* values the VJP re-uses; recomputed from x_t in the backward sweep */
+    real Rm[9], vb[3], h1d[HID], h1n[HID], h2[HID], o[6], eta, Fb[3], Jom[3], qt[4], rn, qn[4];
+} stepaux_t;
+
+static void step_fwd(const model_t* M, const ustep_t* U, const real* x, const real* xi, real dt,
+                     const real* sdt, real* xn, stepaux_t* A) {
+    const real *p = x, *v = x + 3, *q = x + 6, *om = x + 10;
+    real qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    real xx = qx * qx, yy = qy * qy, zz = qz * qz;
+    real xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
+    real* Rm = A->Rm;
+    Rm[0] = FMA(R(-2), yy + zz, R(1)); Rm[1] = R(2) * (xy - wz);          Rm[2] = R(2) * (xz + wy);
+    Rm[3] = R(2) * (xy + wz);          Rm[4] = FMA(R(-2), xx + zz, R(1)); Rm[5] = R(2) * (yz - wx);
+    Rm[6] = R(2) * (xz - wy);          Rm[7] = R(2) * (yz + wx);          Rm[8] = FMA(R(-2), xx + yy, R(1));
+    /* body-frame velocity vb = R^T v */
+    for (int j = 0; j < 3; ++j) A->vb[j] = FMA(Rm[6 + j], v[2], FMA(Rm[3 + j], v[1], Rm[j] * v[0]));
+    real z[NN] = {A->vb[0], A->vb[1], A->vb[2], om[0], om[1], om[2]};
+    /* layer 1: drift rows 0..31 start from U->c, density rows 32..63 from b1 */
+    real pre_d[HID], pre_n[HID], pre_2[HID];
+    for (int r = 0; r < HID; ++r) {
+        real a = U->c[r], b = M->b1[HID + r];
+        for (int k = 0; k < NN; ++k) { a = FMA(M->W1z[r][k], z[k], a); b = FMA(M->W1z[HID + r][k], z[k], b); }
+        pre_d[r] = a; pre_n[r] = b;
+    }
+    for (int r = 0; r < HID; r += 4) { NAME(tanh4)(pre_d + r, A->h1d + r); NAME(tanh4)(pre_n + r, A->h1n + r); }
+    /* layer 2 (drift): k visited in rowmap order */
+    for (int i = 0; i < HID; ++i) {
+        real a = M->b2[i];
+        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int k = rowmap(r, h); a = FMA(M->W2[i][k], A->h1d[k], a); }
+        pre_2[i] = a;
+    }
+    for (int r = 0; r < HID; r += 4) NAME(tanh4)(pre_2 + r, A->h2 + r);
+    /* output layers: two half-sums (h = 0, 1) over r, then (P0 + P1) + bias */
+    for (int i = 0; i < 6; ++i) {
+        real P0 = 0, P1 = 0;
+        for (int r = 0; r < 16; ++r) { P0 = FMA(M->W3[i][rowmap(r, 0)], A->h2[rowmap(r, 0)], P0); P1 = FMA(M->W3[i][rowmap(r, 1)], A->h2[rowmap(r, 1)], P1); }
+        A->o[i] = (P0 + P1) + M->b3[i];
+    }
+    {
+        real P0 = 0, P1 = 0;
+        for (int r = 0; r < 16; ++r) { P0 = FMA(M->w3n[rowmap(r, 0)], A->h1n[rowmap(r, 0)], P0); P1 = FMA(M->w3n[rowmap(r, 1)], A->h1n[rowmap(r, 1)], P1); }
+        A->eta = NAME(sigmoid)((P0 + P1) + M->b3n);
+    }
+    /* rigid body */
+    A->Fb[0] = M->sF[0] * A->o[0]; A->Fb[1] = M->sF[1] * A->o[1]; A->Fb[2] = FMA(M->sF[2], A->o[2], U->Tz);
+    real acc[3];
+    for (int i = 0; i < 3; ++i) {
+        real Fw = FMA(Rm[3 * i + 2], A->Fb[2], FMA(Rm[3 * i + 1], A->Fb[1], Rm[3 * i] * A->Fb[0]));
+        acc[i] = Fw * M->inv_mass;
+    }
+    acc[2] = acc[2] - M->grav;
+    real taub[3];
+    for (int i = 0; i < 3; ++i) { taub[i] = FMA(M->sT[i], A->o[3 + i], U->tau[i]); A->Jom[i] = M->J[i] * om[i]; }
+    real cr[3];
+    cr[0] = FMA(om[1], A->Jom[2], -(om[2] * A->Jom[1]));
+    cr[1] = FMA(om[2], A->Jom[0], -(om[0] * A->Jom[2]));
+    cr[2] = FMA(om[0], A->Jom[1], -(om[1] * A->Jom[0]));
+    real dom[3];
+    for (int i = 0; i < 3; ++i) dom[i] = (taub[i] - cr[i]) * M->iJ[i];
+    real dq[4];
+    dq[0] = R(-0.5) * FMA(qz, om[2], FMA(qy, om[1], qx * om[0]));
+    dq[1] = R(0.5) * FMA(-qz, om[1], FMA(qy, om[2], qw * om[0]));
+    dq[2] = R(0.5) * FMA(-qx, om[2], FMA(qz, om[0], qw * om[1]));
+    dq[3] = R(0.5) * FMA(-qy, om[0], FMA(qx, om[1], qw * om[2]));
+    /* Euler–Maruyama update */
+    real se[NN];
+    for (int i = 0; i < NN; ++i) se[i] = sdt[i] * A->eta;
+    for (int i = 0; i < 3; ++i) {
+        xn[i] = FMA(v[i], dt, p[i]);
+        xn[3 + i] = FMA(se[i], xi[i], FMA(acc[i], dt, v[i]));
+        xn[10 + i] = FMA(se[3 + i], xi[3 + i], FMA(dom[i], dt, om[i]));
+    }
+    for (int i = 0; i < 4; ++i) A->qt[i] = FMA(dq[i], dt, q[i]);
+    real n2 = FMA(A->qt[3], A->qt[3], FMA(A->qt[2], A->qt[2], FMA(A->qt[1], A->qt[1], A->qt[0] * A->qt[0])));
+    A->rn = NAME(rsqrt)(n2);
+    for (int i = 0; i < 4; ++i) { A->qn[i] = A->qt[i] * A->rn; xn[6 + i] = A->qn[i]; }
+}
+
+/* stage state cost at x_{t+1} (SPEC.md §5.3): returns l, optionally the gradient wrt x_{t+1} */
+static real stage_cost(const sdempc_cfg* C, const real* x, const real* xr, real* gx) {
+    real l = 0;
+    for (int i = 0; i < 3; ++i) {
+        real e = x[i] - xr[i];
+        real w = (real)C->perr[i] * e;
+        l = FMA(w, e, l);
+        if (gx) gx[i] = R(2) * w;
+    }
+    for (int i = 0; i < 3; ++i) {
+        real e = x[3 + i] - xr[3 + i];
+        real w = (real)C->verr[i] * e;
+        l = FMA(w, e, l);
+        if (gx) gx[3 + i] = R(2) * w;
+    }
+    for (int i = 0; i < 3; ++i) {
+        real e = x[10 + i] - xr[10 + i];
+        real w = (real)C->werr[i] * e;
+        l = FMA(w, e, l);
+        if (gx) gx[10 + i] = R(2) * w;
+    }
+    real qw = x[6], qx = x[7], qy = x[8], qz = x[9], rw = xr[6], rx = xr[7], ry = xr[8], rz = xr[9];
+    real ex = FMA(rz, qy, FMA(-ry, qz, FMA(-rx, qw, rw * qx)));
+    real ey = FMA(-rz, qx, FMA(-ry, qw, FMA(rx, qz, rw * qy)));
+    real ez = FMA(-rz, qw, FMA(ry, qx, FMA(-rx, qy, rw * qz)));
+    real wxe = (real)C->qerr[0] * ex, wye = (real)C->qerr[1] * ey, wze = (real)C->qerr[2] * ez;
+    l = FMA(wxe, ex, l); l = FMA(wye, ey, l); l = FMA(wze, ez, l);
+    if (gx) {
+        real a = R(2) * wxe, b = R(2) * wye, c = R(2) * wze;
+        gx[6] = FMA(-rz, c, FMA(-ry, b, -rx * a));
+        gx[7] = FMA(ry, c, FMA(-rz, b, rw * a));
+        gx[8] = FMA(-rx, c, FMA(rw, b, rz * a));
+        gx[9] = FMA(rw, c, FMA(rx, b, -ry * a));
+    }
+    return l;
+}
+
+/* VJP of step_fwd. L = adjoint wrt x_{t+1}; etabar_cost = direct d(cost)/d(eta).
+ * Outputs: lam = adjoint wrt x_t; gu[m] = W1u^T abar1 (drift tile); gT = adjoint of Tz; gtau[3]. */
+static void step_vjp(const model_t* M, const real* x, const real* xi, real dt, const real* sdt,
+                     const stepaux_t* A, const real* L, real etabar_cost,
+                     real* lam, real* gu, real* gT, real* gtau) {
+    const real *v = x + 3, *q = x + 6, *om = x + 10;
+    const real *Lp = L, *Lv = L + 3, *Lq = L + 6, *Lo = L + 10;
+    const real* Rm = A->Rm;
+    real qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    /* eta adjoint */
+    real eb = etabar_cost;
+    for (int i = 0; i < 3; ++i) eb = FMA(Lv[i] * sdt[i], xi[i], eb);
+    for (int i = 0; i < 3; ++i) eb = FMA(Lo[i] * sdt[3 + i], xi[3 + i], eb);
+    real ebraw = eb * (A->eta * (R(1) - A->eta));
+    /* quaternion normalisation */
+    real dotq = FMA(A->qn[3], Lq[3], FMA(A->qn[2], Lq[2], FMA(A->qn[1], Lq[1], A->qn[0] * Lq[0])));
+    real qtb[4], dqb[4];
+    for (int i = 0; i < 4; ++i) { qtb[i] = A->rn * FMA(-A->qn[i], dotq, Lq[i]); dqb[i] = qtb[i] * dt; }
+    /* angular acceleration */
+    real taub_b[3], crb[3];
+    for (int i = 0; i < 3; ++i) { taub_b[i] = (Lo[i] * dt) * M->iJ[i]; crb[i] = -taub_b[i]; }
+    /* cr = om x Jom : om_bar += Jom x crb ; Jom_bar = crb x om */
+    real omb[3], Jb[3];
+    omb[0] = Lo[0] + FMA(A->Jom[1], crb[2], -(A->Jom[2] * crb[1]));
+    omb[1] = Lo[1] + FMA(A->Jom[2], crb[0], -(A->Jom[0] * crb[2]));
+    omb[2] = Lo[2] + FMA(A->Jom[0], crb[1], -(A->Jom[1] * crb[0]));
+    Jb[0] = FMA(crb[1], om[2], -(crb[2] * om[1]));
+    Jb[1] = FMA(crb[2], om[0], -(crb[0] * om[2]));
+    Jb[2] = FMA(crb[0], om[1], -(crb[1] * om[0]));
+    for (int i = 0; i < 3; ++i) omb[i] = FMA(M->J[i], Jb[i], omb[i]);
+    /* linear acceleration: acc = R Fb inv_mass - g e3 */
+    real Fwb[3], Fbb[3];
+    for (int i = 0; i < 3; ++i) Fwb[i] = (Lv[i] * dt) * M->inv_mass;
+    for (int j = 0; j < 3; ++j) Fbb[j] = FMA(Rm[6 + j], Fwb[2], FMA(Rm[3 + j], Fwb[1], Rm[j] * Fwb[0]));
+    /* MLP output adjoints */
+    real ob[6];
+    for (int i = 0; i < 3; ++i) { ob[i] = M->sF[i] * Fbb[i]; ob[3 + i] = M->sT[i] * taub_b[i]; }
+    *gT = Fbb[2];
+    for (int i = 0; i < 3; ++i) gtau[i] = taub_b[i];
+    /* MLP VJP (SPEC.md §5.4) */
+    real a2b[HID], a1d[HID], a1n[HID];
+    for (int k = 0; k < HID; ++k) {
+        real hb = 0;
+        for (int i = 0; i < 6; ++i) hb = FMA(M->W3[i][k], ob[i], hb);
+        a2b[k] = hb * FMA(-A->h2[k], A->h2[k], R(1));
+    }
+    for (int k = 0; k < HID; ++k) {
+        real hb = 0;
+        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int i = rowmap(r, h); hb = FMA(M->W2[i][k], a2b[i], hb); }
+        a1d[k] = hb * FMA(-A->h1d[k], A->h1d[k], R(1));
+        a1n[k] = (M->w3n[k] * ebraw) * FMA(-A->h1n[k], A->h1n[k], R(1));
+    }
+    real zb[NN];
+    for (int k = 0; k < NN; ++k) {
+        real P0 = 0, P1 = 0;
+        for (int r = 0; r < 16; ++r) { P0 = FMA(M->W1z[rowmap(r, 0)][k], a1d[rowmap(r, 0)], P0); P1 = FMA(M->W1z[rowmap(r, 1)][k], a1d[rowmap(r, 1)], P1); }
+        for (int r = 0; r < 16; ++r) { P0 = FMA(M->W1z[HID + rowmap(r, 0)][k], a1n[rowmap(r, 0)], P0); P1 = FMA(M->W1z[HID + rowmap(r, 1)][k], a1n[rowmap(r, 1)], P1); }
+        zb[k] = P0 + P1;
+    }
+    for (int j = 0; j < M->m; ++j) {
+        real P0 = 0, P1 = 0;
+        for (int r = 0; r < 16; ++r) { P0 = FMA(M->W1u[rowmap(r, 0)][j], a1d[rowmap(r, 0)], P0); P1 = FMA(M->W1u[rowmap(r, 1)][j], a1d[rowmap(r, 1)], P1); }
+        gu[j] = P0 + P1;
+    }
+    for (int i = 0; i < 3; ++i) omb[i] = omb[i] + zb[3 + i];
+    /* vb = R^T v */
+    real vbar[3];
+    for (int i = 0; i < 3; ++i) {
+        real Rvb = FMA(Rm[3 * i + 2], zb[2], FMA(Rm[3 * i + 1], zb[1], Rm[3 * i] * zb[0]));
+        vbar[i] = FMA(Lp[i], dt, Lv[i]) + Rvb;
+    }
+    /* Rbar_ij = Fwb_i Fb_j + v_i zb_j */
+    real Rb[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rb[3 * i + j] = FMA(v[i], zb[j], Fwb[i] * A->Fb[j]);
+    /* dq = 0.5 q (x) (0, om) */
+    real qb[4];
+    qb[0] = FMA(R(0.5), FMA(dqb[3], om[2], FMA(dqb[2], om[1], dqb[1] * om[0])), qtb[0]);
+    qb[1] = FMA(R(0.5), FMA(dqb[3], om[1], FMA(-dqb[2], om[2], -(dqb[0] * om[0]))), qtb[1]);
+    qb[2] = FMA(R(0.5), FMA(-dqb[3], om[0], FMA(dqb[1], om[2], -(dqb[0] * om[1]))), qtb[2]);
+    qb[3] = FMA(R(0.5), FMA(dqb[2], om[0], FMA(-dqb[1], om[1], -(dqb[0] * om[2]))), qtb[3]);
+    omb[0] = FMA(R(0.5), FMA(-dqb[3], qy, FMA(dqb[2], qz, FMA(dqb[1], qw, -(dqb[0] * qx)))), omb[0]);
+    omb[1] = FMA(R(0.5), FMA(dqb[3], qx, FMA(dqb[2], qw, FMA(-dqb[1], qz, -(dqb[0] * qy)))), omb[1]);
+    omb[2] = FMA(R(0.5), FMA(dqb[3], qw, FMA(-dqb[2], qx, FMA(dqb[1], qy, -(dqb[0] * qz)))), omb[2]);
+    /* R(q) */
+    real s01 = Rb[1] + Rb[3], d10 = Rb[3] - Rb[1];
+    real s02 = Rb[2] + Rb[6], d02 = Rb[2] - Rb[6];
+    real s12 = Rb[5] + Rb[7], d21 = Rb[7] - Rb[5];
+    qb[0] = FMA(R(2), FMA(qx, d21, FMA(qy, d02, qz * d10)), qb[0]);
+    qb[1] = FMA(R(2), FMA(qw, d21, FMA(qz, s02, qy * s01)), FMA(R(-4) * qx, Rb[4] + Rb[8], qb[1]));
+    qb[2] = FMA(R(2), FMA(qz, s12, FMA(qw, d02, qx * s01)), FMA(R(-4) * qy, Rb[0] + Rb[8], qb[2]));
+    qb[3] = FMA(R(2), FMA(qy, s12, FMA(qx, s02, qw * d10)), FMA(R(-4) * qz, Rb[0] + Rb[4], qb[3]));
+    for (int i = 0; i < 3; ++i) { lam[i] = Lp[i]; lam[3 + i] = vbar[i]; lam[10 + i] = omb[i]; }
+    for (int i = 0; i < 4; ++i) lam[6 + i] = qb[i];
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* reductions (SPEC.md §6)                                                                     */
+/* ------------------------------------------------------------------------------------------- */
+/* particle reduction: groups of 32 (xor butterfly 16,8,4,2,1), group g -> slot g%4 (sequential),
+ * total = ((S0+S1)+S2)+S3. vals has P entries. */
+static real preduce(const real* vals, int P) {
+    real S[NSLOT] = {0, 0, 0, 0};
+    int G = (P + 31) / 32;
+    for (int g = 0; g < G; ++g) {
+        real v[32];
+        for (int j = 0; j < 32; ++j) v[j] = (g * 32 + j < P) ? vals[g * 32 + j] : R(0);
+        for (int s = 16; s >= 1; s >>= 1) {
+            real w[32];
+            for (int j = 0; j < 32; ++j) w[j] = v[j] + v[j ^ s];
+            memcpy(v, w, sizeof v);
+        }
+        S[g % NSLOT] = S[g % NSLOT] + v[0];
+    }
+    return ((S[0] + S[1]) + S[2]) + S[3];
+}
+/* block dot product over N elements with 256 lanes: lane i chains e = i, i+256, ...; xor butterfly
+ * 32,16,8,4,2,1 inside each 64-lane wave; total = ((w0+w1)+w2)+w3 */
+static real dot256(const real* a, const real* b, int N) {
+    real v[256];
+    for (int i = 0; i < 256; ++i) {
+        real acc = 0;
+        for (int e = i; e < N; e += 256) acc = FMA(a[e], b ? b[e] : R(1), acc);
+        v[i] = acc;
+    }
+    for (int w = 0; w < 4; ++w)
+        for (int s = 32; s >= 1; s >>= 1) {
+            real t[64];
+            for (int j = 0; j < 64; ++j) t[j] = v[w * 64 + j] + v[w * 64 + (j ^ s)];
+            memcpy(v + w * 64, t, sizeof t);
+        }
+    return ((v[0] + v[64]) + v[128]) + v[192];
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* problem context                                                                             */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const sdempc_cfg* C;
+    model_t M;
+    int H, P, m;
+    real* dt;    /* [H] */
+    real* sdt;   /* [H][6] sigma_i * sqrt(dt) */
+    real* disc;  /* [H+1] */
+    real invP;
+} ctx_t;
+
+static int ctx_init(ctx_t* X, const sdempc_cfg* C, const void* blob) {
+    if (!C || C->struct_size != (int32_t)sizeof(sdempc_cfg)) return SDEMPC_EINVAL;
+    if (parse_blob(blob, &X->M)) return SDEMPC_EBLOB;
+    X->C = C; X->H = C->horizon; X->P = C->num_particles; X->m = C->num_motors;
+    if (X->H < 1 || X->P < 1 || X->m != X->M.m) return SDEMPC_EINVAL;
+    X->dt = (real*)malloc(sizeof(real) * X->H);
+    X->sdt = (real*)malloc(sizeof(real) * X->H * NN);
+    X->disc = (real*)malloc(sizeof(real) * (X->H + 1));
+    for (int t = 0; t < X->H; ++t) {
+        float dtf = C->time_steps[t];
+        float sq = sqrtf(dtf);
+        X->dt[t] = dtf;
+        for (int i = 0; i < NN; ++i) X->sdt[t * NN + i] = (real)((float)X->M.sigma[i] * sq);
+    }
+    /* stage weights: discount^t / H (cost is the horizon mean, SPEC.md §5.3) */
+    float d = 1.0f / (float)X->H;
+    for (int t = 0; t <= X->H; ++t) { X->disc[t] = d; d = d * C->discount; }
+    X->invP = (real)(1.0f / (float)X->P);
+    return 0;
+}
+static void ctx_free(ctx_t* X) { free(X->dt); free(X->sdt); free(X->disc); }
+
+/* control cost and its gradient (SPEC.md §5.5): element e = t*m + j */
+static real ucost(const ctx_t* X, const real* u, real* gcu) {
+    const sdempc_cfg* C = X->C;
+    int H = X->H, m = X->m, N = H * m;
+    real* ce = (real*)malloc(sizeof(real) * N);
+    real* dw = (real*)malloc(sizeof(real) * N);
+    for (int t = 0; t < H; ++t) for (int j = 0; j < m; ++j) {
+        int e = t * m + j;
+        real du = u[e] - (real)C->uref[j];
+        real a = ((real)C->uerr * du) * du;
+        dw[e] = 0;
+        if (t >= 1) {
+            real ds = u[e] - u[e - m];
+            a = FMA((real)C->u_slew_coeff * ds, ds, a);
+            real d = (R(2) * (real)C->u_slew_coeff) * ds;
+            if (C->has_slew_constr) {
+                real hi = ds - (real)C->u_slew_hi[j]; if (hi < 0) hi = 0;
+                real lo = (real)C->u_slew_lo[j] - ds; if (lo < 0) lo = 0;
+                a = FMA((real)C->u_slew_constr_coeff * hi, hi, a);
+                a = FMA((real)C->u_slew_constr_coeff * lo, lo, a);
+                d = FMA(R(2) * (real)C->u_slew_constr_coeff, hi - lo, d);
+            }
+            dw[e] = d;
+        }
+        ce[e] = X->disc[t] * a;
+    }
+    if (gcu)
+        for (int t = 0; t < H; ++t) for (int j = 0; j < m; ++j) {
+            int e = t * m + j;
+            real du = u[e] - (real)C->uref[j];
+            real g = X->disc[t] * FMA(R(2) * (real)C->uerr, du, dw[e]);
+            if (t + 1 < H) g = FMA(-X->disc[t + 1], dw[e + m], g);
+            gcu[e] = g;
+        }
+    real tot = dot256(ce, NULL, N);
+    free(ce); free(dw);
+    return tot;
+}
+
+/* rollout: expected cost; optional traj [P][H+1][13], xmean [H+1][13] (SPEC.md §5.3, §7) */
+static real rollout(const ctx_t* X, const real* x0, const real* u, const real* xref, const real* noise,
+                    real* traj, real* xmean) {
+    int H = X->H, P = X->P, m = X->m;
+    ustep_t* U = (ustep_t*)malloc(sizeof(ustep_t) * H);
+    for (int t = 0; t < H; ++t) ustep_eval(&X->M, u + t * m, &U[t]);
+    real* Jp = (real*)malloc(sizeof(real) * P);
+    real* xs = NULL;
+    if (xmean) xs = (real*)malloc(sizeof(real) * P * (H + 1) * NX);
+    stepaux_t A;
+    for (int p = 0; p < P; ++p) {
+        real x[NX], xn[NX];
+        memcpy(x, x0, sizeof x);
+        real* tp = traj ? traj + (size_t)p * (H + 1) * NX : NULL;
+        real* sp = xs ? xs + (size_t)p * (H + 1) * NX : NULL;
+        if (tp) memcpy(tp, x, sizeof x);
+        if (sp) memcpy(sp, x, sizeof x);
+        real J = 0;
+        for (int t = 0; t < H; ++t) {
+            step_fwd(&X->M, &U[t], x, noise + ((size_t)p * H + t) * NN, X->dt[t], X->sdt + t * NN, xn, &A);
+            real l = stage_cost(X->C, xn, xref + (t + 1) * NX, NULL);
+            l = FMA((real)X->C->res_mult * A.eta, A.eta, l);
+            J = FMA(X->disc[t], l, J);
+            memcpy(x, xn, sizeof x);
+            if (tp) memcpy(tp + (t + 1) * NX, x, sizeof x);
+            if (sp) memcpy(sp + (t + 1) * NX, x, sizeof x);
+        }
+        Jp[p] = J;
+    }
+    real tot = preduce(Jp, P);
+    real cu = ucost(X, u, NULL);
+    if (xmean) {
+        real* col = (real*)malloc(sizeof(real) * P);
+        for (int t = 0; t <= H; ++t) for (int i = 0; i < NX; ++i) {
+            for (int p = 0; p < P; ++p) col[p] = xs[((size_t)p * (H + 1) + t) * NX + i];
+            xmean[t * NX + i] = preduce(col, P) * X->invP;
+        }
+        free(col); free(xs);
+    }
+    free(U); free(Jp);
+    return FMA(tot, X->invP, cu);
+}
+
+/* cost + gradient wrt u by the adjoint sweep (SPEC.md §5.4, §6) */
+static real cost_grad(const ctx_t* X, const real* x0, const real* u, const real* xref, const real* noise, real* grad) {
+    int H = X->H, P = X->P, m = X->m;
+    const model_t* M = &X->M;
+    ustep_t* U = (ustep_t*)malloc(sizeof(ustep_t) * H);
+    for (int t = 0; t < H; ++t) ustep_eval(M, u + t * m, &U[t]);
+    real* traj = (real*)malloc(sizeof(real) * (size_t)P * (H + 1) * NX);
+    real* Jp = (real*)malloc(sizeof(real) * P);
+    /* per-particle, per-step adjoint outputs: [H][m+4][P] */
+    int nq = m + 4;
+    real* Q = (real*)malloc(sizeof(real) * (size_t)H * nq * P);
+    stepaux_t A;
+    for (int p = 0; p < P; ++p) {
+        real* tp = traj + (size_t)p * (H + 1) * NX;
+        memcpy(tp, x0, sizeof(real) * NX);
+        real J = 0;
+        for (int t = 0; t < H; ++t) {
+            step_fwd(M, &U[t], tp + t * NX, noise + ((size_t)p * H + t) * NN, X->dt[t], X->sdt + t * NN, tp + (t + 1) * NX, &A);
+            real l = stage_cost(X->C, tp + (t + 1) * NX, xref + (t + 1) * NX, NULL);
+            l = FMA((real)X->C->res_mult * A.eta, A.eta, l);
+            J = FMA(X->disc[t], l, J);
+        }
+        Jp[p] = J;
+        real lam[NX];
+        for (int i = 0; i < NX; ++i) lam[i] = 0;
+        for (int t = H - 1; t >= 0; --t) {
+            real xn[NX], gx[NX], L[NX], lamn[NX], gu[MAXM], gT, gtau[3];
+            step_fwd(M, &U[t], tp + t * NX, noise + ((size_t)p * H + t) * NN, X->dt[t], X->sdt + t * NN, xn, &A);
+            stage_cost(X->C, tp + (t + 1) * NX, xref + (t + 1) * NX, gx);
+            for (int i = 0; i < NX; ++i) L[i] = FMA(X->disc[t], gx[i], lam[i]);
+            real ebc = X->disc[t] * ((R(2) * (real)X->C->res_mult) * A.eta);
+            step_vjp(M, tp + t * NX, noise + ((size_t)p * H + t) * NN, X->dt[t], X->sdt + t * NN, &A, L, ebc, lamn, gu, &gT, gtau);
+            memcpy(lam, lamn, sizeof lam);
+            for (int j = 0; j < m; ++j) Q[((size_t)t * nq + j) * P + p] = gu[j];
+            Q[((size_t)t * nq + m) * P + p] = gT;
+            for (int i = 0; i < 3; ++i) Q[((size_t)t * nq + m + 1 + i) * P + p] = gtau[i];
+        }
+    }
+    real tot = preduce(Jp, P);
+    real* gcu = (real*)malloc(sizeof(real) * H * m);
+    real cu = ucost(X, u, gcu);
+    for (int t = 0; t < H; ++t) {
+        real S[MAXM + 4];
+        for (int k = 0; k < nq; ++k) S[k] = preduce(Q + ((size_t)t * nq + k) * P, P);
+        for (int j = 0; j < m; ++j) {
+            real a = S[j];
+            a = FMA(S[m], U[t].dT[j], a);
+            a = FMA(S[m + 1], M->ry[j] * U[t].dT[j], a);
+            a = FMA(S[m + 2], -(M->rx[j] * U[t].dT[j]), a);
+            a = FMA(S[m + 3], U[t].dM[j], a);
+            grad[t * m + j] = FMA(a, X->invP, gcu[t * m + j]);
+        }
+    }
+    free(U); free(traj); free(Jp); free(Q); free(gcu);
+    return FMA(tot, X->invP, cu);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* accelerated proximal gradient with Armijo backtracking (SPEC.md §8)                         */
+/* ------------------------------------------------------------------------------------------- */
+static inline real clampr(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static void solve(const ctx_t* X, const real* x0, const real* xref, const real* noise,
+                  const real* u_init, real s_in, real* uopt, real* xevol, real* info, real* trace, int trace_cap) {
+    const sdempc_cfg* C = X->C;
+    int H = X->H, m = X->m, N = H * m;
+    real *xk = malloc(sizeof(real) * N), *yk = malloc(sizeof(real) * N), *xn = malloc(sizeof(real) * N),
+         *g = malloc(sizeof(real) * N), *ub = malloc(sizeof(real) * N), *d1 = malloc(sizeof(real) * N), *d2 = malloc(sizeof(real) * N);
+    /* momentum table beta[kr] (host float32 arithmetic) */
+    int nb = C->max_iter + 2;
+    real* beta = malloc(sizeof(real) * nb);
+    for (int i = 0; i < nb; ++i) {
+        float b = (i == 0) ? C->beta_init : (float)(i + 1) / (float)(i + 4);
+        if (i > 0 && C->use_moment_scale) b = C->moment_scale * b;
+        beta[i] = b;
+    }
+    for (int e = 0; e < N; ++e) { xk[e] = clampr(u_init[e], (real)C->u_lo[e % m], (real)C->u_hi[e % m]); yk[e] = xk[e]; ub[e] = xk[e]; }
+    real c_init = rollout(X, x0, xk, xref, noise, NULL, NULL);
+    real c_x = c_init, s = s_in, gsq = 0, sum_ls = 0, sum_s = 0;
+    int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1; /* plain: yk == xk (no momentum in yk) */
+    for (int k = 0; k < C->max_iter; ++k) {
+        real c_y = cost_grad(X, x0, yk, xref, noise, g);
+        gsq = dot256(g, g, N);
+        real c_n = 0;
+        int nls = 0;
+        if (C->ls_maxls > 0) {
+            if (k > 0 && C->ls_reset_option == 1) s = s * (real)C->ls_increase_factor;
+            if (s > (real)C->ls_max_stepsize) s = (real)C->ls_max_stepsize;
+            for (int j = 0; j < C->ls_maxls; ++j) {
+                for (int e = 0; e < N; ++e) { xn[e] = clampr(FMA(-s, g[e], yk[e]), (real)C->u_lo[e % m], (real)C->u_hi[e % m]); d1[e] = xn[e] - yk[e]; }
+                c_n = rollout(X, x0, xn, xref, noise, NULL, NULL);
+                real gd = dot256(g, d1, N);
+                nls = j + 1;
+                if (c_n <= FMA((real)C->ls_coef, gd, c_y)) break;
+                if (j < C->ls_maxls - 1) s = s * (real)C->ls_decrease_factor;
+            }
+        } else {
+            s = (real)C->stepsize;
+            for (int e = 0; e < N; ++e) xn[e] = clampr(FMA(-s, g[e], yk[e]), (real)C->u_lo[e % m], (real)C->u_hi[e % m]);
+            c_n = rollout(X, x0, xn, xref, noise, NULL, NULL);
+            nls = 1;
+        }
+        sum_ls = sum_ls + (real)nls; sum_s = sum_s + s; nit = k + 1; nls_tot += nls;
+        if (trace && k < trace_cap) { trace[4 * k] = c_y; trace[4 * k + 1] = c_n; trace[4 * k + 2] = s; trace[4 * k + 3] = (real)nls; }
+        int stop = (FABS(c_n - c_x) <= FMA((real)C->rtol, FABS(c_x), (real)C->atol));
+        if (c_n < c_x) {
+            /* monotone acceptance: the new iterate lowers the cost of the current one */
+            for (int e = 0; e < N; ++e) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
+            real rs = dot256(d1, d2, N);
+            if (rs > 0) { /* adaptive restart, gradient scheme */
+                kr = 0; plain = 1;
+                for (int e = 0; e < N; ++e) yk[e] = xn[e];
+            } else {
+                real b = beta[kr];
+                for (int e = 0; e < N; ++e) yk[e] = clampr(FMA(b, d2[e], xn[e]), (real)C->u_lo[e % m], (real)C->u_hi[e % m]);
+                kr = kr + 1; plain = 0;
+            }
+            c_x = c_n; noimp = 0;
+            memcpy(xk, xn, sizeof(real) * N);
+        } else {
+            /* no decrease: drop the momentum and retry from xk with the (already shrunk) step size;
+             * only a failed plain gradient step may signal convergence */
+            if (!plain) stop = 0;
+            kr = 0; plain = 1;
+            memcpy(yk, xk, sizeof(real) * N);
+            noimp = noimp + 1;
+        }
+        if (noimp >= C->max_no_improvement_iter) stop = 1;
+        if (stop) break;
+    }
+    real c_best = c_x;
+    memcpy(ub, xk, sizeof(real) * N);
+    memcpy(uopt, ub, sizeof(real) * N);
+    rollout(X, x0, ub, xref, noise, NULL, xevol);
+    info[0] = nit ? (real)((float)sum_ls / (float)nit) : 0;
+    info[1] = s;
+    info[2] = (real)nit;
+    info[3] = gsq;
+    info[4] = nit ? (real)((float)sum_s / (float)nit) : 0;
+    info[5] = c_init;
+    info[6] = c_best;
+    info[7] = (real)nls_tot;
+    free(xk); free(yk); free(xn); free(g); free(ub); free(d1); free(d2); free(beta);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* exported API (float I/O in both builds)                                                     */
+/* ------------------------------------------------------------------------------------------- */
+static real* to_real(const float* a, size_t n) { real* r = malloc(sizeof(real) * n); for (size_t i = 0; i < n; ++i) r[i] = a[i]; return r; }
+
+int NAME(rollout)(const sdempc_cfg* C, const void* blob, const float* x0, const float* u, const float* xref,
+                  const float* noise, double* cost, float* traj, float* xmean) {
+    ctx_t X; int rc = ctx_init(&X, C, blob); if (rc) return rc;
+    int H = X.H, P = X.P, m = X.m;
+    real *rx0 = to_real(x0, NX), *ru = to_real(u, H * m), *rxr = to_real(xref, (H + 1) * NX), *rn = to_real(noise, (size_t)P * H * NN);
+    real* rt = traj ? malloc(sizeof(real) * (size_t)P * (H + 1) * NX) : NULL;
+    real* rm = xmean ? malloc(sizeof(real) * (H + 1) * NX) : NULL;
+    *cost = (double)rollout(&X, rx0, ru, rxr, rn, rt, rm);
+    if (rt) { for (size_t i = 0; i < (size_t)P * (H + 1) * NX; ++i) traj[i] = (float)rt[i]; free(rt); }
+    if (rm) { for (int i = 0; i < (H + 1) * NX; ++i) xmean[i] = (float)rm[i]; free(rm); }
+    free(rx0); free(ru); free(rxr); free(rn); ctx_free(&X);
+    return 0;
+}
+
+int NAME(grad)(const sdempc_cfg* C, const void* blob, const float* x0, const float* u, const float* xref,
+               const float* noise, double* cost, double* grad) {
+    ctx_t X; int rc = ctx_init(&X, C, blob); if (rc) return rc;
+    int H = X.H, P = X.P, m = X.m;
+    real *rx0 = to_real(x0, NX), *ru = to_real(u, H * m), *rxr = to_real(xref, (H + 1) * NX), *rn = to_real(noise, (size_t)P * H * NN);
+    real* g = malloc(sizeof(real) * H * m);
+    *cost = (double)cost_grad(&X, rx0, ru, rxr, rn, g);
+    for (int i = 0; i < H * m; ++i) grad[i] = (double)g[i];
+    free(g); free(rx0); free(ru); free(rxr); free(rn); ctx_free(&X);
+    return 0;
+}
+
+/* cost as a function of double-precision u (finite-difference tests, ORC_DOUBLE build only keeps the
+ * precision; in the float build u is rounded to float) */
+int NAME(cost_du)(const sdempc_cfg* C, const void* blob, const float* x0, const double* u, const float* xref,
+                  const float* noise, double* cost) {
+    ctx_t X; int rc = ctx_init(&X, C, blob); if (rc) return rc;
+    int H = X.H, P = X.P, m = X.m;
+    real *rx0 = to_real(x0, NX), *rxr = to_real(xref, (H + 1) * NX), *rn = to_real(noise, (size_t)P * H * NN);
+    real* ru = malloc(sizeof(real) * H * m);
+    for (int i = 0; i < H * m; ++i) ru[i] = (real)u[i];
+    *cost = (double)rollout(&X, rx0, ru, rxr, rn, NULL, NULL);
+    free(ru); free(rx0); free(rxr); free(rn); ctx_free(&X);
+    return 0;
+}
+
+int NAME(solve)(const sdempc_cfg* C, const void* blob, const float* x0, const float* xref, const float* noise,
+                const float* u_init, float stepsize_in, float* uopt, float* xevol, float* info8,
+                float* trace /* [trace_cap][4] or NULL */, int trace_cap) {
+    ctx_t X; int rc = ctx_init(&X, C, blob); if (rc) return rc;
+    int H = X.H, P = X.P, m = X.m;
+    real *rx0 = to_real(x0, NX), *rxr = to_real(xref, (H + 1) * NX), *rn = to_real(noise, (size_t)P * H * NN), *rui = to_real(u_init, H * m);
+    real *ruo = malloc(sizeof(real) * H * m), *rxe = malloc(sizeof(real) * (H + 1) * NX), rinfo[8];
+    real* rtr = trace ? calloc((size_t)trace_cap * 4, sizeof(real)) : NULL;
+    solve(&X, rx0, rxr, rn, rui, (real)stepsize_in, ruo, rxe, rinfo, rtr, trace_cap);
+    for (int i = 0; i < H * m; ++i) uopt[i] = (float)ruo[i];
+    for (int i = 0; i < (H + 1) * NX; ++i) xevol[i] = (float)rxe[i];
+    for (int i = 0; i < 8; ++i) info8[i] = (float)rinfo[i];
+    if (trace) { for (int i = 0; i < trace_cap * 4; ++i) trace[i] = (float)rtr[i]; free(rtr); }
+    free(rx0); free(rxr); free(rn); free(rui); free(ruo); free(rxe); ctx_free(&X);
+    return 0;
+}
+
+/* batch of independent solves, one after another on the calling thread (cpu_baseline timing) */
+int NAME(solve_batch)(const sdempc_cfg* C, const void* blob, int B, const float* x0, const float* xref, const float* noise,
+                      const float* u_init, const float* stepsize_in, float* uopt, float* xevol, float* info8) {
+    int H = C->horizon, P = C->num_particles, m = C->num_motors;
+    for (int b = 0; b < B; ++b) {
+        int rc = NAME(solve)(C, blob, x0 + (size_t)b * NX, xref + (size_t)b * (H + 1) * NX, noise + (size_t)b * P * H * NN,
+                             u_init + (size_t)b * H * m, stepsize_in[b], uopt + (size_t)b * H * m, xevol + (size_t)b * (H + 1) * NX,
+                             info8 + (size_t)b * 8, NULL, 0);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* single EM step and its VJP, exposed for unit tests */
+int NAME(step)(const sdempc_cfg* C, const void* blob, const float* x, const float* u, const float* xi, int t, float* xn, float* eta) {
+    ctx_t X; int rc = ctx_init(&X, C, blob); if (rc) return rc;
+    real *rx = to_real(x, NX), *ru = to_real(u, X.m), *rxi = to_real(xi, NN), out[NX];
+    ustep_t U; stepaux_t A;
+    ustep_eval(&X.M, ru, &U);
+    step_fwd(&X.M, &U, rx, rxi, X.dt[t], X.sdt + t * NN, out, &A);
+    for (int i = 0; i < NX; ++i) xn[i] = (float)out[i];
+    *eta = (float)A.eta;
+    free(rx); free(ru); free(rxi); ctx_free(&X);
+    return 0;
+}

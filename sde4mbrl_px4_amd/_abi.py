@@ -1,0 +1,110 @@
+"""ctypes mirror of include/sdempc.h (struct layouts + library loader)."""
+import ctypes as C
+import os
+
+NX = 13
+NNOISE = 6
+MAX_MOTORS = 8
+HID = 32
+BLOB_MAGIC = 0x31454453
+BLOB_HEADER_INTS = 16
+BLOB_FLOATS = 2120
+
+_F8 = C.c_float * MAX_MOTORS
+_F3 = C.c_float * 3
+
+
+class SdempcCfg(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("horizon", C.c_int32),
+        ("num_particles", C.c_int32),
+        ("num_motors", C.c_int32),
+        ("time_steps", C.POINTER(C.c_float)),
+        ("discount", C.c_float),
+        ("uref", _F8),
+        ("uerr", C.c_float),
+        ("perr", _F3), ("verr", _F3), ("qerr", _F3), ("werr", _F3),
+        ("res_mult", C.c_float),
+        ("u_slew_coeff", C.c_float),
+        ("has_slew_constr", C.c_int32),
+        ("u_slew_lo", _F8), ("u_slew_hi", _F8),
+        ("u_slew_constr_coeff", C.c_float),
+        ("u_lo", _F8), ("u_hi", _F8),
+        ("max_iter", C.c_int32),
+        ("max_no_improvement_iter", C.c_int32),
+        ("use_moment_scale", C.c_int32),
+        ("moment_scale", C.c_float),
+        ("beta_init", C.c_float),
+        ("atol", C.c_float), ("rtol", C.c_float),
+        ("stepsize", C.c_float),
+        ("ls_init_stepsize", C.c_float), ("ls_max_stepsize", C.c_float), ("ls_coef", C.c_float),
+        ("ls_decrease_factor", C.c_float), ("ls_increase_factor", C.c_float),
+        ("ls_reset_option", C.c_int32),
+        ("ls_maxls", C.c_int32),
+    ]
+
+
+class SdempcInfo(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "avg_linesearch", "stepsize", "num_steps", "grad_sqr", "avg_stepsize", "init_cost", "opt_cost",
+        "num_ls_trials")]
+
+
+INFO_FIELDS = [f[0] for f in SdempcInfo._fields_]
+
+_LIB = None
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdempc.so")
+
+
+def load_library():
+    """Load csrc/libsdempc.so. Fails loudly: there is no CPU fallback for the product path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C sde4mbrl_px4_amd/csrc). sde4mbrl_px4_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, i32, fp = C.c_void_p, C.c_int32, C.POINTER(C.c_float)
+    lib.sdempc_create.argtypes = [C.POINTER(SdempcCfg), vp, C.c_size_t, i32, C.POINTER(vp)]
+    lib.sdempc_create.restype = C.c_int
+    lib.sdempc_destroy.argtypes = [vp]
+    lib.sdempc_destroy.restype = None
+    lib.sdempc_last_error.argtypes = [vp]
+    lib.sdempc_last_error.restype = C.c_char_p
+    lib.sdempc_abi_version.restype = C.c_int
+    lib.sdempc_set_device.argtypes = [vp, i32]
+    lib.sdempc_reset.argtypes = [vp, fp, fp, fp, C.POINTER(SdempcInfo)]
+    lib.sdempc_rollout_batch.argtypes = [vp, i32, fp, fp, fp, fp, fp, fp, fp]
+    lib.sdempc_grad_batch.argtypes = [vp, i32, fp, fp, fp, fp, fp, fp]
+    lib.sdempc_solve_batch.argtypes = [vp, i32, fp, fp, fp, fp, fp, fp, fp, C.POINTER(SdempcInfo)]
+    lib.sdempc_noise_dev_floats.argtypes = [vp, i32]
+    lib.sdempc_noise_dev_floats.restype = C.c_size_t
+    lib.sdempc_traj_dev_floats.argtypes = [vp, i32]
+    lib.sdempc_traj_dev_floats.restype = C.c_size_t
+    lib.sdempc_noise_to_device_layout.argtypes = [vp, i32, fp, fp]
+    lib.sdempc_solve_batch_dev.argtypes = [vp, i32] + [vp] * 9
+    lib.sdempc_rollout_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.sdempc_grad_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.sdempc_last_kernel_ms.argtypes = [vp]
+    lib.sdempc_last_kernel_ms.restype = C.c_float
+    for name in ("sdempc_set_device", "sdempc_reset", "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch",
+                 "sdempc_noise_to_device_layout", "sdempc_solve_batch_dev", "sdempc_rollout_batch_dev",
+                 "sdempc_grad_batch_dev"):
+        getattr(lib, name).restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "sdempc_create", "sdempc_destroy", "sdempc_last_error", "sdempc_abi_version", "sdempc_set_device", "sdempc_reset",
+    "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch", "sdempc_noise_dev_floats",
+    "sdempc_traj_dev_floats", "sdempc_noise_to_device_layout", "sdempc_solve_batch_dev", "sdempc_rollout_batch_dev",
+    "sdempc_grad_batch_dev", "sdempc_last_kernel_ms",
+]

@@ -1,0 +1,401 @@
+// sdempc_api.cpp — C ABI (include/sdempc.h) over the HIP kernels in sdempc_kernels.hip.
+//
+// Reference-side counterpart: the solver objects built in SDEControlROS.load_single_mpc
+// (sde4mbrl_px4/mpc_controller/sde_control.py:681-721) and used by mpc_process_fn (:328-450).
+// Host logic only: argument checking, table construction (time grid, discount, momentum), lazy HIP
+// context creation (the reference builds its solvers before fork(), sde_control.py:69-75), staging
+// buffers for the host-pointer entry points and layout conversion. No arithmetic of the hot path
+// runs on the host and there is no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sdempc.h"
+#include "sdempc_kernels.h"
+
+using namespace sdempc;
+
+namespace {
+std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+}  // namespace
+
+struct sdempc_handle {
+    sdempc_cfg cfg;
+    std::vector<float> time_steps;
+    std::vector<float> blob_f;  // float payload of the model blob
+    int m = 0, H = 0, P = 0, G = 0, max_batch = 0;
+    int device = 0;
+    bool dev_ready = false;
+    std::string err;
+    KArgs base;
+    // host tables
+    std::vector<float> h_sdt, h_disc, h_beta;
+    // device tables
+    DevBuf d_dt, d_sdt, d_disc, d_beta, d_wts;
+    // workspace + staging (sized for max_batch)
+    DevBuf d_traj, d_x0, d_u, d_xref, d_noise, d_step, d_cost, d_grad, d_xmean, d_uopt, d_info;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::vector<float> h_noise_stage, h_traj_stage;
+};
+
+namespace {
+
+int fail(sdempc_handle* h, int code, const char* fmt, const char* detail = "") {
+    char buf[512];
+    snprintf(buf, sizeof buf, fmt, detail);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                 \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            char b__[400];                                                              \
+            snprintf(b__, sizeof b__, "%s failed: %s", #call, hipGetErrorString(e__)); \
+            (h)->err = b__;                                                             \
+            return SDEMPC_EDEVICE;                                                      \
+        }                                                                               \
+    } while (0)
+
+int dev_alloc(sdempc_handle* h, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    HIPCHK(h, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return 0;
+}
+void dev_free(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+size_t noise_floats(const sdempc_handle* h, int B) { return (size_t)B * h->G * h->H * SDEMPC_NNOISE * 32; }
+size_t traj_floats(const sdempc_handle* h, int B) { return (size_t)B * h->G * (h->H + 1) * SDEMPC_NX * 32; }
+
+int ensure_device(sdempc_handle* h) {
+    if (h->dev_ready) {
+        HIPCHK(h, hipSetDevice(h->device));
+        return 0;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(h, SDEMPC_EDEVICE, "no HIP device available (%s); sdempc has no CPU fallback", hipGetErrorString(e));
+    if (h->device >= n) return fail(h, SDEMPC_EDEVICE, "device ordinal out of range%s");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreate(&h->ev0));
+    HIPCHK(h, hipEventCreate(&h->ev1));
+    const int H = h->H, m = h->m, B = h->max_batch;
+    int rc;
+    if ((rc = dev_alloc(h, h->d_dt, sizeof(float) * H))) return rc;
+    if ((rc = dev_alloc(h, h->d_sdt, sizeof(float) * H * SDEMPC_NNOISE))) return rc;
+    if ((rc = dev_alloc(h, h->d_disc, sizeof(float) * (H + 1)))) return rc;
+    if ((rc = dev_alloc(h, h->d_beta, sizeof(float) * h->h_beta.size()))) return rc;
+    if ((rc = dev_alloc(h, h->d_wts, sizeof(float) * h->blob_f.size()))) return rc;
+    HIPCHK(h, hipMemcpy(h->d_dt.p, h->time_steps.data(), sizeof(float) * H, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_sdt.p, h->h_sdt.data(), sizeof(float) * H * SDEMPC_NNOISE, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_disc.p, h->h_disc.data(), sizeof(float) * (H + 1), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_beta.p, h->h_beta.data(), sizeof(float) * h->h_beta.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->d_wts.p, h->blob_f.data(), sizeof(float) * h->blob_f.size(), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(h, h->d_traj, sizeof(float) * traj_floats(h, B)))) return rc;
+    HIPCHK(h, hipMemset(h->d_traj.p, 0, h->d_traj.bytes));
+    if ((rc = dev_alloc(h, h->d_x0, sizeof(float) * B * SDEMPC_NX))) return rc;
+    if ((rc = dev_alloc(h, h->d_u, sizeof(float) * B * H * m))) return rc;
+    if ((rc = dev_alloc(h, h->d_xref, sizeof(float) * B * (H + 1) * SDEMPC_NX))) return rc;
+    if ((rc = dev_alloc(h, h->d_noise, sizeof(float) * noise_floats(h, B)))) return rc;
+    if ((rc = dev_alloc(h, h->d_step, sizeof(float) * B))) return rc;
+    if ((rc = dev_alloc(h, h->d_cost, sizeof(float) * B))) return rc;
+    if ((rc = dev_alloc(h, h->d_grad, sizeof(float) * B * H * m))) return rc;
+    if ((rc = dev_alloc(h, h->d_xmean, sizeof(float) * B * (H + 1) * SDEMPC_NX))) return rc;
+    if ((rc = dev_alloc(h, h->d_uopt, sizeof(float) * B * H * m))) return rc;
+    if ((rc = dev_alloc(h, h->d_info, sizeof(float) * B * 8))) return rc;
+    h->base.dt = (const float*)h->d_dt.p;
+    h->base.sdt = (const float*)h->d_sdt.p;
+    h->base.disc = (const float*)h->d_disc.p;
+    h->base.beta = (const float*)h->d_beta.p;
+    h->base.wts = (const float*)h->d_wts.p;
+    h->base.traj = (float*)h->d_traj.p;
+    h->dev_ready = true;
+    return 0;
+}
+
+int check_batch(sdempc_handle* h, int B) {
+    if (!h) return SDEMPC_EINVAL;
+    if (B < 1) return fail(h, SDEMPC_EINVAL, "batch must be >= 1%s");
+    if (B > h->max_batch) return fail(h, SDEMPC_ECAPACITY, "batch exceeds max_batch given to sdempc_create%s");
+    return 0;
+}
+
+void noise_to_dev_layout(const sdempc_handle* h, int B, const float* in, float* out) {
+    const int P = h->P, H = h->H, G = h->G;
+    memset(out, 0, sizeof(float) * noise_floats(h, B));
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < P; ++p) {
+            const int g = p / 32, l = p % 32;
+            for (int t = 0; t < H; ++t)
+                for (int i = 0; i < SDEMPC_NNOISE; ++i)
+                    out[((((size_t)b * G + g) * H + t) * SDEMPC_NNOISE + i) * 32 + l] = in[(((size_t)b * P + p) * H + t) * SDEMPC_NNOISE + i];
+        }
+}
+
+int stage_common(sdempc_handle* h, int B, const float* x0, const float* u, const float* xref, const float* noise) {
+    const int H = h->H, m = h->m;
+    HIPCHK(h, hipMemcpyAsync(h->d_x0.p, x0, sizeof(float) * B * SDEMPC_NX, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_u.p, u, sizeof(float) * B * H * m, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_xref.p, xref, sizeof(float) * B * (H + 1) * SDEMPC_NX, hipMemcpyHostToDevice, h->stream));
+    h->h_noise_stage.resize(noise_floats(h, B));
+    noise_to_dev_layout(h, B, noise, h->h_noise_stage.data());
+    HIPCHK(h, hipMemcpyAsync(h->d_noise.p, h->h_noise_stage.data(), sizeof(float) * noise_floats(h, B), hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+template <class F>
+int timed_launch(sdempc_handle* h, hipStream_t st, F&& f) {
+    HIPCHK(h, hipEventRecord(h->ev0, st));
+    hipError_t e = f();
+    if (e != hipSuccess) return fail(h, SDEMPC_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+    HIPCHK(h, hipEventRecord(h->ev1, st));
+    h->timed = true;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sdempc_abi_version(void) { return 1; }
+
+const char* sdempc_last_error(const sdempc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_bytes, int32_t max_batch, sdempc_handle** out) {
+    if (!out) return fail(nullptr, SDEMPC_EINVAL, "out is NULL%s");
+    *out = nullptr;
+    if (!cfg || cfg->struct_size != (int32_t)sizeof(sdempc_cfg)) return fail(nullptr, SDEMPC_EINVAL, "cfg NULL or struct_size mismatch%s");
+    if (!model_blob || blob_bytes < sizeof(int32_t) * SDEMPC_BLOB_HEADER_INTS + sizeof(float) * SDEMPC_BLOB_FLOATS)
+        return fail(nullptr, SDEMPC_EBLOB, "model blob too small%s");
+    const int32_t* hd = (const int32_t*)model_blob;
+    if (hd[0] != SDEMPC_BLOB_MAGIC || hd[1] != 1 || hd[3] != SDEMPC_HID || hd[4] != 6 || hd[5] != SDEMPC_NNOISE)
+        return fail(nullptr, SDEMPC_EBLOB, "model blob header mismatch%s");
+    const int m = hd[2];
+    if (m < 1 || m > SDEMPC_MAX_MOTORS || m != cfg->num_motors) return fail(nullptr, SDEMPC_EINVAL, "num_motors of cfg and model blob differ or out of range%s");
+    if (cfg->horizon < 1 || cfg->horizon > 4096 || cfg->num_particles < 1 || !cfg->time_steps || max_batch < 1)
+        return fail(nullptr, SDEMPC_EINVAL, "horizon/num_particles/time_steps/max_batch invalid%s");
+    if (cfg->max_iter < 0 || cfg->ls_maxls < 0 || cfg->max_no_improvement_iter < 1) return fail(nullptr, SDEMPC_EINVAL, "apg parameters invalid%s");
+    for (int t = 0; t < cfg->horizon; ++t)
+        if (!(cfg->time_steps[t] > 0.0f)) return fail(nullptr, SDEMPC_EINVAL, "time_steps must be positive%s");
+    if (smem_bytes(cfg->horizon, m) > 160 * 1024) return fail(nullptr, SDEMPC_EINVAL, "horizon too large for one workgroup's LDS (160 KiB)%s");
+    sdempc_handle* h = new (std::nothrow) sdempc_handle();
+    if (!h) return fail(nullptr, SDEMPC_ENOMEM, "out of memory%s");
+    h->cfg = *cfg;
+    h->H = cfg->horizon; h->P = cfg->num_particles; h->m = m; h->G = (h->P + 31) / 32; h->max_batch = max_batch;
+    h->time_steps.assign(cfg->time_steps, cfg->time_steps + h->H);
+    h->cfg.time_steps = h->time_steps.data();
+    const float* f = (const float*)(hd + SDEMPC_BLOB_HEADER_INTS);
+    h->blob_f.assign(f, f + SDEMPC_BLOB_FLOATS);
+    // tables (SPEC.md §5: float32 host arithmetic)
+    const float* sigma = f + 48;
+    h->h_sdt.resize((size_t)h->H * SDEMPC_NNOISE);
+    for (int t = 0; t < h->H; ++t) {
+        float sq = sqrtf(h->time_steps[t]);
+        for (int i = 0; i < SDEMPC_NNOISE; ++i) h->h_sdt[(size_t)t * SDEMPC_NNOISE + i] = sigma[i] * sq;
+    }
+    h->h_disc.resize(h->H + 1);
+    float d = 1.0f / (float)h->H;
+    for (int t = 0; t <= h->H; ++t) { h->h_disc[t] = d; d = d * cfg->discount; }
+    h->h_beta.resize(cfg->max_iter + 2);
+    for (int i = 0; i < cfg->max_iter + 2; ++i) {
+        float b = (i == 0) ? cfg->beta_init : (float)(i + 1) / (float)(i + 4);
+        if (i > 0 && cfg->use_moment_scale) b = cfg->moment_scale * b;
+        h->h_beta[i] = b;
+    }
+    // kernel argument block
+    KArgs& a = h->base;
+    memset(&a, 0, sizeof a);
+    a.H = h->H; a.P = h->P; a.m = m; a.G = h->G;
+    a.invP = 1.0f / (float)h->P;
+    a.M.inv_mass = f[0]; a.M.grav = f[1];
+    for (int i = 0; i < 3; ++i) { a.M.J[i] = f[2 + i]; a.M.iJ[i] = f[5 + i]; }
+    a.M.ct2 = f[8]; a.M.ct1 = f[9]; a.M.ct0 = f[10]; a.M.cm2 = f[11]; a.M.cm1 = f[12];
+    for (int j = 0; j < 8; ++j) { a.M.rx[j] = f[16 + j]; a.M.ry[j] = f[24 + j]; a.M.dir[j] = f[32 + j]; }
+    for (int i = 0; i < 3; ++i) { a.M.sF[i] = f[40 + i]; a.M.sT[i] = f[43 + i]; }
+    const int off_b3 = 56 + 384 + 64 + 256 + 1024 + 32 + 256;
+    for (int i = 0; i < 6; ++i) a.M.b3[i] = f[off_b3 + i];
+    a.M.b3n = f[off_b3 + 8 + 32];
+    for (int i = 0; i < 3; ++i) { a.C.perr[i] = cfg->perr[i]; a.C.verr[i] = cfg->verr[i]; a.C.qerr[i] = cfg->qerr[i]; a.C.werr[i] = cfg->werr[i]; }
+    a.C.res_mult = cfg->res_mult; a.C.uerr = cfg->uerr; a.C.slew = cfg->u_slew_coeff; a.C.slew_cc = cfg->u_slew_constr_coeff;
+    a.C.has_sc = cfg->has_slew_constr;
+    for (int j = 0; j < 8; ++j) {
+        a.C.slew_lo[j] = cfg->u_slew_lo[j]; a.C.slew_hi[j] = cfg->u_slew_hi[j]; a.C.uref[j] = cfg->uref[j];
+        a.C.ulo[j] = cfg->u_lo[j]; a.C.uhi[j] = cfg->u_hi[j];
+    }
+    a.A.max_iter = cfg->max_iter; a.A.max_noimp = cfg->max_no_improvement_iter; a.A.maxls = cfg->ls_maxls;
+    a.A.reset_inc = cfg->ls_reset_option == 1;
+    a.A.atol = cfg->atol; a.A.rtol = cfg->rtol; a.A.stepsize = cfg->stepsize; a.A.smax = cfg->ls_max_stepsize;
+    a.A.coef = cfg->ls_coef; a.A.dec = cfg->ls_decrease_factor; a.A.inc = cfg->ls_increase_factor;
+    *out = h;
+    return SDEMPC_OK;
+}
+
+void sdempc_destroy(sdempc_handle* h) {
+    if (!h) return;
+    if (h->dev_ready) {
+        (void)hipSetDevice(h->device);
+        for (DevBuf* b : {&h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise,
+                          &h->d_step, &h->d_cost, &h->d_grad, &h->d_xmean, &h->d_uopt, &h->d_info})
+            dev_free(*b);
+        if (h->ev0) (void)hipEventDestroy(h->ev0);
+        if (h->ev1) (void)hipEventDestroy(h->ev1);
+        if (h->stream) (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+int sdempc_set_device(sdempc_handle* h, int32_t device) {
+    if (!h) return SDEMPC_EINVAL;
+    if (h->dev_ready) return fail(h, SDEMPC_EINVAL, "sdempc_set_device must precede the first device call%s");
+    if (device < 0) return fail(h, SDEMPC_EINVAL, "negative device ordinal%s");
+    h->device = device;
+    return SDEMPC_OK;
+}
+
+int sdempc_reset(sdempc_handle* h, const float* x, const float* xdes, float* yk, sdempc_info* info) {
+    if (!h || !yk || !info) return SDEMPC_EINVAL;
+    (void)x; (void)xdes;
+    for (int t = 0; t < h->H; ++t)
+        for (int j = 0; j < h->m; ++j) yk[t * h->m + j] = h->cfg.uref[j];
+    memset(info, 0, sizeof *info);
+    info->stepsize = h->cfg.ls_maxls > 0 ? h->cfg.ls_init_stepsize : h->cfg.stepsize;
+    return SDEMPC_OK;
+}
+
+size_t sdempc_noise_dev_floats(const sdempc_handle* h, int32_t B) { return h ? noise_floats(h, B) : 0; }
+size_t sdempc_traj_dev_floats(const sdempc_handle* h, int32_t B) { return h ? traj_floats(h, B) : 0; }
+
+int sdempc_noise_to_device_layout(const sdempc_handle* h, int32_t B, const float* noise_host, float* out_host) {
+    if (!h || !noise_host || !out_host || B < 1) return SDEMPC_EINVAL;
+    noise_to_dev_layout(h, B, noise_host, out_host);
+    return SDEMPC_OK;
+}
+
+int sdempc_rollout_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* u_dev, const void* xref_dev, const void* noise_dev,
+                             void* cost_dev, void* xmean_dev, int32_t store_traj, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!x0_dev || !u_dev || !xref_dev || !noise_dev || !cost_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    KArgs a = h->base;
+    a.x0 = (const float*)x0_dev; a.u = (const float*)u_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
+    a.cost = (float*)cost_dev; a.xmean = (float*)xmean_dev; a.store_traj = store_traj;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return timed_launch(h, st, [&] { return launch_rollout(a, B, st); });
+}
+
+int sdempc_grad_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* u_dev, const void* xref_dev, const void* noise_dev,
+                          void* cost_dev, void* grad_dev, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!x0_dev || !u_dev || !xref_dev || !noise_dev || !cost_dev || !grad_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    KArgs a = h->base;
+    a.x0 = (const float*)x0_dev; a.u = (const float*)u_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
+    a.cost = (float*)cost_dev; a.grad = (float*)grad_dev;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return timed_launch(h, st, [&] { return launch_grad(a, B, st); });
+}
+
+int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* xref_dev, const void* noise_dev, const void* u_init_dev,
+                           const void* stepsize_dev, void* uopt_dev, void* xevol_dev, void* info_dev, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!x0_dev || !xref_dev || !noise_dev || !u_init_dev || !stepsize_dev || !uopt_dev || !xevol_dev || !info_dev)
+        return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    KArgs a = h->base;
+    a.x0 = (const float*)x0_dev; a.u = (const float*)u_init_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
+    a.stepsize_in = (const float*)stepsize_dev; a.uopt = (float*)uopt_dev; a.xmean = (float*)xevol_dev; a.info = (float*)info_dev;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return timed_launch(h, st, [&] { return launch_solve(a, B, st); });
+}
+
+float sdempc_last_kernel_ms(const sdempc_handle* h) {
+    if (!h || !h->timed) return -1.0f;
+    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+int sdempc_rollout_batch(sdempc_handle* h, int32_t B, const float* x0, const float* u, const float* xref, const float* noise, float* cost,
+                         float* traj, float* xmean) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!x0 || !u || !xref || !noise || !cost) return fail(h, SDEMPC_EINVAL, "NULL host pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    if ((rc = stage_common(h, B, x0, u, xref, noise))) return rc;
+    rc = sdempc_rollout_batch_dev(h, B, h->d_x0.p, h->d_u.p, h->d_xref.p, h->d_noise.p, h->d_cost.p, xmean ? h->d_xmean.p : nullptr, traj ? 1 : 0, h->stream);
+    if (rc) return rc;
+    const int H = h->H, P = h->P, G = h->G;
+    HIPCHK(h, hipMemcpyAsync(cost, h->d_cost.p, sizeof(float) * B, hipMemcpyDeviceToHost, h->stream));
+    if (xmean) HIPCHK(h, hipMemcpyAsync(xmean, h->d_xmean.p, sizeof(float) * B * (H + 1) * SDEMPC_NX, hipMemcpyDeviceToHost, h->stream));
+    if (traj) {
+        h->h_traj_stage.resize(traj_floats(h, B));
+        HIPCHK(h, hipMemcpyAsync(h->h_traj_stage.data(), h->d_traj.p, sizeof(float) * traj_floats(h, B), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (traj) {
+        const float* s = h->h_traj_stage.data();
+        for (int b = 0; b < B; ++b)
+            for (int p = 0; p < P; ++p)
+                for (int t = 0; t <= H; ++t)
+                    for (int i = 0; i < SDEMPC_NX; ++i)
+                        traj[(((size_t)b * P + p) * (H + 1) + t) * SDEMPC_NX + i] = s[((((size_t)b * G + p / 32) * (H + 1) + t) * SDEMPC_NX + i) * 32 + p % 32];
+    }
+    return SDEMPC_OK;
+}
+
+int sdempc_grad_batch(sdempc_handle* h, int32_t B, const float* x0, const float* u, const float* xref, const float* noise, float* cost, float* grad) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!x0 || !u || !xref || !noise || !cost || !grad) return fail(h, SDEMPC_EINVAL, "NULL host pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    if ((rc = stage_common(h, B, x0, u, xref, noise))) return rc;
+    rc = sdempc_grad_batch_dev(h, B, h->d_x0.p, h->d_u.p, h->d_xref.p, h->d_noise.p, h->d_cost.p, h->d_grad.p, h->stream);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(cost, h->d_cost.p, sizeof(float) * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(grad, h->d_grad.p, sizeof(float) * B * h->H * h->m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SDEMPC_OK;
+}
+
+int sdempc_solve_batch(sdempc_handle* h, int32_t B, const float* x0, const float* xref, const float* noise, const float* u_init,
+                       const float* stepsize_in, float* uopt, float* xevol, sdempc_info* info) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!x0 || !xref || !noise || !u_init || !stepsize_in || !uopt || !xevol || !info) return fail(h, SDEMPC_EINVAL, "NULL host pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    if ((rc = stage_common(h, B, x0, u_init, xref, noise))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_step.p, stepsize_in, sizeof(float) * B, hipMemcpyHostToDevice, h->stream));
+    rc = sdempc_solve_batch_dev(h, B, h->d_x0.p, h->d_xref.p, h->d_noise.p, h->d_u.p, h->d_step.p, h->d_uopt.p, h->d_xmean.p, h->d_info.p, h->stream);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(uopt, h->d_uopt.p, sizeof(float) * B * h->H * h->m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(xevol, h->d_xmean.p, sizeof(float) * B * (h->H + 1) * SDEMPC_NX, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof(float) * B * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SDEMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// sdempc_kernels.h — kernel argument block shared by the HIP kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace sdempc {
+
+struct ModelK {  // physics prior + small output-layer constants (SPEC.md §2), passed in SGPRs
+    float inv_mass, grav, J[3], iJ[3], ct2, ct1, ct0, cm2, cm1;
+    float rx[8], ry[8], dir[8];
+    float sF[3], sT[3];
+    float b3[6], b3n;
+};
+struct CostK {
+    float perr[3], verr[3], qerr[3], werr[3];
+    float res_mult, uerr, slew, slew_cc;
+    int has_sc;
+    float slew_lo[8], slew_hi[8], uref[8], ulo[8], uhi[8];
+};
+struct ApgK {
+    int max_iter, max_noimp, maxls, reset_inc;
+    float atol, rtol, stepsize, smax, coef, dec, inc;
+};
+struct KArgs {
+    int H, P, m, G;
+    float invP;
+    ModelK M;
+    CostK C;
+    ApgK A;
+    // device tables (owned by the handle)
+    const float* dt;    // [H]
+    const float* sdt;   // [H][6]  sigma_i * sqrt(dt_t)
+    const float* disc;  // [H+1]   discount^t / H
+    const float* beta;  // [max_iter+2] momentum table
+    const float* wts;   // blob float payload
+    // per call
+    const float* x0;           // [B][13]
+    const float* u;            // [B][H][m]   control sequence (rollout/grad) or warm start (solve)
+    const float* xref;         // [B][H+1][13]
+    const float* noise;        // [B][G][H][6][32]
+    const float* stepsize_in;  // [B] (solve)
+    float* traj;               // [B][G][H+1][13][32] workspace
+    float* cost;               // [B]
+    float* grad;               // [B][H][m]
+    float* xmean;              // [B][H+1][13] or null
+    float* uopt;               // [B][H][m]
+    float* info;               // [B][8] raw: sum_ls, stepsize, nit, grad_sqr, sum_s, c_init, c_opt, nls_total
+    int store_traj;
+};
+
+size_t smem_bytes(int H, int m);
+hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st);
+hipError_t launch_grad(const KArgs& a, int B, hipStream_t st);
+hipError_t launch_solve(const KArgs& a, int B, hipStream_t st);
+
+}  // namespace sdempc

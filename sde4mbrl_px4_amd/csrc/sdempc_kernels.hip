@@ -1,0 +1,910 @@
+// sdempc_kernels.hip — hand-written gfx950 (CDNA4) kernels for the MPC inner loop.
+//
+// Path replaced (reference): the body of m_mpc / m_reset that sde4mbrl_px4 obtains from
+// load_mpc_from_cfgfile (sde4mbrl_px4/mpc_controller/sde_control.py:685) and calls per tick
+// (sde_control.py:345-350,400-416). Arithmetic spec: SPEC.md (this repo); rows A3-A7 of SURVEY.md §8a.
+//
+// Mapping to the hardware
+//   * one workgroup (4 wave64 = 256 threads, one wave per SIMD) per MPC problem instance; the whole
+//     accelerated-proximal-gradient loop runs inside the kernel (no host round trip per iteration).
+//   * a wave integrates 32 SDE particles at a time in the v_mfma_f32_32x32x2_f32 accumulator layout:
+//     lane l <-> particle column j = l&31, lane half h = l>>5; accumulator register r holds hidden
+//     unit rowmap(r,h) = (r&3) + 8*(r>>2) + 4*h of that particle.
+//   * MLP layers are chained MFMAs: the layer-1 accumulator registers ARE the B operands of layer 2
+//     (k-step r <-> register r), so activations never leave registers; weights (A operands) stay
+//     resident in VGPRs for the whole solve. f32 MFMA is bit-exactly a k-ordered fmaf chain
+//     (tools/mfma_probe.hip), which is what lets the CPU oracle reproduce these kernels bit for bit.
+//   * activations / rigid-body physics / cost run on the VALU with the explicit operation order of
+//     SPEC.md; tanh uses the batched-reciprocal form (4 values share one Newton reciprocal).
+//   * the particle x horizon tensor (x_t for every particle) is streamed to HBM in the forward sweep
+//     and read back in the adjoint sweep, layout [instance][group][t][13][32] (128-byte rows);
+//     the noise tensor uses [instance][group][t][6][32].
+//   * per-step control-dependent terms (W1u u_t + b1, rotor thrust/torques) are computed once per
+//     rollout per instance into LDS and enter the MFMA as its C operand.
+//   * reductions over particles use xor butterflies inside the 32-lane groups and a fixed slot order
+//     across waves; no atomics anywhere, results are run-to-run deterministic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sdempc_kernels.h"
+
+namespace sdempc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#define DI __device__ __forceinline__
+
+constexpr int NX = 13, NN = 6, HID = 32, NT = 256, NW = 4;
+
+// ------------------------------------------------------------------------------------------------
+// SPEC.md §3: elementary functions (bit-reproducible: only fma / mul / add / integer ops)
+// ------------------------------------------------------------------------------------------------
+DI float rcp_spec(float d) {
+    float y = __uint_as_float(0x7EF311C7u - __float_as_uint(d));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { float e = FMA(-d, y, 1.0f); y = FMA(y, e, y); }
+    return y;
+}
+DI float rsqrt_spec(float a) {
+    float y = __uint_as_float(0x5F3759DFu - (__float_as_uint(a) >> 1));
+    float h = 0.5f * a;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { float t = y * y; t = FMA(-h, t, 1.5f); y = y * t; }
+    return y;
+}
+DI float exp2_spec(float x, float c) {
+    float t2 = FMA(x, c, 12582912.0f);
+    float n = t2 - 12582912.0f;
+    float f = FMA(x, c, -n);
+    float p = 0.001327647129073739f;
+    p = FMA(p, f, 0.009675540961325169f);
+    p = FMA(p, f, 0.05550713092088699f);
+    p = FMA(p, f, 0.24022120237350464f);
+    p = FMA(p, f, 0.6931469440460205f);
+    p = FMA(p, f, 1.0000001192092896f);
+    return __uint_as_float(__float_as_uint(p) + (__float_as_uint(t2) << 23));
+}
+DI float clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+// tanh of 4 values with one shared reciprocal (SPEC.md §3.4)
+DI void tanh4(float& a0, float& a1, float& a2, float& a3) {
+    float d0 = 1.0f + exp2_spec(clampf(a0, -9.0f, 9.0f), 2.885390043258667f);
+    float d1 = 1.0f + exp2_spec(clampf(a1, -9.0f, 9.0f), 2.885390043258667f);
+    float d2 = 1.0f + exp2_spec(clampf(a2, -9.0f, 9.0f), 2.885390043258667f);
+    float d3 = 1.0f + exp2_spec(clampf(a3, -9.0f, 9.0f), 2.885390043258667f);
+    float p2 = d0 * d1, p3 = p2 * d2, p4 = p3 * d3;
+    float r = rcp_spec(p4);
+    float r3 = r * p3; r = r * d3;
+    float r2 = r * p2; r = r * d2;
+    float r1 = r * d0;
+    float r0 = r * d1;
+    a0 = FMA(-2.0f, r0, 1.0f); a1 = FMA(-2.0f, r1, 1.0f); a2 = FMA(-2.0f, r2, 1.0f); a3 = FMA(-2.0f, r3, 1.0f);
+}
+DI void tanh16(f32x16& v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float a = v[4 * q], b = v[4 * q + 1], c = v[4 * q + 2], d = v[4 * q + 3];
+        tanh4(a, b, c, d);
+        v[4 * q] = a; v[4 * q + 1] = b; v[4 * q + 2] = c; v[4 * q + 3] = d;
+    }
+}
+DI float sigmoid_spec(float x) {
+    float E = exp2_spec(clampf(x, -30.0f, 30.0f), -1.4426950216293335f);
+    return rcp_spec(1.0f + E);
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared-memory carve (floats). One instance per workgroup.
+// ------------------------------------------------------------------------------------------------
+struct Smem {
+    float *W3, *w3n, *b1n, *b2, *b1d, *W1zT, *W1uT;  // weights, row-major in hidden-unit index
+    float *ust;                                        // [H][36]: c[32], Tz, tau[3]
+    float *xref;                                       // [H+1][13]
+    float *SX;                                         // max(4*H*12, 4*(H+1)*13): per-wave partials
+    float *dt, *sdt, *disc;                            // [H], [H][6], [H+1]
+    float *red;                                        // [16] block-reduction scratch
+    float *v[6];                                       // N-vectors: 0 xk, 1 yk, 2 xn, 3 g, 4 d1, 5 ucur
+};
+constexpr int UST = 36;
+
+DI Smem carve(float* base, int H, int m) {
+    Smem s;
+    float* p = base;
+    s.W3 = p; p += 6 * HID;
+    s.w3n = p; p += HID;
+    s.b1n = p; p += HID;
+    s.b2 = p; p += HID;
+    s.b1d = p; p += HID;
+    s.W1zT = p; p += NN * 2 * HID;
+    s.W1uT = p; p += 8 * HID;
+    s.ust = p; p += H * UST;
+    s.xref = p; p += ((H + 1) * NX + 3) & ~3;
+    s.SX = p; p += 4 * (H + 1) * NX;
+    s.dt = p; p += (H + 3) & ~3;
+    s.sdt = p; p += (H * NN + 3) & ~3;
+    s.disc = p; p += (H + 1 + 3) & ~3;
+    s.red = p; p += 16;
+    int nv = (H * m + 3) & ~3;
+    for (int i = 0; i < 6; ++i) { s.v[i] = p; p += nv; }
+    return s;
+}
+size_t smem_bytes(int H, int m) {
+    size_t f = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 4 * (H + 1) * NX +
+               ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
+    return f * sizeof(float);
+}
+
+// blob float payload offsets (SPEC.md §2)
+constexpr int OFF_W1Z = 56, OFF_B1 = OFF_W1Z + 384, OFF_W1U = OFF_B1 + 64, OFF_W2 = OFF_W1U + 256, OFF_B2 = OFF_W2 + 1024,
+              OFF_W3 = OFF_B2 + 32, OFF_B3 = OFF_W3 + 256, OFF_W3N = OFF_B3 + 8, OFF_B3N = OFF_W3N + 32;
+
+// MFMA A operands kept in registers for the whole kernel
+struct WaveW {
+    float w1d[3], w1n[3], w2[16], w2t[16];
+};
+
+DI int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid) {
+    const float* w = a.wts;
+    for (int i = tid; i < 6 * HID; i += NT) sm.W3[i] = w[OFF_W3 + i];
+    for (int i = tid; i < HID; i += NT) {
+        sm.w3n[i] = w[OFF_W3N + i];
+        sm.b1d[i] = w[OFF_B1 + i];
+        sm.b1n[i] = w[OFF_B1 + HID + i];
+        sm.b2[i] = w[OFF_B2 + i];
+    }
+    for (int i = tid; i < NN * 2 * HID; i += NT) { int k = i / (2 * HID), r = i % (2 * HID); sm.W1zT[i] = w[OFF_W1Z + r * NN + k]; }
+    for (int i = tid; i < 8 * HID; i += NT) { int j = i / HID, r = i % HID; sm.W1uT[i] = w[OFF_W1U + r * 8 + j]; }
+    for (int i = tid; i < a.H; i += NT) sm.dt[i] = a.dt[i];
+    for (int i = tid; i < a.H * NN; i += NT) sm.sdt[i] = a.sdt[i];
+    for (int i = tid; i <= a.H; i += NT) sm.disc[i] = a.disc[i];
+    int lane = tid & 63, j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { ww.w1d[s] = w[OFF_W1Z + j * NN + 2 * s + h]; ww.w1n[s] = w[OFF_W1Z + (HID + j) * NN + 2 * s + h]; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ww.w2[r] = w[OFF_W2 + j * HID + rowmap(r, h)]; ww.w2t[r] = w[OFF_W2 + rowmap(r, h) * HID + j]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-wide helpers (all 256 threads call; the result is identical in every thread)
+// ------------------------------------------------------------------------------------------------
+DI float wave_bfly64(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s);
+    return v;
+}
+DI float group_bfly32(float v) {
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) v = v + __shfl_xor(v, s);
+    return v;
+}
+// SPEC.md §6.2 dot256: lane chains e = tid, tid+256, ...; butterflies; ((w0+w1)+w2)+w3
+DI float block_dot(const Smem& sm, const float* x, const float* y, int N, int tid) {
+    float acc = 0.0f;
+    for (int e = tid; e < N; e += NT) acc = FMA(x[e], y ? y[e] : 1.0f, acc);
+    acc = wave_bfly64(acc);
+    __syncthreads();
+    if ((tid & 63) == 0) sm.red[tid >> 6] = acc;
+    __syncthreads();
+    return ((sm.red[0] + sm.red[1]) + sm.red[2]) + sm.red[3];
+}
+
+// SPEC.md §5.5: control cost element and d/du pieces
+DI float slew_dw(const KArgs& a, const float* u, int t, int j, int m, float& cterm) {
+    // returns dw(t,j) and the (undiscounted) slew cost term for t >= 1
+    float ds = u[t * m + j] - u[(t - 1) * m + j];
+    float c = (a.C.slew * ds) * ds;
+    float d = (2.0f * a.C.slew) * ds;
+    if (a.C.has_sc) {
+        float hi = ds - a.C.slew_hi[j]; hi = hi < 0.0f ? 0.0f : hi;
+        float lo = a.C.slew_lo[j] - ds; lo = lo < 0.0f ? 0.0f : lo;
+        c = FMA(a.C.slew_cc * hi, hi, c);
+        c = FMA(a.C.slew_cc * lo, lo, c);
+        d = FMA(2.0f * a.C.slew_cc, hi - lo, d);
+    }
+    cterm = c;
+    return d;
+}
+DI float ucost_elem(const KArgs& a, const Smem& sm, const float* u, int e, int m) {
+    int t = e / m, j = e - t * m;
+    float du = u[e] - a.C.uref[j];
+    float c = (a.C.uerr * du) * du;
+    if (t >= 1) {
+        float ds = u[e] - u[e - m];
+        c = FMA(a.C.slew * ds, ds, c);
+        if (a.C.has_sc) {
+            float hi = ds - a.C.slew_hi[j]; hi = hi < 0.0f ? 0.0f : hi;
+            float lo = a.C.slew_lo[j] - ds; lo = lo < 0.0f ? 0.0f : lo;
+            c = FMA(a.C.slew_cc * hi, hi, c);
+            c = FMA(a.C.slew_cc * lo, lo, c);
+        }
+    }
+    return sm.disc[t] * c;
+}
+DI float block_ucost(const KArgs& a, const Smem& sm, const float* u, int tid) {
+    int N = a.H * a.m;
+    float acc = 0.0f;
+    for (int e = tid; e < N; e += NT) acc = FMA(ucost_elem(a, sm, u, e, a.m), 1.0f, acc);
+    acc = wave_bfly64(acc);
+    __syncthreads();
+    if ((tid & 63) == 0) sm.red[tid >> 6] = acc;
+    __syncthreads();
+    return ((sm.red[0] + sm.red[1]) + sm.red[2]) + sm.red[3];
+}
+
+// SPEC.md §5.1: per-step control-dependent constants into sm.ust
+DI void block_prepass(const KArgs& a, const Smem& sm, const float* u, int tid) {
+    const int H = a.H, m = a.m;
+    for (int e = tid; e < H * HID; e += NT) {
+        int t = e >> 5, r = e & 31;
+        float c = sm.b1d[r];
+        for (int j = 0; j < m; ++j) c = FMA(sm.W1uT[j * HID + r], u[t * m + j], c);
+        sm.ust[t * UST + r] = c;
+    }
+    for (int t = tid; t < H; t += NT) {
+        float Tz = 0.0f, t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+        for (int j = 0; j < m; ++j) {
+            float uj = u[t * m + j];
+            float T = FMA(FMA(a.M.ct2, uj, a.M.ct1), uj, a.M.ct0);
+            float Mq = a.M.dir[j] * (FMA(a.M.cm2, uj, a.M.cm1) * uj);
+            Tz = Tz + T;
+            t0 = FMA(a.M.ry[j], T, t0);
+            t1 = FMA(-a.M.rx[j], T, t1);
+            t2 = t2 + Mq;
+        }
+        sm.ust[t * UST + 32] = Tz; sm.ust[t * UST + 33] = t0; sm.ust[t * UST + 34] = t1; sm.ust[t * UST + 35] = t2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one Euler–Maruyama step for the wave's 32 particles (SPEC.md §5.2)
+// ------------------------------------------------------------------------------------------------
+struct StepAux {
+    float Rm[9];
+    f32x16 h1d, h1n, h2;
+    float eta, Fb[3], Jom[3], rn, qn[4];
+};
+
+DI float xhalf(float v) { return __shfl_xor(v, 32); }
+
+DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, const float* x, const float* xi, float* xn, StepAux& A) {
+    const float* ust = sm.ust + t * UST;
+    const float dt = sm.dt[t];
+    const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const float xx = qx * qx, yy = qy * qy, zz = qz * qz;
+    const float xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
+    float* Rm = A.Rm;
+    Rm[0] = FMA(-2.0f, yy + zz, 1.0f); Rm[1] = 2.0f * (xy - wz);          Rm[2] = 2.0f * (xz + wy);
+    Rm[3] = 2.0f * (xy + wz);          Rm[4] = FMA(-2.0f, xx + zz, 1.0f); Rm[5] = 2.0f * (yz - wx);
+    Rm[6] = 2.0f * (xz - wy);          Rm[7] = 2.0f * (yz + wx);          Rm[8] = FMA(-2.0f, xx + yy, 1.0f);
+    float z[NN];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) z[j] = FMA(Rm[6 + j], x[5], FMA(Rm[3 + j], x[4], Rm[j] * x[3]));
+    z[3] = x[10]; z[4] = x[11]; z[5] = x[12];
+    // layer 1: C operand = per-step offsets (drift) / bias (density); K = 6 -> 3 MFMAs per tile
+    f32x16 accD, accN;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 c4 = *reinterpret_cast<const float4*>(ust + 8 * q + 4 * h);
+        float4 n4 = *reinterpret_cast<const float4*>(sm.b1n + 8 * q + 4 * h);
+        accD[4 * q] = c4.x; accD[4 * q + 1] = c4.y; accD[4 * q + 2] = c4.z; accD[4 * q + 3] = c4.w;
+        accN[4 * q] = n4.x; accN[4 * q + 1] = n4.y; accN[4 * q + 2] = n4.z; accN[4 * q + 3] = n4.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        float b = h ? z[2 * s + 1] : z[2 * s];
+        accD = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1d[s], b, accD, 0, 0, 0);
+        accN = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1n[s], b, accN, 0, 0, 0);
+    }
+    tanh16(accD);
+    tanh16(accN);
+    A.h1d = accD; A.h1n = accN;
+    // layer 2 (drift): B operand of k-step r is accumulator register r of layer 1
+    f32x16 acc2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 b4 = *reinterpret_cast<const float4*>(sm.b2 + 8 * q + 4 * h);
+        acc2[4 * q] = b4.x; acc2[4 * q + 1] = b4.y; acc2[4 * q + 2] = b4.z; acc2[4 * q + 3] = b4.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w2[r], accD[r], acc2, 0, 0, 0);
+    tanh16(acc2);
+    A.h2 = acc2;
+    // output layers on the VALU: per-half partial chains, then (P0 + P1) + bias
+    float o[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float P = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
+            P = FMA(w4.x, acc2[4 * q], P); P = FMA(w4.y, acc2[4 * q + 1], P); P = FMA(w4.z, acc2[4 * q + 2], P); P = FMA(w4.w, acc2[4 * q + 3], P);
+        }
+        o[i] = (P + xhalf(P)) + a.M.b3[i];
+    }
+    float eta;
+    {
+        float P = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
+            P = FMA(w4.x, accN[4 * q], P); P = FMA(w4.y, accN[4 * q + 1], P); P = FMA(w4.z, accN[4 * q + 2], P); P = FMA(w4.w, accN[4 * q + 3], P);
+        }
+        eta = sigmoid_spec((P + xhalf(P)) + a.M.b3n);
+    }
+    A.eta = eta;
+    // rigid body
+    A.Fb[0] = a.M.sF[0] * o[0]; A.Fb[1] = a.M.sF[1] * o[1]; A.Fb[2] = FMA(a.M.sF[2], o[2], ust[32]);
+    float acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float Fw = FMA(Rm[3 * i + 2], A.Fb[2], FMA(Rm[3 * i + 1], A.Fb[1], Rm[3 * i] * A.Fb[0]));
+        acc[i] = Fw * a.M.inv_mass;
+    }
+    acc[2] = acc[2] - a.M.grav;
+    float taub[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { taub[i] = FMA(a.M.sT[i], o[3 + i], ust[33 + i]); A.Jom[i] = a.M.J[i] * x[10 + i]; }
+    float cr[3];
+    cr[0] = FMA(x[11], A.Jom[2], -(x[12] * A.Jom[1]));
+    cr[1] = FMA(x[12], A.Jom[0], -(x[10] * A.Jom[2]));
+    cr[2] = FMA(x[10], A.Jom[1], -(x[11] * A.Jom[0]));
+    float dom[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dom[i] = (taub[i] - cr[i]) * a.M.iJ[i];
+    float dq[4];
+    dq[0] = -0.5f * FMA(qz, x[12], FMA(qy, x[11], qx * x[10]));
+    dq[1] = 0.5f * FMA(-qz, x[11], FMA(qy, x[12], qw * x[10]));
+    dq[2] = 0.5f * FMA(-qx, x[12], FMA(qz, x[10], qw * x[11]));
+    dq[3] = 0.5f * FMA(-qy, x[10], FMA(qx, x[11], qw * x[12]));
+    const float* sdt = sm.sdt + t * NN;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        xn[i] = FMA(x[3 + i], dt, x[i]);
+        xn[3 + i] = FMA(sdt[i] * eta, xi[i], FMA(acc[i], dt, x[3 + i]));
+        xn[10 + i] = FMA(sdt[3 + i] * eta, xi[3 + i], FMA(dom[i], dt, x[10 + i]));
+    }
+    float qt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qt[i] = FMA(dq[i], dt, x[6 + i]);
+    float n2 = FMA(qt[3], qt[3], FMA(qt[2], qt[2], FMA(qt[1], qt[1], qt[0] * qt[0])));
+    A.rn = rsqrt_spec(n2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { A.qn[i] = qt[i] * A.rn; xn[6 + i] = A.qn[i]; }
+}
+
+// SPEC.md §5.3 stage cost at x_{t+1}; GX: also the gradient
+template <bool GX>
+DI float stage_cost(const KArgs& a, const float* x, const float* xr, float* gx) {
+    float l = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { float e = x[i] - xr[i]; float w = a.C.perr[i] * e; l = FMA(w, e, l); if (GX) gx[i] = 2.0f * w; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { float e = x[3 + i] - xr[3 + i]; float w = a.C.verr[i] * e; l = FMA(w, e, l); if (GX) gx[3 + i] = 2.0f * w; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { float e = x[10 + i] - xr[10 + i]; float w = a.C.werr[i] * e; l = FMA(w, e, l); if (GX) gx[10 + i] = 2.0f * w; }
+    float qw = x[6], qx = x[7], qy = x[8], qz = x[9], rw = xr[6], rx = xr[7], ry = xr[8], rz = xr[9];
+    float ex = FMA(rz, qy, FMA(-ry, qz, FMA(-rx, qw, rw * qx)));
+    float ey = FMA(-rz, qx, FMA(-ry, qw, FMA(rx, qz, rw * qy)));
+    float ez = FMA(-rz, qw, FMA(ry, qx, FMA(-rx, qy, rw * qz)));
+    float wxe = a.C.qerr[0] * ex, wye = a.C.qerr[1] * ey, wze = a.C.qerr[2] * ez;
+    l = FMA(wxe, ex, l); l = FMA(wye, ey, l); l = FMA(wze, ez, l);
+    if (GX) {
+        float ga = 2.0f * wxe, gb = 2.0f * wye, gc = 2.0f * wze;
+        gx[6] = FMA(-rz, gc, FMA(-ry, gb, -rx * ga));
+        gx[7] = FMA(ry, gc, FMA(-rz, gb, rw * ga));
+        gx[8] = FMA(-rx, gc, FMA(rw, gb, rz * ga));
+        gx[9] = FMA(rw, gc, FMA(rx, gb, -ry * ga));
+    }
+    return l;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector-Jacobian product of one step (SPEC.md §5.4). gq[0..m-1] = W1u^T abar1, gq[m] = Tz adjoint,
+// gq[m+1..m+3] = rotor-torque adjoint
+// ------------------------------------------------------------------------------------------------
+template <int M>
+DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, const float* x, const float* xi, const StepAux& A,
+                 const float* L, float etabar_cost, float* lam, float* gq) {
+    const float dt = sm.dt[t];
+    const float* sdt = sm.sdt + t * NN;
+    const float* Rm = A.Rm;
+    const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const float* v = x + 3;
+    const float* om = x + 10;
+    float eb = etabar_cost;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) eb = FMA(L[3 + i] * sdt[i], xi[i], eb);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) eb = FMA(L[10 + i] * sdt[3 + i], xi[3 + i], eb);
+    float ebraw = eb * (A.eta * (1.0f - A.eta));
+    float dotq = FMA(A.qn[3], L[9], FMA(A.qn[2], L[8], FMA(A.qn[1], L[7], A.qn[0] * L[6])));
+    float qtb[4], dqb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qtb[i] = A.rn * FMA(-A.qn[i], dotq, L[6 + i]); dqb[i] = qtb[i] * dt; }
+    float taub_b[3], crb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { taub_b[i] = (L[10 + i] * dt) * a.M.iJ[i]; crb[i] = -taub_b[i]; }
+    float omb[3], Jb[3];
+    omb[0] = L[10] + FMA(A.Jom[1], crb[2], -(A.Jom[2] * crb[1]));
+    omb[1] = L[11] + FMA(A.Jom[2], crb[0], -(A.Jom[0] * crb[2]));
+    omb[2] = L[12] + FMA(A.Jom[0], crb[1], -(A.Jom[1] * crb[0]));
+    Jb[0] = FMA(crb[1], om[2], -(crb[2] * om[1]));
+    Jb[1] = FMA(crb[2], om[0], -(crb[0] * om[2]));
+    Jb[2] = FMA(crb[0], om[1], -(crb[1] * om[0]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) omb[i] = FMA(a.M.J[i], Jb[i], omb[i]);
+    float Fwb[3], Fbb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Fwb[i] = (L[3 + i] * dt) * a.M.inv_mass;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Fbb[j] = FMA(Rm[6 + j], Fwb[2], FMA(Rm[3 + j], Fwb[1], Rm[j] * Fwb[0]));
+    float ob[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ob[i] = a.M.sF[i] * Fbb[i]; ob[3 + i] = a.M.sT[i] * taub_b[i]; }
+    gq[M] = Fbb[2];
+    gq[M + 1] = taub_b[0]; gq[M + 2] = taub_b[1]; gq[M + 3] = taub_b[2];
+    // MLP VJP: abar2 on the VALU, W2^T abar2 by MFMA in the accumulator layout
+    f32x16 a2b;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f, hb3 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
+            hb0 = FMA(w4.x, ob[i], hb0); hb1 = FMA(w4.y, ob[i], hb1); hb2 = FMA(w4.z, ob[i], hb2); hb3 = FMA(w4.w, ob[i], hb3);
+        }
+        a2b[4 * q] = hb0 * FMA(-A.h2[4 * q], A.h2[4 * q], 1.0f);
+        a2b[4 * q + 1] = hb1 * FMA(-A.h2[4 * q + 1], A.h2[4 * q + 1], 1.0f);
+        a2b[4 * q + 2] = hb2 * FMA(-A.h2[4 * q + 2], A.h2[4 * q + 2], 1.0f);
+        a2b[4 * q + 3] = hb3 * FMA(-A.h2[4 * q + 3], A.h2[4 * q + 3], 1.0f);
+    }
+    f32x16 accB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w2t[r], a2b[r], accB, 0, 0, 0);
+    f32x16 a1d, a1n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 w4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
+        float wn[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int r = 4 * q + c;
+            a1d[r] = accB[r] * FMA(-A.h1d[r], A.h1d[r], 1.0f);
+            a1n[r] = (wn[c] * ebraw) * FMA(-A.h1n[r], A.h1n[r], 1.0f);
+        }
+    }
+    float zb[NN];
+#pragma unroll
+    for (int k = 0; k < NN; ++k) {
+        float P = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + 8 * q + 4 * h);
+            P = FMA(w4.x, a1d[4 * q], P); P = FMA(w4.y, a1d[4 * q + 1], P); P = FMA(w4.z, a1d[4 * q + 2], P); P = FMA(w4.w, a1d[4 * q + 3], P);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + HID + 8 * q + 4 * h);
+            P = FMA(w4.x, a1n[4 * q], P); P = FMA(w4.y, a1n[4 * q + 1], P); P = FMA(w4.z, a1n[4 * q + 2], P); P = FMA(w4.w, a1n[4 * q + 3], P);
+        }
+        zb[k] = P + xhalf(P);
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        float P = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.W1uT + j * HID + 8 * q + 4 * h);
+            P = FMA(w4.x, a1d[4 * q], P); P = FMA(w4.y, a1d[4 * q + 1], P); P = FMA(w4.z, a1d[4 * q + 2], P); P = FMA(w4.w, a1d[4 * q + 3], P);
+        }
+        gq[j] = P + xhalf(P);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) omb[i] = omb[i] + zb[3 + i];
+    float vbar[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float Rvb = FMA(Rm[3 * i + 2], zb[2], FMA(Rm[3 * i + 1], zb[1], Rm[3 * i] * zb[0]));
+        vbar[i] = FMA(L[i], dt, L[3 + i]) + Rvb;
+    }
+    float Rb[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Rb[3 * i + j] = FMA(v[i], zb[j], Fwb[i] * A.Fb[j]);
+    float qb[4];
+    qb[0] = FMA(0.5f, FMA(dqb[3], om[2], FMA(dqb[2], om[1], dqb[1] * om[0])), qtb[0]);
+    qb[1] = FMA(0.5f, FMA(dqb[3], om[1], FMA(-dqb[2], om[2], -(dqb[0] * om[0]))), qtb[1]);
+    qb[2] = FMA(0.5f, FMA(-dqb[3], om[0], FMA(dqb[1], om[2], -(dqb[0] * om[1]))), qtb[2]);
+    qb[3] = FMA(0.5f, FMA(dqb[2], om[0], FMA(-dqb[1], om[1], -(dqb[0] * om[2]))), qtb[3]);
+    omb[0] = FMA(0.5f, FMA(-dqb[3], qy, FMA(dqb[2], qz, FMA(dqb[1], qw, -(dqb[0] * qx)))), omb[0]);
+    omb[1] = FMA(0.5f, FMA(dqb[3], qx, FMA(dqb[2], qw, FMA(-dqb[1], qz, -(dqb[0] * qy)))), omb[1]);
+    omb[2] = FMA(0.5f, FMA(dqb[3], qw, FMA(-dqb[2], qx, FMA(dqb[1], qy, -(dqb[0] * qz)))), omb[2]);
+    float s01 = Rb[1] + Rb[3], d10 = Rb[3] - Rb[1];
+    float s02 = Rb[2] + Rb[6], d02 = Rb[2] - Rb[6];
+    float s12 = Rb[5] + Rb[7], d21 = Rb[7] - Rb[5];
+    qb[0] = FMA(2.0f, FMA(qx, d21, FMA(qy, d02, qz * d10)), qb[0]);
+    qb[1] = FMA(2.0f, FMA(qw, d21, FMA(qz, s02, qy * s01)), FMA(-4.0f * qx, Rb[4] + Rb[8], qb[1]));
+    qb[2] = FMA(2.0f, FMA(qz, s12, FMA(qw, d02, qx * s01)), FMA(-4.0f * qy, Rb[0] + Rb[8], qb[2]));
+    qb[3] = FMA(2.0f, FMA(qy, s12, FMA(qx, s02, qw * d10)), FMA(-4.0f * qz, Rb[0] + Rb[4], qb[3]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { lam[i] = L[i]; lam[3 + i] = vbar[i]; lam[10 + i] = omb[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lam[6 + i] = qb[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-level rollout: expected cost of control sequence u (LDS). SPEC.md §5.3/§6/§7
+//   store_traj: stream x_t to a.traj; want_mean: particle mean trajectory -> xmean_out (global)
+// ------------------------------------------------------------------------------------------------
+DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
+    const int H = a.H, G = a.G, P = a.P;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const bool want_mean = xmean_out != nullptr;
+    __syncthreads();
+    block_prepass(a, sm, u, tid);
+    if (want_mean)
+        for (int i = tid; i < 4 * (H + 1) * NX; i += NT) sm.SX[i] = 0.0f;
+    float cu = block_ucost(a, sm, u, tid);  // contains barriers: prepass results visible afterwards
+    float x0r[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x0r[i] = a.x0[b * NX + i];
+    float Sw = 0.0f;
+    float* xm = sm.SX + wave * (H + 1) * NX;
+    for (int g = wave; g < G; g += NW) {
+        const bool valid = (g * 32 + j) < P;
+        const float* nz = a.noise + ((size_t)(b * G + g) * H) * NN * 32 + j;
+        float* tj = a.traj + ((size_t)(b * G + g) * (H + 1)) * NX * 32 + j;
+        float x[NX], xn[NX], xi[NN];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = x0r[i];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) xi[i] = nz[i * 32];
+        if (store_traj) {
+#pragma unroll
+            for (int c = 0; c < 7; ++c) { if (c + 7 * h < NX) tj[(c + 7 * h) * 32] = h ? x[(c + 7) % NX] : x[c]; }
+        }
+        if (want_mean) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { float s = group_bfly32(valid ? x[i] : 0.0f); if (lane == 0) xm[i] = xm[i] + s; }
+        }
+        float J = 0.0f;
+        StepAux A;
+        for (int t = 0; t < H; ++t) {
+            float xin[NN];
+            if (t + 1 < H) {
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
+            }
+            step_fwd(a, sm, ww, t, h, x, xi, xn, A);
+            float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
+            l = FMA(a.C.res_mult * A.eta, A.eta, l);
+            J = FMA(sm.disc[t], l, J);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xn[i];
+            if (t + 1 < H) {
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xi[i] = xin[i];
+            }
+            if (store_traj) {
+                float* tp = tj + (size_t)(t + 1) * NX * 32;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) { if (c + 7 * h < NX) tp[(c + 7 * h) * 32] = h ? x[(c + 7) % NX] : x[c]; }
+            }
+            if (want_mean) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { float s = group_bfly32(valid ? x[i] : 0.0f); if (lane == 0) xm[(t + 1) * NX + i] = xm[(t + 1) * NX + i] + s; }
+            }
+        }
+        float T = group_bfly32(valid ? J : 0.0f);
+        Sw = Sw + T;
+    }
+    __syncthreads();
+    if (lane == 0) sm.red[8 + wave] = Sw;
+    __syncthreads();
+    float tot = ((sm.red[8] + sm.red[9]) + sm.red[10]) + sm.red[11];
+    if (want_mean) {
+        for (int i = tid; i < (H + 1) * NX; i += NT) {
+            const int st = (H + 1) * NX;
+            float s = ((sm.SX[i] + sm.SX[st + i]) + sm.SX[2 * st + i]) + sm.SX[3 * st + i];
+            xmean_out[i] = s * a.invP;
+        }
+    }
+    return FMA(tot, a.invP, cu);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-level cost + gradient (forward sweep with trajectory store, adjoint sweep). SPEC.md §5.4/§6
+//   y: control sequence in LDS; gout: gradient [H*m] in LDS
+// ------------------------------------------------------------------------------------------------
+template <int M>
+DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const float* y, float* gout, int b, int tid) {
+    const int H = a.H, G = a.G, P = a.P, m = a.m;
+    constexpr int nq = M + 4;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    __syncthreads();
+    block_prepass(a, sm, y, tid);
+    for (int i = tid; i < 4 * H * 12; i += NT) sm.SX[i] = 0.0f;
+    float cu = block_ucost(a, sm, y, tid);
+    float x0r[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x0r[i] = a.x0[b * NX + i];
+    float Sw = 0.0f;
+    float* Sq = sm.SX + wave * H * 12;
+    for (int g = wave; g < G; g += NW) {
+        const bool valid = (g * 32 + j) < P;
+        const float* nz = a.noise + ((size_t)(b * G + g) * H) * NN * 32 + j;
+        float* tj = a.traj + ((size_t)(b * G + g) * (H + 1)) * NX * 32 + j;
+        float x[NX], xn[NX], xi[NN];
+        StepAux A;
+        // ---- forward sweep, x_t streamed to HBM ----
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = x0r[i];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) xi[i] = nz[i * 32];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) { if (c + 7 * h < NX) tj[(c + 7 * h) * 32] = h ? x[(c + 7) % NX] : x[c]; }
+        float J = 0.0f;
+        for (int t = 0; t < H; ++t) {
+            float xin[NN];
+            if (t + 1 < H) {
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
+            }
+            step_fwd(a, sm, ww, t, h, x, xi, xn, A);
+            float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
+            l = FMA(a.C.res_mult * A.eta, A.eta, l);
+            J = FMA(sm.disc[t], l, J);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xn[i];
+            if (t + 1 < H) {
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xi[i] = xin[i];
+            }
+            float* tp = tj + (size_t)(t + 1) * NX * 32;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) { if (c + 7 * h < NX) tp[(c + 7 * h) * 32] = h ? x[(c + 7) % NX] : x[c]; }
+        }
+        Sw = Sw + group_bfly32(valid ? J : 0.0f);
+        // ---- adjoint sweep: x (registers) currently holds x_H ----
+        float lam[NX], xt[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam[i] = 0.0f;
+        // make this wave's own stores visible to its loads (same CU, same wave: program order)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        {
+            const float* tp = tj + (size_t)(H - 1) * NX * 32;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xt[i] = tp[i * 32];
+#pragma unroll
+            for (int i = 0; i < NN; ++i) xi[i] = nz[((H - 1) * NN + i) * 32];
+        }
+        for (int t = H - 1; t >= 0; --t) {
+            float xtp[NX], xip[NN];
+            if (t > 0) {
+                const float* tp = tj + (size_t)(t - 1) * NX * 32;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xtp[i] = tp[i * 32];
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xip[i] = nz[((t - 1) * NN + i) * 32];
+            }
+            // x = x_{t+1}, xt = x_t
+            float gx[NX], L[NX], lamn[NX], gq[12];
+            step_fwd(a, sm, ww, t, h, xt, xi, xn, A);
+            stage_cost<true>(a, x, sm.xref + (t + 1) * NX, gx);
+            const float dsc = sm.disc[t];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) L[i] = FMA(dsc, gx[i], lam[i]);
+            float ebc = dsc * ((2.0f * a.C.res_mult) * A.eta);
+            step_vjp<M>(a, sm, ww, t, h, xt, xi, A, L, ebc, lamn, gq);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { lam[i] = lamn[i]; x[i] = xt[i]; }
+#pragma unroll
+            for (int k = 0; k < nq; ++k) {
+                float s = group_bfly32(valid ? gq[k] : 0.0f);
+                if (lane == 0) Sq[t * 12 + k] = Sq[t * 12 + k] + s;
+            }
+            if (t > 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xt[i] = xtp[i];
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xi[i] = xip[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) sm.red[8 + wave] = Sw;
+    __syncthreads();
+    float tot = ((sm.red[8] + sm.red[9]) + sm.red[10]) + sm.red[11];
+    // gradient assembly (SPEC.md §6.3)
+    const int N = H * m, st = H * 12;
+    for (int e = tid; e < N; e += NT) {
+        int t = e / m, jj = e - t * m;
+        float S[5];
+        int idx[5] = {jj, M, M + 1, M + 2, M + 3};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int o = t * 12 + idx[k];
+            S[k] = ((sm.SX[o] + sm.SX[st + o]) + sm.SX[2 * st + o]) + sm.SX[3 * st + o];
+        }
+        float uj = y[e];
+        float dT = FMA(2.0f * a.M.ct2, uj, a.M.ct1);
+        float dM = a.M.dir[jj] * FMA(2.0f * a.M.cm2, uj, a.M.cm1);
+        float acc = S[0];
+        acc = FMA(S[1], dT, acc);
+        acc = FMA(S[2], a.M.ry[jj] * dT, acc);
+        acc = FMA(S[3], -(a.M.rx[jj] * dT), acc);
+        acc = FMA(S[4], dM, acc);
+        // control-cost gradient
+        float du = uj - a.C.uref[jj];
+        float dw = 0.0f, ctmp;
+        if (t >= 1) dw = slew_dw(a, y, t, jj, m, ctmp);
+        float gcu = sm.disc[t] * FMA(2.0f * a.C.uerr, du, dw);
+        if (t + 1 < H) { float dwn = slew_dw(a, y, t + 1, jj, m, ctmp); gcu = FMA(-sm.disc[t + 1], dwn, gcu); }
+        gout[e] = FMA(acc, a.invP, gcu);
+    }
+    __syncthreads();
+    return FMA(tot, a.invP, cu);
+}
+
+DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
+    for (int i = tid; i < (a.H + 1) * NX; i += NT) sm.xref[i] = a.xref[(size_t)b * (a.H + 1) * NX + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT, 2) sdempc_rollout_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    Smem sm = carve(smem, a.H, a.m);
+    WaveW ww;
+    load_weights(a, sm, ww, tid);
+    load_common(a, sm, b, tid);
+    const int N = a.H * a.m;
+    for (int e = tid; e < N; e += NT) sm.v[5][e] = a.u[(size_t)b * N + e];
+    float c = block_rollout(a, sm, ww, sm.v[5], b, tid, a.store_traj != 0, a.xmean ? a.xmean + (size_t)b * (a.H + 1) * NX : nullptr);
+    if (tid == 0) a.cost[b] = c;
+}
+
+template <int M>
+__global__ void __launch_bounds__(NT, 2) sdempc_grad_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    Smem sm = carve(smem, a.H, a.m);
+    WaveW ww;
+    load_weights(a, sm, ww, tid);
+    load_common(a, sm, b, tid);
+    const int N = a.H * a.m;
+    for (int e = tid; e < N; e += NT) sm.v[5][e] = a.u[(size_t)b * N + e];
+    float c = block_cost_grad<M>(a, sm, ww, sm.v[5], sm.v[3], b, tid);
+    if (tid == 0) a.cost[b] = c;
+    for (int e = tid; e < N; e += NT) a.grad[(size_t)b * N + e] = sm.v[3][e];
+}
+
+// SPEC.md §8: monotone accelerated proximal gradient with Armijo backtracking, one instance per block
+template <int M>
+__global__ void __launch_bounds__(NT, 2) sdempc_solve_kernel(KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    Smem sm = carve(smem, a.H, a.m);
+    WaveW ww;
+    load_weights(a, sm, ww, tid);
+    load_common(a, sm, b, tid);
+    const int m = a.m, N = a.H * m;
+    float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
+    for (int e = tid; e < N; e += NT) {
+        int jj = e % m;
+        float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
+        xk[e] = v; yk[e] = v;
+    }
+    const float c_init = block_rollout(a, sm, ww, xk, b, tid, false, nullptr);
+    float c_x = c_init, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f;
+    int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1;
+    for (int k = 0; k < a.A.max_iter; ++k) {
+        const float c_y = block_cost_grad<M>(a, sm, ww, yk, g, b, tid);
+        gsq = block_dot(sm, g, g, N, tid);
+        float c_n = 0.0f;
+        int nls = 0;
+        if (a.A.maxls > 0) {
+            if (k > 0 && a.A.reset_inc) s = s * a.A.inc;
+            if (s > a.A.smax) s = a.A.smax;
+            for (int jl = 0; jl < a.A.maxls; ++jl) {
+                __syncthreads();
+                for (int e = tid; e < N; e += NT) {
+                    int jj = e % m;
+                    float v = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                    xn[e] = v; d1[e] = v - yk[e];
+                }
+                c_n = block_rollout(a, sm, ww, xn, b, tid, false, nullptr);
+                float gd = block_dot(sm, g, d1, N, tid);
+                nls = jl + 1;
+                if (c_n <= FMA(a.A.coef, gd, c_y)) break;
+                if (jl < a.A.maxls - 1) s = s * a.A.dec;
+            }
+        } else {
+            s = a.A.stepsize;
+            __syncthreads();
+            for (int e = tid; e < N; e += NT) { int jj = e % m; xn[e] = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]); }
+            c_n = block_rollout(a, sm, ww, xn, b, tid, false, nullptr);
+            nls = 1;
+        }
+        sum_ls = sum_ls + (float)nls; sum_s = sum_s + s; nit = k + 1; nls_tot += nls;
+        int stop = (__builtin_fabsf(c_n - c_x) <= FMA(a.A.rtol, __builtin_fabsf(c_x), a.A.atol));
+        __syncthreads();
+        if (c_n < c_x) {
+            for (int e = tid; e < N; e += NT) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
+            float rs = block_dot(sm, d1, d2, N, tid);
+            if (rs > 0.0f) {
+                kr = 0; plain = 1;
+                for (int e = tid; e < N; e += NT) { yk[e] = xn[e]; xk[e] = xn[e]; }
+            } else {
+                float bt = a.beta[kr];
+                for (int e = tid; e < N; e += NT) { int jj = e % m; yk[e] = clampf(FMA(bt, d2[e], xn[e]), a.C.ulo[jj], a.C.uhi[jj]); xk[e] = xn[e]; }
+                kr = kr + 1; plain = 0;
+            }
+            c_x = c_n; noimp = 0;
+        } else {
+            if (!plain) stop = 0;
+            kr = 0; plain = 1;
+            for (int e = tid; e < N; e += NT) yk[e] = xk[e];
+            noimp = noimp + 1;
+        }
+        if (noimp >= a.A.max_noimp) stop = 1;
+        if (stop) break;
+    }
+    __syncthreads();
+    for (int e = tid; e < N; e += NT) a.uopt[(size_t)b * N + e] = xk[e];
+    block_rollout(a, sm, ww, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
+    if (tid == 0) {
+        float* inf = a.info + (size_t)b * 8;
+        const float fn = (float)nit;
+        inf[0] = nit ? sum_ls / fn : 0.0f; inf[1] = s; inf[2] = fn; inf[3] = gsq; inf[4] = nit ? sum_s / fn : 0.0f;
+        inf[5] = c_init; inf[6] = c_x; inf[7] = (float)nls_tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static hipError_t set_smem_attr(const void* fn, size_t bytes) {
+    if (bytes > 64 * 1024) return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return hipSuccess;
+}
+hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) {
+    size_t sb = smem_bytes(a.H, a.m);
+    hipError_t e = set_smem_attr((const void*)sdempc_rollout_kernel, sb);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sdempc_rollout_kernel, dim3(B), dim3(NT), sb, st, a);
+    return hipGetLastError();
+}
+template <int M>
+static hipError_t launch_grad_t(const KArgs& a, int B, hipStream_t st, size_t sb) {
+    hipError_t e = set_smem_attr((const void*)sdempc_grad_kernel<M>, sb);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sdempc_grad_kernel<M>, dim3(B), dim3(NT), sb, st, a);
+    return hipGetLastError();
+}
+template <int M>
+static hipError_t launch_solve_t(const KArgs& a, int B, hipStream_t st, size_t sb) {
+    hipError_t e = set_smem_attr((const void*)sdempc_solve_kernel<M>, sb);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sdempc_solve_kernel<M>, dim3(B), dim3(NT), sb, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_grad(const KArgs& a, int B, hipStream_t st) {
+    size_t sb = smem_bytes(a.H, a.m);
+    if (a.m == 4) return launch_grad_t<4>(a, B, st, sb);
+    if (a.m == 6) return launch_grad_t<6>(a, B, st, sb);
+    return launch_grad_t<8>(a, B, st, sb);
+}
+hipError_t launch_solve(const KArgs& a, int B, hipStream_t st) {
+    size_t sb = smem_bytes(a.H, a.m);
+    if (a.m == 4) return launch_solve_t<4>(a, B, st, sb);
+    if (a.m == 6) return launch_solve_t<6>(a, B, st, sb);
+    return launch_solve_t<8>(a, B, st, sb);
+}
+
+}  // namespace sdempc

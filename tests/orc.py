@@ -1,0 +1,121 @@
+"""ctypes wrapper around oracle/liborc.so — the CPU restatement used as the parity checker.
+
+Test infrastructure only (see oracle/sde_mpc_oracle.c header). Builds the library with
+`make -C oracle` when it is missing or older than its source.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+
+def build():
+    so = os.path.join(ORC_DIR, "liborc.so")
+    src = os.path.join(ORC_DIR, "sde_mpc_oracle.c")
+    hdr = os.path.join(ROOT, "include", "sdempc.h")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", ORC_DIR, "-s"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        for pre in ("orc_", "orcd_"):
+            ft = C.c_float if pre == "orc_" else C.c_double
+            for fn in ("rcp", "rsqrt", "tanh", "sigmoid"):
+                f = getattr(_LIB, pre + fn)
+                f.argtypes, f.restype = [ft], ft
+    return _LIB
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Oracle:
+    """Oracle bound to one (config, model blob). double=True selects the float64 build."""
+
+    def __init__(self, mpc_cfg, model, double=False):
+        self.cfg_py = mpc_cfg
+        self.cfg, self._keep = mpc_cfg.to_cfg()
+        self.blob = model.to_blob() if hasattr(model, "to_blob") else bytes(model)
+        self._blobbuf = C.create_string_buffer(self.blob, len(self.blob))
+        self.pre = "orcd_" if double else "orc_"
+        self.H, self.P, self.m = mpc_cfg.horizon, mpc_cfg.num_particles, mpc_cfg.num_motors
+
+    def _fn(self, name):
+        return getattr(lib(), self.pre + name)
+
+    def rollout(self, x0, u, xref, noise, want_traj=False, want_mean=False):
+        H, P = self.H, self.P
+        x0, u, xref, noise = _f32(x0), _f32(u), _f32(xref), _f32(noise)
+        assert u.shape == (H, self.m) and xref.shape == (H + 1, 13) and noise.shape == (P, H, 6)
+        cost = C.c_double()
+        traj = np.zeros((P, H + 1, 13), np.float32) if want_traj else None
+        mean = np.zeros((H + 1, 13), np.float32) if want_mean else None
+        rc = self._fn("rollout")(C.byref(self.cfg), self._blobbuf, _fp(x0), _fp(u), _fp(xref), _fp(noise), C.byref(cost),
+                                 _fp(traj) if want_traj else None, _fp(mean) if want_mean else None)
+        assert rc == 0, rc
+        return cost.value, traj, mean
+
+    def grad(self, x0, u, xref, noise):
+        x0, u, xref, noise = _f32(x0), _f32(u), _f32(xref), _f32(noise)
+        cost = C.c_double()
+        g = np.zeros((self.H, self.m), np.float64)
+        rc = self._fn("grad")(C.byref(self.cfg), self._blobbuf, _fp(x0), _fp(u), _fp(xref), _fp(noise), C.byref(cost), _dp(g))
+        assert rc == 0, rc
+        return cost.value, g
+
+    def cost_du(self, x0, u64, xref, noise):
+        x0, xref, noise = _f32(x0), _f32(xref), _f32(noise)
+        u64 = np.ascontiguousarray(u64, dtype=np.float64)
+        cost = C.c_double()
+        rc = self._fn("cost_du")(C.byref(self.cfg), self._blobbuf, _fp(x0), _dp(u64), _fp(xref), _fp(noise), C.byref(cost))
+        assert rc == 0, rc
+        return cost.value
+
+    def solve(self, x0, xref, noise, u_init, stepsize_in, trace_cap=0):
+        x0, xref, noise, u_init = _f32(x0), _f32(xref), _f32(noise), _f32(u_init)
+        uopt = np.zeros((self.H, self.m), np.float32)
+        xevol = np.zeros((self.H + 1, 13), np.float32)
+        info = np.zeros(8, np.float32)
+        trace = np.zeros((trace_cap, 4), np.float32) if trace_cap else None
+        rc = self._fn("solve")(C.byref(self.cfg), self._blobbuf, _fp(x0), _fp(xref), _fp(noise), _fp(u_init),
+                               C.c_float(stepsize_in), _fp(uopt), _fp(xevol), _fp(info),
+                               _fp(trace) if trace_cap else None, C.c_int(trace_cap))
+        assert rc == 0, rc
+        return uopt, xevol, info, trace
+
+    def solve_batch(self, x0, xref, noise, u_init, stepsize_in):
+        B = x0.shape[0]
+        x0, xref, noise, u_init, stepsize_in = _f32(x0), _f32(xref), _f32(noise), _f32(u_init), _f32(stepsize_in)
+        uopt = np.zeros((B, self.H, self.m), np.float32)
+        xevol = np.zeros((B, self.H + 1, 13), np.float32)
+        info = np.zeros((B, 8), np.float32)
+        rc = self._fn("solve_batch")(C.byref(self.cfg), self._blobbuf, C.c_int(B), _fp(x0), _fp(xref), _fp(noise), _fp(u_init),
+                                     _fp(stepsize_in), _fp(uopt), _fp(xevol), _fp(info))
+        assert rc == 0, rc
+        return uopt, xevol, info
+
+    def step(self, x, u, xi, t=0):
+        x, u, xi = _f32(x), _f32(u), _f32(xi)
+        xn = np.zeros(13, np.float32)
+        eta = C.c_float()
+        rc = self._fn("step")(C.byref(self.cfg), self._blobbuf, _fp(x), _fp(u), _fp(xi), C.c_int(t), _fp(xn), C.byref(eta))
+        assert rc == 0, rc
+        return xn, eta.value

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the MPC inner loop on MI355X: MPC solves/sec (+ p50 solve latency), Iris H=50 P=128.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched under torch.distributed.run,
+one rank per GPU over RCCL). A "step" = one launch of the solve kernel over one batch of B independent
+MPC problem instances per GPU (synthetic initial states; inputs already resident in HBM). Weak scaling:
+B per GPU is fixed, instances are sharded one batch per GPU with no data-path collective; rank 0
+broadcasts the shared model blob once over RCCL at start-up. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+F32_MFMA_PEAK_TF = 157.3     # dense f32-input MFMA peak (= f32 vector peak), same guide
+
+
+def algorithmic_counts(cfg, n_it, n_ls):
+    """SURVEY.md §8(d) per-solve algorithmic bytes and flops (n_w = 6 noisy dims, f32)."""
+    P, H, m = cfg.num_particles, cfg.horizon, cfg.num_motors
+    nw = 6
+    b_grad = 4 * (P * H * nw + 2 * P * (H + 1) * 13 + P * H * nw + 2 * H * m + (H + 1) * 13)
+    b_ls = 4 * (P * H * nw + H * m + (H + 1) * 13)
+    w_bytes = 4 * 2120
+    # init-cost rollout and final mean-trajectory rollout are forward-only passes too
+    bytes_solve = n_it * b_grad + (n_ls + 2) * b_ls + w_bytes
+    f_step = 2 * ((6 + m) * 32 + 32 * 32 + 32 * 6) + 2 * (6 * 32 + 32 * 1)   # drift + density nets, forward
+    flops_solve = f_step * P * H * (2 * n_it + n_ls + 2)
+    return bytes_solve, flops_solve, b_grad, b_ls
+
+
+def cpu_baseline(cfg, model, n_threads, x0, xref, noise, u0, s0):
+    """Oracle (CPU restatement, kind 'port') on the host cores: one solve per thread, wall clock."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    oracles = [orc.Oracle(cfg, model) for _ in range(n_threads)]
+    out = [None] * n_threads
+
+    def work(i):
+        out[i] = oracles[i].solve(x0[i], xref[i], noise[i], u0[i], s0)
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    dt = time.time() - t0
+    return n_threads / dt, dt, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=2048, help="MPC problem instances per GPU per step")
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "c2_iris_traj_h50_p128.yaml"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--latency-reps", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from sde4mbrl_px4_amd import load_mpc_config, synthetic_hexa, synthetic_iris
+    from sde4mbrl_px4_amd import workload as W
+    from sde4mbrl_px4_amd.solver import SdeMpcSolver
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = load_mpc_config(args.config)
+    H, P, m, B = cfg.horizon, cfg.num_particles, cfg.num_motors, args.batch
+    # shared model: rank 0 builds it, RCCL broadcast over xGMI (read-only weights are the only shared data)
+    blob = (synthetic_iris() if m == 4 else synthetic_hexa()).to_blob()
+    blob_t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    if world > 1:
+        if rank != 0:
+            blob_t.zero_()
+        dist.broadcast(blob_t, src=0)
+    blob = bytes(blob_t.cpu().numpy().tobytes())
+
+    solver = SdeMpcSolver(cfg, blob, max_batch=B, device=local_rank)
+    # synthetic inputs, distinct per rank, resident in HBM before timing
+    seed0 = rank * B
+    x0_h = W.random_initial_states(B, seed0)
+    xref_h = np.stack([W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(B)])
+    rng = np.random.default_rng(12345 + rank)
+    nd = solver.lib.sdempc_noise_dev_floats(solver._h, B)
+    noise_dev_h = rng.standard_normal(nd, dtype=np.float32)  # generated directly in the device layout
+    yk, info0 = solver.reset()
+    u0_h = np.tile(yk[None], (B, 1, 1))
+    s0 = float(info0["stepsize"])
+    x0 = torch.from_numpy(x0_h).to(dev)
+    xref = torch.from_numpy(xref_h).to(dev)
+    noise = torch.from_numpy(noise_dev_h).to(dev)
+    u0 = torch.from_numpy(u0_h).to(dev)
+    step_in = torch.full((B,), s0, dtype=torch.float32, device=dev)
+    uopt = torch.empty((B, H, m), dtype=torch.float32, device=dev)
+    xevol = torch.empty((B, H + 1, 13), dtype=torch.float32, device=dev)
+    info = torch.empty((B, 8), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        solver.solve_dev(B, x0.data_ptr(), xref.data_ptr(), noise.data_ptr(), u0.data_ptr(), step_in.data_ptr(),
+                         uopt.data_ptr(), xevol.data_ptr(), info.data_ptr(), stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(None)
+    # HIP-event duration of the last launch on its own stream (events recorded inside the C ABI)
+    sync_all()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # per-launch kernel duration from HIP events, measured live on the launch stream (separate launches)
+    ev_ms = []
+    for _ in range(min(args.steps, 3)):
+        step()
+        ev_ms.append(solver.last_kernel_ms())
+    torch.cuda.synchronize()
+    info_h = info.cpu().numpy()
+    n_it = float(info_h[:, 2].mean())
+    n_ls = float(info_h[:, 7].mean())
+
+    if rank == 0:
+        solves = world * B * args.steps
+        value = solves / elapsed
+        bytes_solve, flops_solve, b_grad, b_ls = algorithmic_counts(cfg, n_it, n_ls)
+        k_ms = float(np.mean(ev_ms))
+        ach_gbs = bytes_solve * B / (k_ms * 1e-3) / 1e9
+        ach_tf = flops_solve * B / (k_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                key = f"{os.path.basename(args.config)}:B{B}"
+                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        # p50 latency of a single solve (B=1 launches), outside the timed region
+        lat = []
+        for _ in range(args.latency_reps):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            solver.solve_dev(1, x0.data_ptr(), xref.data_ptr(), noise.data_ptr(), u0.data_ptr(), step_in.data_ptr(),
+                             uopt.data_ptr(), xevol.data_ptr(), info.data_ptr(), stream)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t) * 1e3)
+        out = {
+            "metric": "MPC solves/sec, Iris H=50 P=128 (p50 solve latency in p50_solve_latency_ms)",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{os.path.basename(args.config)}: H={H} P={P} m={m}, {B} independent MPC instances per GPU per step, "
+                                   f"cold-start solves from the hover guess, max_iter={cfg.max_iter} maxls={cfg.ls_maxls}",
+                       "instances_per_gpu": B, "N_it_mean": n_it, "N_ls_mean": n_ls, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+            "p50_solve_latency_ms": float(np.median(lat)),
+            "p50_batch_latency_ms": float(np.median(ev_ms)),
+            "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
+                         "traffic": traffic, "kernel": "sdempc_solve_kernel<4>", "kernel_ms": k_ms,
+                         "note": "f32-exact path: MLP contractions on v_mfma_f32_32x32x2_f32 (157.3 TF dense peak = f32 vector peak); "
+                                 "algorithmic flops = SURVEY §8d MLP formula x P*H*(2*N_it+N_ls+2)"},
+            "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+                             "traffic": traffic, "bytes_per_solve": bytes_solve, "B_grad": b_grad, "B_ls": b_ls},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            nthr = args.cpu_threads or min(os.cpu_count() or 1, 64)
+            from sde4mbrl_px4_amd.model import RotorSDEModel  # noqa: F401
+            noise_h = W.make_noise(nthr, P, H, 777)
+            xb = W.random_initial_states(nthr, 0)
+            xr = np.stack([W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(nthr)])
+            ub = np.tile(yk[None], (nthr, 1, 1))
+            v, dt, _ = cpu_baseline(cfg, blob, nthr, xb, xr, noise_h, ub, s0)
+            out["cpu_baseline"] = {"value": v, "unit": "solves/s", "cores": nthr, "kind": "port",
+                                   "sample": f"{nthr} solves of the same workload (one per thread, {dt:.1f} s wall) by the C oracle "
+                                             "(CPU restatement, not the reference JAX path: that cannot run here)"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    solver.close()
+
+
+if __name__ == "__main__":
+    main()

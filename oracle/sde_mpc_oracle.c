@@ -366,8 +366,8 @@ static void step_vjp(const model_t* M, const real* x, const real* xi, real dt, c
     real zb[NN];
     for (int k = 0; k < NN; ++k) {
         real P0 = 0, P1 = 0;
-        for (int r = 0; r < 16; ++r) { P0 = FMA(M->W1z[rowmap(r, 0)][k], a1d[rowmap(r, 0)], P0); P1 = FMA(M->W1z[rowmap(r, 1)][k], a1d[rowmap(r, 1)], P1); }
         for (int r = 0; r < 16; ++r) { P0 = FMA(M->W1z[HID + rowmap(r, 0)][k], a1n[rowmap(r, 0)], P0); P1 = FMA(M->W1z[HID + rowmap(r, 1)][k], a1n[rowmap(r, 1)], P1); }
+        for (int r = 0; r < 16; ++r) { P0 = FMA(M->W1z[rowmap(r, 0)][k], a1d[rowmap(r, 0)], P0); P1 = FMA(M->W1z[rowmap(r, 1)][k], a1d[rowmap(r, 1)], P1); }
         zb[k] = P0 + P1;
     }
     for (int j = 0; j < M->m; ++j) {

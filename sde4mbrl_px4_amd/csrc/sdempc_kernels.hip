@@ -96,6 +96,7 @@ DI float sigmoid_spec(float x) {
 // ------------------------------------------------------------------------------------------------
 struct Smem {
     float *W3, *w3n, *b1n, *b2, *b1d, *W1zT, *W1uT;  // weights, row-major in hidden-unit index
+    float *A2, *A2T;                                   // MFMA A operands of W2 / W2^T: [q][lane][4]
     float *ust;                                        // [H][36]: c[32], Tz, tau[3]
     float *xref;                                       // [H+1][13]
     float *SX;                                         // max(4*H*12, 4*(H+1)*13): per-wave partials
@@ -115,6 +116,8 @@ DI Smem carve(float* base, int H, int m) {
     s.b1d = p; p += HID;
     s.W1zT = p; p += NN * 2 * HID;
     s.W1uT = p; p += 8 * HID;
+    s.A2 = p; p += HID * HID;
+    s.A2T = p; p += HID * HID;
     s.ust = p; p += H * UST;
     s.xref = p; p += ((H + 1) * NX + 3) & ~3;
     s.SX = p; p += 4 * (H + 1) * NX;
@@ -127,7 +130,7 @@ DI Smem carve(float* base, int H, int m) {
     return s;
 }
 size_t smem_bytes(int H, int m) {
-    size_t f = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 4 * (H + 1) * NX +
+    size_t f = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + 2 * HID * HID + (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 4 * (H + 1) * NX +
                ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
     return f * sizeof(float);
 }
@@ -138,9 +141,11 @@ constexpr int OFF_W1Z = 56, OFF_B1 = OFF_W1Z + 384, OFF_W1U = OFF_B1 + 64, OFF_W
 
 // MFMA A operands kept in registers for the whole kernel
 struct WaveW {
-    float w1d[3], w1n[3], w2[16], w2t[16];
+    float w1d[3], w1n[3];
 };
 
+DI int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
+DI int opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
 DI int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid) {
@@ -160,23 +165,52 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid) {
     int lane = tid & 63, j = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int s = 0; s < 3; ++s) { ww.w1d[s] = w[OFF_W1Z + j * NN + 2 * s + h]; ww.w1n[s] = w[OFF_W1Z + (HID + j) * NN + 2 * s + h]; }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ww.w2[r] = w[OFF_W2 + j * HID + rowmap(r, h)]; ww.w2t[r] = w[OFF_W2 + rowmap(r, h) * HID + j]; }
+    // A operand of k-step r for lane l: W2[j][rowmap(r,h)] (forward) / W2[rowmap(r,h)][j] (transpose)
+    for (int i = tid; i < HID * HID; i += NT) {
+        int c = i & 3, l = (i >> 2) & 63, q = i >> 8, jj = l & 31, hh = l >> 5, r = 4 * q + c;
+        sm.A2[i] = w[OFF_W2 + jj * HID + rowmap(r, hh)];
+        sm.A2T[i] = w[OFF_W2 + rowmap(r, hh) * HID + jj];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // block-wide helpers (all 256 threads call; the result is identical in every thread)
 // ------------------------------------------------------------------------------------------------
-DI float wave_bfly64(float v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s);
-    return v;
+// Cross-lane sums without LDS traffic. Each stage adds the value of the xor-partner lane; because
+// float addition is commutative and every stage leaves partner lanes bitwise equal, rotations inside
+// already-periodic rows reproduce the xor butterfly of SPEC.md §6 exactly:
+//   xor 32: v_permlane32_swap(v,v) -> {lo,lo},{hi,hi};  xor 16: v_permlane16_swap(v,v);
+//   xor 8 / 4: DPP row_ror:8 / row_ror:4 (rows are 8-periodic after the xor-8 stage);
+//   xor 2 / 1: DPP quad_perm [2,3,0,1] / [1,0,3,2].
+template <int CTRL>
+DI float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// NB: the swap instructions exchange halves/rows BETWEEN two registers; given the same register twice
+// they alias (tools/lane_probe.hip), so the second operand is forced into its own VGPR.
+DI float xor32_sum(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(b) : "v"(a));            // (a tied "+v" copy gets folded away by LLVM)
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);   // r[0] = {lo,lo}, r[1] = {hi,hi}
+    const unsigned r0 = r[0], r1 = r[1];   // (bit_cast straight from r[1] reads element 0: keep the temporaries)
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+DI float xor16_sum(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(b) : "v"(a));
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);   // r[0] = {r0,r0,r2,r2}, r[1] = {r1,r1,r3,r3}
+    const unsigned r0 = r[0], r1 = r[1];
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
 }
 DI float group_bfly32(float v) {
-#pragma unroll
-    for (int s = 16; s >= 1; s >>= 1) v = v + __shfl_xor(v, s);
+    v = xor16_sum(v);
+    v = v + dpp_f<0x128>(v);  // row_ror:8
+    v = v + dpp_f<0x124>(v);  // row_ror:4
+    v = v + dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = v + dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
     return v;
 }
+DI float wave_bfly64(float v) { return group_bfly32(xor32_sum(v)); }
 // SPEC.md §6.2 dot256: lane chains e = tid, tid+256, ...; butterflies; ((w0+w1)+w2)+w3
 DI float block_dot(const Smem& sm, const float* x, const float* y, int N, int tid) {
     float acc = 0.0f;
@@ -264,9 +298,8 @@ struct StepAux {
     float eta, Fb[3], Jom[3], rn, qn[4];
 };
 
-DI float xhalf(float v) { return __shfl_xor(v, 32); }
 
-DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, const float* x, const float* xi, float* xn, StepAux& A) {
+DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, float* xn, StepAux& A) {
     const float* ust = sm.ust + t * UST;
     const float dt = sm.dt[t];
     const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
@@ -280,6 +313,8 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
 #pragma unroll
     for (int j = 0; j < 3; ++j) z[j] = FMA(Rm[6 + j], x[5], FMA(Rm[3 + j], x[4], Rm[j] * x[3]));
     z[3] = x[10]; z[4] = x[11]; z[5] = x[12];
+    __builtin_amdgcn_sched_barrier(0);
+
     // layer 1: C operand = per-step offsets (drift) / bias (density); K = 6 -> 3 MFMAs per tile
     f32x16 accD, accN;
 #pragma unroll
@@ -295,9 +330,15 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
         accD = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1d[s], b, accD, 0, 0, 0);
         accN = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1n[s], b, accN, 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+
     tanh16(accD);
+    __builtin_amdgcn_sched_barrier(0);
+
     tanh16(accN);
     A.h1d = accD; A.h1n = accN;
+    __builtin_amdgcn_sched_barrier(0);
+
     // layer 2 (drift): B operand of k-step r is accumulator register r of layer 1
     f32x16 acc2;
 #pragma unroll
@@ -306,20 +347,36 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
         acc2[4 * q] = b4.x; acc2[4 * q + 1] = b4.y; acc2[4 * q + 2] = b4.z; acc2[4 * q + 3] = b4.w;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w2[r], accD[r], acc2, 0, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+        float4 w4 = *reinterpret_cast<const float4*>(sm.A2 + (q * 64 + lane) * 4);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, accD[4 * q], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, accD[4 * q + 1], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, accD[4 * q + 2], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, accD[4 * q + 3], acc2, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
     tanh16(acc2);
     A.h2 = acc2;
+    __builtin_amdgcn_sched_barrier(0);
+
     // output layers on the VALU: per-half partial chains, then (P0 + P1) + bias
     float o[6];
+    {
+        float Po[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        float P = 0.0f;
+        for (int i = 0; i < 6; ++i) Po[i] = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
-            P = FMA(w4.x, acc2[4 * q], P); P = FMA(w4.y, acc2[4 * q + 1], P); P = FMA(w4.z, acc2[4 * q + 2], P); P = FMA(w4.w, acc2[4 * q + 3], P);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
+                Po[i] = FMA(w4.x, acc2[4 * q], Po[i]); Po[i] = FMA(w4.y, acc2[4 * q + 1], Po[i]); Po[i] = FMA(w4.z, acc2[4 * q + 2], Po[i]); Po[i] = FMA(w4.w, acc2[4 * q + 3], Po[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        o[i] = (P + xhalf(P)) + a.M.b3[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[i] = xor32_sum(Po[i]) + a.M.b3[i];
     }
     float eta;
     {
@@ -329,9 +386,11 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
             float4 w4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
             P = FMA(w4.x, accN[4 * q], P); P = FMA(w4.y, accN[4 * q + 1], P); P = FMA(w4.z, accN[4 * q + 2], P); P = FMA(w4.w, accN[4 * q + 3], P);
         }
-        eta = sigmoid_spec((P + xhalf(P)) + a.M.b3n);
+        eta = sigmoid_spec(xor32_sum(P) + a.M.b3n);
     }
     A.eta = eta;
+    __builtin_amdgcn_sched_barrier(0);
+
     // rigid body
     A.Fb[0] = a.M.sF[0] * o[0]; A.Fb[1] = a.M.sF[1] * o[1]; A.Fb[2] = FMA(a.M.sF[2], o[2], ust[32]);
     float acc[3];
@@ -403,7 +462,7 @@ DI float stage_cost(const KArgs& a, const float* x, const float* xr, float* gx) 
 // gq[m+1..m+3] = rotor-torque adjoint
 // ------------------------------------------------------------------------------------------------
 template <int M>
-DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, const float* x, const float* xi, const StepAux& A,
+DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, const StepAux& A,
                  const float* L, float etabar_cost, float* lam, float* gq) {
     const float dt = sm.dt[t];
     const float* sdt = sm.sdt + t * NN;
@@ -443,64 +502,84 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     for (int i = 0; i < 3; ++i) { ob[i] = a.M.sF[i] * Fbb[i]; ob[3 + i] = a.M.sT[i] * taub_b[i]; }
     gq[M] = Fbb[2];
     gq[M + 1] = taub_b[0]; gq[M + 2] = taub_b[1]; gq[M + 3] = taub_b[2];
-    // MLP VJP: abar2 on the VALU, W2^T abar2 by MFMA in the accumulator layout
-    f32x16 a2b;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f, hb3 = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
-            hb0 = FMA(w4.x, ob[i], hb0); hb1 = FMA(w4.y, ob[i], hb1); hb2 = FMA(w4.z, ob[i], hb2); hb3 = FMA(w4.w, ob[i], hb3);
-        }
-        a2b[4 * q] = hb0 * FMA(-A.h2[4 * q], A.h2[4 * q], 1.0f);
-        a2b[4 * q + 1] = hb1 * FMA(-A.h2[4 * q + 1], A.h2[4 * q + 1], 1.0f);
-        a2b[4 * q + 2] = hb2 * FMA(-A.h2[4 * q + 2], A.h2[4 * q + 2], 1.0f);
-        a2b[4 * q + 3] = hb3 * FMA(-A.h2[4 * q + 3], A.h2[4 * q + 3], 1.0f);
-    }
-    f32x16 accB;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w2t[r], a2b[r], accB, 0, 0, 0);
-    f32x16 a1d, a1n;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float4 w4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
-        float wn[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            int r = 4 * q + c;
-            a1d[r] = accB[r] * FMA(-A.h1d[r], A.h1d[r], 1.0f);
-            a1n[r] = (wn[c] * ebraw) * FMA(-A.h1n[r], A.h1n[r], 1.0f);
-        }
-    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // MLP VJP. Order chosen to keep few tiles live: density tile first (frees h1n), then the drift
+    // tile: abar2 on the VALU, W2^T abar2 by MFMA in the accumulator layout.
     float zb[NN];
+    {
+        float Pz[NN], Pu[M];
 #pragma unroll
-    for (int k = 0; k < NN; ++k) {
-        float P = 0.0f;
+        for (int k = 0; k < NN; ++k) Pz[k] = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < M; ++jj) Pu[jj] = 0.0f;
+        // density net: abar1n = (w3n * etaraw_bar) * (1 - h1n^2); zbar += W1z[32:64]^T abar1n
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + 8 * q + 4 * h);
-            P = FMA(w4.x, a1d[4 * q], P); P = FMA(w4.y, a1d[4 * q + 1], P); P = FMA(w4.z, a1d[4 * q + 2], P); P = FMA(w4.w, a1d[4 * q + 3], P);
+            float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
+            float an0 = (wn4.x * ebraw) * FMA(-A.h1n[4 * q], A.h1n[4 * q], 1.0f);
+            float an1 = (wn4.y * ebraw) * FMA(-A.h1n[4 * q + 1], A.h1n[4 * q + 1], 1.0f);
+            float an2 = (wn4.z * ebraw) * FMA(-A.h1n[4 * q + 2], A.h1n[4 * q + 2], 1.0f);
+            float an3 = (wn4.w * ebraw) * FMA(-A.h1n[4 * q + 3], A.h1n[4 * q + 3], 1.0f);
+#pragma unroll
+            for (int k = 0; k < NN; ++k) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + HID + 8 * q + 4 * h);
+                Pz[k] = FMA(w4.x, an0, Pz[k]); Pz[k] = FMA(w4.y, an1, Pz[k]); Pz[k] = FMA(w4.z, an2, Pz[k]); Pz[k] = FMA(w4.w, an3, Pz[k]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // drift net
+        f32x16 a2b;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + HID + 8 * q + 4 * h);
-            P = FMA(w4.x, a1n[4 * q], P); P = FMA(w4.y, a1n[4 * q + 1], P); P = FMA(w4.z, a1n[4 * q + 2], P); P = FMA(w4.w, a1n[4 * q + 3], P);
+            float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f, hb3 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
+                hb0 = FMA(w4.x, ob[i], hb0); hb1 = FMA(w4.y, ob[i], hb1); hb2 = FMA(w4.z, ob[i], hb2); hb3 = FMA(w4.w, ob[i], hb3);
+            }
+            a2b[4 * q] = hb0 * FMA(-A.h2[4 * q], A.h2[4 * q], 1.0f);
+            a2b[4 * q + 1] = hb1 * FMA(-A.h2[4 * q + 1], A.h2[4 * q + 1], 1.0f);
+            a2b[4 * q + 2] = hb2 * FMA(-A.h2[4 * q + 2], A.h2[4 * q + 2], 1.0f);
+            a2b[4 * q + 3] = hb3 * FMA(-A.h2[4 * q + 3], A.h2[4 * q + 3], 1.0f);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        zb[k] = P + xhalf(P);
+        f32x16 accB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.A2T + (q * 64 + lane) * 4);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, a2b[4 * q], accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, a2b[4 * q + 1], accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, a2b[4 * q + 2], accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, a2b[4 * q + 3], accB, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float ad0 = accB[4 * q] * FMA(-A.h1d[4 * q], A.h1d[4 * q], 1.0f);
+            float ad1 = accB[4 * q + 1] * FMA(-A.h1d[4 * q + 1], A.h1d[4 * q + 1], 1.0f);
+            float ad2 = accB[4 * q + 2] * FMA(-A.h1d[4 * q + 2], A.h1d[4 * q + 2], 1.0f);
+            float ad3 = accB[4 * q + 3] * FMA(-A.h1d[4 * q + 3], A.h1d[4 * q + 3], 1.0f);
+#pragma unroll
+            for (int k = 0; k < NN; ++k) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + 8 * q + 4 * h);
+                Pz[k] = FMA(w4.x, ad0, Pz[k]); Pz[k] = FMA(w4.y, ad1, Pz[k]); Pz[k] = FMA(w4.z, ad2, Pz[k]); Pz[k] = FMA(w4.w, ad3, Pz[k]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < M; ++jj) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W1uT + jj * HID + 8 * q + 4 * h);
+                Pu[jj] = FMA(w4.x, ad0, Pu[jj]); Pu[jj] = FMA(w4.y, ad1, Pu[jj]); Pu[jj] = FMA(w4.z, ad2, Pu[jj]); Pu[jj] = FMA(w4.w, ad3, Pu[jj]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < NN; ++k) zb[k] = xor32_sum(Pz[k]);
+#pragma unroll
+        for (int jj = 0; jj < M; ++jj) gq[jj] = xor32_sum(Pu[jj]);
     }
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        float P = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 w4 = *reinterpret_cast<const float4*>(sm.W1uT + j * HID + 8 * q + 4 * h);
-            P = FMA(w4.x, a1d[4 * q], P); P = FMA(w4.y, a1d[4 * q + 1], P); P = FMA(w4.z, a1d[4 * q + 2], P); P = FMA(w4.w, a1d[4 * q + 3], P);
-        }
-        gq[j] = P + xhalf(P);
-    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 3; ++i) omb[i] = omb[i] + zb[3 + i];
     float vbar[3];
@@ -540,6 +619,7 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
 //   store_traj: stream x_t to a.traj; want_mean: particle mean trajectory -> xmean_out (global)
 // ------------------------------------------------------------------------------------------------
 DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
+    b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;
     const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
     const bool want_mean = xmean_out != nullptr;
@@ -578,7 +658,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 #pragma unroll
                 for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
             }
-            step_fwd(a, sm, ww, t, h, x, xi, xn, A);
+            step_fwd(a, sm, ww, t, h, lane, x, xi, xn, A);
             float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
             l = FMA(a.C.res_mult * A.eta, A.eta, l);
             J = FMA(sm.disc[t], l, J);
@@ -621,6 +701,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 // ------------------------------------------------------------------------------------------------
 template <int M>
 DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const float* y, float* gout, int b, int tid) {
+    b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P, m = a.m;
     constexpr int nq = M + 4;
     const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
@@ -653,7 +734,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 #pragma unroll
                 for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
             }
-            step_fwd(a, sm, ww, t, h, x, xi, xn, A);
+            step_fwd(a, sm, ww, t, h, lane, x, xi, xn, A);
             float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
             l = FMA(a.C.res_mult * A.eta, A.eta, l);
             J = FMA(sm.disc[t], l, J);
@@ -672,45 +753,35 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         float lam[NX], xt[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) lam[i] = 0.0f;
-        // make this wave's own stores visible to its loads (same CU, same wave: program order)
+        // this wave's own stores of x_t must be visible to its loads (same CU: workgroup scope)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        {
-            const float* tp = tj + (size_t)(H - 1) * NX * 32;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xt[i] = tp[i * 32];
-#pragma unroll
-            for (int i = 0; i < NN; ++i) xi[i] = nz[((H - 1) * NN + i) * 32];
-        }
         for (int t = H - 1; t >= 0; --t) {
-            float xtp[NX], xip[NN];
-            if (t > 0) {
-                const float* tp = tj + (size_t)(t - 1) * NX * 32;
+            {
+                const float* tp = tj + (size_t)t * NX * 32;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) xtp[i] = tp[i * 32];
+                for (int i = 0; i < NX; ++i) xt[i] = tp[i * 32];
 #pragma unroll
-                for (int i = 0; i < NN; ++i) xip[i] = nz[((t - 1) * NN + i) * 32];
+                for (int i = 0; i < NN; ++i) xi[i] = nz[(t * NN + i) * 32];
             }
-            // x = x_{t+1}, xt = x_t
-            float gx[NX], L[NX], lamn[NX], gq[12];
-            step_fwd(a, sm, ww, t, h, xt, xi, xn, A);
-            stage_cost<true>(a, x, sm.xref + (t + 1) * NX, gx);
+            // x = x_{t+1}: fold the stage-cost gradient into the incoming adjoint
             const float dsc = sm.disc[t];
+            {
+                float gx[NX];
+                stage_cost<true>(a, x, sm.xref + (t + 1) * NX, gx);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) L[i] = FMA(dsc, gx[i], lam[i]);
+                for (int i = 0; i < NX; ++i) lam[i] = FMA(dsc, gx[i], lam[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float lamn[NX], gq[12];
+            step_fwd(a, sm, ww, t, h, lane, xt, xi, xn, A);
             float ebc = dsc * ((2.0f * a.C.res_mult) * A.eta);
-            step_vjp<M>(a, sm, ww, t, h, xt, xi, A, L, ebc, lamn, gq);
+            step_vjp<M>(a, sm, ww, t, h, lane, xt, xi, A, lam, ebc, lamn, gq);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { lam[i] = lamn[i]; x[i] = xt[i]; }
 #pragma unroll
             for (int k = 0; k < nq; ++k) {
                 float s = group_bfly32(valid ? gq[k] : 0.0f);
                 if (lane == 0) Sq[t * 12 + k] = Sq[t * 12 + k] + s;
-            }
-            if (t > 0) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) xt[i] = xtp[i];
-#pragma unroll
-                for (int i = 0; i < NN; ++i) xi[i] = xip[i];
             }
         }
     }

@@ -11,3 +11,17 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_first():
+    """PyTorch-ROCm bundles its own HIP runtime; when a process uses both torch and libsdempc.so the
+    torch runtime has to come up first. Harmless on the CPU box."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda")
+    except Exception:
+        pass
+    yield

@@ -1,0 +1,140 @@
+"""CPU tests: YAML schema parsing, model blob layout and the C-ABI library surface (no compute calls)."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cases import CDIR, ROOT
+from sde4mbrl_px4_amd import MPCConfig, load_mpc_config, synthetic_hexa, synthetic_iris
+from sde4mbrl_px4_amd import _abi
+
+REF_LAUNCH = "/root/reference/launch"
+
+
+def test_benchmark_configs_parse():
+    c2 = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml"))
+    assert (c2.horizon, c2.num_particles, c2.num_motors, c2.max_iter, c2.ls_maxls) == (50, 128, 4, 200, 4)
+    assert c2.perr == [100.0, 100.0, 200.0] and c2.qerr == [1.0, 1.0, 100.0] and c2.u_slew_constr is None
+    assert c2.moment_scale is None and c2.ls_reset_option == "increase" and c2.ls_max_stepsize == 1.0
+    np.testing.assert_allclose(c2.time_steps, np.full(50, 0.05, np.float32))
+    c1 = load_mpc_config(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"))
+    assert c1.max_iter == 100 and c1.ls_max_stepsize == 10.0 and c1.u_slew_constr[1] == [-26.0, 0.32] and c1.uerr == pytest.approx(0.01)
+    c3 = load_mpc_config(os.path.join(CDIR, "c3_hexa_traj_h50_p256.yaml"))
+    assert c3.num_motors == 6 and c3.uref == pytest.approx([0.42] * 6) and c3.num_particles == 256
+    c5 = load_mpc_config(os.path.join(CDIR, "c5_iris_traj_h200_p1024.yaml"))
+    assert (c5.horizon, c5.num_particles) == (200, 1024)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_LAUNCH), reason="reference tree not present (GPU box)")
+def test_reference_yaml_files_parse_verbatim():
+    """Every shipped MPC YAML of the reference parses; shipped sizes are H=20, P=1."""
+    files = sorted(glob.glob(os.path.join(REF_LAUNCH, "*_mpc.yaml")))
+    assert len(files) == 6
+    for f in files:
+        c = load_mpc_config(f)
+        assert c.horizon == 20 and c.num_particles == 1 and c.num_motors in (4, 6)
+        assert c.trajectory_path is None or c.trajectory_path.endswith(".csv")
+        cfg, keep = c.to_cfg()
+        assert cfg.struct_size == C.sizeof(_abi.SdempcCfg) and cfg.horizon == 20
+    iris = load_mpc_config(os.path.join(REF_LAUNCH, "iris_sitl_traj_mpc.yaml"))
+    ours = load_mpc_config(os.path.join(CDIR, "iris_traj_shipped_h20_p1.yaml"))
+    for k in ("uref", "uerr", "perr", "verr", "qerr", "werr", "res_mult", "u_slew_coeff", "horizon", "num_particles", "max_iter",
+              "beta_init", "atol", "rtol", "ls_init_stepsize", "ls_max_stepsize", "ls_coef", "ls_decrease_factor", "ls_increase_factor",
+              "ls_maxls", "input_bound", "discount", "short_step_dt"):
+        assert getattr(iris, k) == getattr(ours, k), k
+
+
+def test_time_grid_and_validation():
+    c = MPCConfig(horizon=7, num_short_dt=3, short_step_dt=0.02, long_step_dt=0.1)
+    np.testing.assert_allclose(c.time_steps, [0.02] * 3 + [0.1] * 4)
+    with pytest.raises(ValueError):
+        MPCConfig(ls_reset_option="bogus").to_cfg()
+    with pytest.raises(ValueError):
+        MPCConfig(uref=[0.7] * 3).to_cfg()
+    cfg, _ = MPCConfig(enforce_ubound=False).to_cfg()
+    assert cfg.u_lo[0] < -1e30 and cfg.u_hi[0] > 1e30
+
+
+def test_model_blob_layout():
+    for model in (synthetic_iris(), synthetic_hexa()):
+        blob = model.to_blob()
+        assert len(blob) == 4 * (_abi.BLOB_HEADER_INTS + _abi.BLOB_FLOATS)
+        hd = np.frombuffer(blob[:64], np.int32)
+        assert hd[0] == _abi.BLOB_MAGIC and hd[2] == model.num_motors and hd[3] == 32
+        f = np.frombuffer(blob[64:], np.float32)
+        assert f[0] == np.float32(1.0) / np.float32(model.mass)
+        np.testing.assert_array_equal(f[56:56 + 384].reshape(64, 6), model.W1z)
+        np.testing.assert_array_equal(f[56 + 384 + 64:56 + 384 + 64 + 256].reshape(32, 8)[:, :model.num_motors], model.W1u)
+    # hover equilibrium of the synthetic vehicles: thrust at uref equals weight (2 % tolerance)
+    m = synthetic_iris()
+    T = 4 * (m.thrust_poly[0] * 0.71 ** 2 + m.thrust_poly[1] * 0.71)
+    assert abs(T - m.mass * m.grav) < 0.02 * m.mass * m.grav
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "sdempc.h")).read()
+    return sorted(set(re.findall(r"\b(sdempc_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _abi.load_library()
+    syms = _header_symbols()
+    assert set(syms) == set(_abi.EXPORTED_SYMBOLS)
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert lib.sdempc_abi_version() == 1
+
+
+def test_handle_lifecycle_and_errors_without_gpu():
+    lib = _abi.load_library()
+    cfg_py = load_mpc_config(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"))
+    cfg, keep = cfg_py.to_cfg()
+    blob = synthetic_iris().to_blob()
+    buf = C.create_string_buffer(blob, len(blob))
+    h = C.c_void_p()
+    assert lib.sdempc_create(C.byref(cfg), buf, len(blob), 4, C.byref(h)) == 0
+    # m_reset is host-only: hover guess + initial telemetry (sde_control.py:706-707 reads .yk)
+    yk = np.zeros((20, 4), np.float32)
+    info = _abi.SdempcInfo()
+    x = np.zeros(13, np.float32)
+    fp = C.POINTER(C.c_float)
+    assert lib.sdempc_reset(h, x.ctypes.data_as(fp), x.ctypes.data_as(fp), yk.ctypes.data_as(fp), C.byref(info)) == 0
+    np.testing.assert_allclose(yk, 0.71)
+    assert info.stepsize == pytest.approx(0.01) and info.num_steps == 0
+    assert lib.sdempc_noise_dev_floats(h, 3) == 3 * 1 * 20 * 6 * 32
+    assert lib.sdempc_traj_dev_floats(h, 2) == 2 * 1 * 21 * 13 * 32
+    # capacity is checked before any device work
+    dummy = np.zeros(8, np.float32).ctypes.data_as(fp)
+    assert lib.sdempc_rollout_batch(h, 5, dummy, dummy, dummy, dummy, dummy, None, None) == -5
+    assert b"max_batch" in lib.sdempc_last_error(h)
+    lib.sdempc_destroy(h)
+    # bad arguments
+    h2 = C.c_void_p()
+    bad = _abi.SdempcCfg.from_buffer_copy(cfg)
+    bad.struct_size = 12
+    assert lib.sdempc_create(C.byref(bad), buf, len(blob), 1, C.byref(h2)) == -1
+    assert lib.sdempc_create(C.byref(cfg), buf, 100, 1, C.byref(h2)) == -2
+    hexa = synthetic_hexa().to_blob()
+    hb = C.create_string_buffer(hexa, len(hexa))
+    assert lib.sdempc_create(C.byref(cfg), hb, len(hexa), 1, C.byref(h2)) == -1     # 4-motor cfg, 6-motor model
+    assert b"num_motors" in lib.sdempc_last_error(None)
+    corrupted = bytearray(blob)
+    corrupted[0] ^= 0xFF
+    cb = C.create_string_buffer(bytes(corrupted), len(corrupted))
+    assert lib.sdempc_create(C.byref(cfg), cb, len(blob), 1, C.byref(h2)) == -2
+
+
+def test_no_cpu_fallback_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from sde4mbrl_px4_amd.solver import SdempcError, SdeMpcSolver
+    from sde4mbrl_px4_amd import workload as W
+    cfg = MPCConfig(horizon=4, num_short_dt=4, num_particles=2, max_iter=1)
+    S = SdeMpcSolver(cfg, synthetic_iris(), max_batch=1)
+    with pytest.raises(SdempcError, match="no HIP device|failed"):
+        S.rollout(W.random_initial_states(1), np.full((1, 4, 4), 0.7, np.float32), W.reference_window(0, cfg.time_steps)[None], W.make_noise(1, 2, 4))
+    S.close()

@@ -1,0 +1,225 @@
+"""GPU parity tests: the HIP path (through the C ABI, include/sdempc.h) against the CPU oracle and the
+committed golden vectors. Integer-like bar: float32 results are required to be BIT-IDENTICAL, which
+is stricter than the 1e-4 relative tolerance BASELINE.json's north_star asks for; the tolerance
+version of each check is asserted as well so a future non-reproducing kernel fails with a clear message.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from cases import CDIR, bits_differ, golden_cases, load_golden
+from sde4mbrl_px4_amd import MPCConfig, load_mpc_config, synthetic_hexa, synthetic_iris
+from sde4mbrl_px4_amd import workload as W
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4   # north_star tolerance (float32)
+
+
+def _solver(cfg, model, B):
+    from sde4mbrl_px4_amd.solver import SdeMpcSolver
+    return SdeMpcSolver(cfg, model, max_batch=B)
+
+
+def _close(a, b, what):
+    np.testing.assert_allclose(a, b, rtol=RTOL, atol=1e-5, err_msg=what)
+
+
+@pytest.mark.parametrize("name", list(golden_cases().keys()))
+def test_golden_vectors(name):
+    cfg, model, seed, curr_t, pos = golden_cases()[name]
+    g = load_golden(name)
+    S = _solver(cfg, model, 1)
+    cost, traj, xmean = S.rollout(g["x0"][None], g["u"][None], g["xref"][None], g["noise"][None], True, True)
+    _close(cost[0], g["cost"], "cost")
+    _close(traj[0, 0], g["traj_p0"], "traj")
+    assert cost[0] == g["cost"] and bits_differ(traj[0, :, -1, :], g["traj_last"]) == 0 and bits_differ(xmean[0], g["xmean"]) == 0
+    gc, grad = S.grad(g["x0"][None], g["u"][None], g["xref"][None], g["noise"][None])
+    _close(grad[0], g["grad"], "grad")
+    assert gc[0] == g["grad_cost"] and bits_differ(grad[0], g["grad"]) == 0
+    uopt, xevol, info = S.solve(g["x0"][None], g["xref"][None], g["noise"][None], g["u_init"][None], np.array([g["stepsize_in"]], np.float32))
+    _close(uopt[0], g["uopt"], "uopt")
+    _close(xevol[0], g["xevol"], "xevol")
+    assert bits_differ(uopt[0], g["uopt"]) == 0 and bits_differ(xevol[0], g["xevol"]) == 0 and bits_differ(info[0], g["info"]) == 0
+    # A8 post-processing of the driver loop (sde_control.py:428-432) on the GPU outputs
+    thrust = uopt[0].sum(axis=1) / uopt.shape[2]
+    wopt = np.stack([thrust, xevol[0, 1:, 10], xevol[0, 1:, 11], xevol[0, 1:, 12]]).T.astype(np.float64)
+    np.testing.assert_array_equal(wopt, g["wopt"])
+    S.close()
+
+
+def _problem(cfg, B, seed=0, pos=False):
+    H, P, m = cfg.horizon, cfg.num_particles, cfg.num_motors
+    x0 = W.random_initial_states(B, seed)
+    xref = np.stack([W.constant_reference(W.HOVER, H) if pos else W.reference_window(0.13 * b, cfg.time_steps) for b in range(B)])
+    noise = W.make_noise(B, P, H, seed)
+    rng = np.random.default_rng(seed + 5)
+    u = np.clip(np.asarray(cfg.uref, np.float32) + 0.1 * rng.standard_normal((B, H, m)), 1e-4, 1).astype(np.float32)
+    return x0, xref, noise, u
+
+
+EDGE = {
+    "P1": dict(horizon=9, num_short_dt=9, num_particles=1),
+    "P31": dict(horizon=7, num_short_dt=7, num_particles=31),
+    "P33": dict(horizon=7, num_short_dt=3, long_step_dt=0.1, num_particles=33),
+    "P160_5groups": dict(horizon=6, num_short_dt=6, num_particles=160),
+    "P290_ragged": dict(horizon=5, num_short_dt=5, num_particles=290),
+    "H1": dict(horizon=1, num_short_dt=1, num_particles=32),
+    "H130_N_gt_256": dict(horizon=130, num_short_dt=130, num_particles=32),
+    "discount_slewconstr": dict(horizon=12, num_short_dt=12, num_particles=40, discount=0.9, u_slew_coeff=0.5,
+                                u_slew_constr=[[-0.02, 0.03]] * 4, u_slew_constr_coeff=10.0),
+    "conservative_ls": dict(horizon=10, num_short_dt=10, num_particles=32, ls_reset_option="conservative"),
+    "moment_scale": dict(horizon=10, num_short_dt=10, num_particles=32, moment_scale=0.5),
+    "no_linesearch": dict(horizon=10, num_short_dt=10, num_particles=32, ls_maxls=0, stepsize=1e-4),
+    "unbounded_u": dict(horizon=10, num_short_dt=10, num_particles=32, enforce_ubound=False),
+}
+
+
+@pytest.mark.parametrize("name", list(EDGE.keys()))
+def test_edge_cases_bit_exact(name):
+    kw = dict(u_slew_coeff=1.0, max_iter=8, max_no_improvement_iter=8)
+    kw.update(EDGE[name])
+    cfg = MPCConfig(**kw)
+    model = synthetic_iris()
+    B = 3
+    x0, xref, noise, u = _problem(cfg, B, seed=21)
+    S, O = _solver(cfg, model, B), orc.Oracle(cfg, model)
+    cost, traj, xmean = S.rollout(x0, u, xref, noise, True, True)
+    gc, grad = S.grad(x0, u, xref, noise)
+    u0 = np.tile(np.asarray(cfg.uref, np.float32), (B, cfg.horizon, 1))
+    s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
+    uopt, xevol, info = S.solve(x0, xref, noise, u0, s0)
+    for b in range(B):
+        c, t, xm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True)
+        _close(cost[b], c, "cost")
+        assert cost[b] == np.float32(c) and bits_differ(traj[b], t) == 0 and bits_differ(xmean[b], xm) == 0
+        c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
+        _close(grad[b], g2, "grad")
+        assert gc[b] == np.float32(c2) and bits_differ(grad[b], g2.astype(np.float32)) == 0
+        uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u0[b], float(s0[b]))
+        _close(uopt[b], uo, "uopt")
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], inf) == 0
+    S.close()
+
+
+def test_hexa_six_motors_bit_exact():
+    cfg = load_mpc_config(os.path.join(CDIR, "c3_hexa_traj_h50_p256.yaml")).replace(horizon=14, num_short_dt=14, num_particles=96, max_iter=6, max_no_improvement_iter=6)
+    model = synthetic_hexa()
+    B = 2
+    x0, xref, noise, u = _problem(cfg, B, seed=4)
+    S, O = _solver(cfg, model, B), orc.Oracle(cfg, model)
+    gc, grad = S.grad(x0, u, xref, noise)
+    u0 = np.tile(np.asarray(cfg.uref, np.float32), (B, cfg.horizon, 1))
+    uopt, xevol, info = S.solve(x0, xref, noise, u0, np.full(B, 0.01, np.float32))
+    for b in range(B):
+        c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
+        assert gc[b] == np.float32(c2) and bits_differ(grad[b], g2.astype(np.float32)) == 0
+        uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u0[b], 0.01)
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], inf) == 0
+    S.close()
+
+
+def test_warm_start_chain_matches_oracle():
+    """Three consecutive ticks, each warm-started from the previous (uopt, stepsize) like mpc_process_fn
+    (sde_control.py:412: opt_state is threaded through successive calls)."""
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(horizon=16, num_short_dt=16, num_particles=64, max_iter=10, max_no_improvement_iter=10)
+    model = synthetic_iris()
+    S, O = _solver(cfg, model, 1), orc.Oracle(cfg, model)
+    x = W.random_initial_states(1, 9)
+    ug = uo = np.tile(np.asarray(cfg.uref, np.float32), (1, cfg.horizon, 1))
+    sg = so = 0.01
+    for tick in range(3):
+        xref = W.reference_window(0.05 * tick, cfg.time_steps)[None]
+        noise = W.make_noise(1, 64, 16, 100 + tick)
+        ug, xe_g, info_g = S.solve(x, xref, noise, ug, np.array([sg], np.float32))
+        u1, xe_o, info_o, _ = O.solve(x[0], xref[0], noise[0], uo[0], so)
+        uo = u1[None]
+        assert bits_differ(ug, uo) == 0 and bits_differ(xe_g[0], xe_o) == 0 and bits_differ(info_g[0], info_o) == 0
+        sg, so = float(info_g[0, 1]), float(info_o[1])
+        x = xe_g[:, 1, :].copy()
+    S.close()
+
+
+def test_batch_position_independence_and_determinism():
+    cfg = MPCConfig(horizon=10, num_short_dt=10, num_particles=64, u_slew_coeff=1.0, max_iter=5, max_no_improvement_iter=5)
+    model = synthetic_iris()
+    B = 37
+    x0, xref, noise, u = _problem(cfg, B, seed=2)
+    S = _solver(cfg, model, B)
+    u0 = np.tile(np.asarray(cfg.uref, np.float32), (B, 10, 1))
+    s0 = np.full(B, 0.01, np.float32)
+    a = S.solve(x0, xref, noise, u0, s0)
+    b = S.solve(x0, xref, noise, u0, s0)
+    for p, q in zip(a, b):
+        assert bits_differ(p, q) == 0                                   # run-to-run deterministic
+    perm = np.random.default_rng(0).permutation(B)
+    c = S.solve(x0[perm], xref[perm], noise[perm], u0[perm], s0[perm])
+    for p, q in zip(a, c):
+        assert bits_differ(p[perm], q) == 0                             # result independent of batch slot
+    S.close()
+
+
+def test_full_size_c2_properties_and_sampled_parity():
+    """BASELINE config C2 at full size (H=50, P=128): size-independent properties on a batch plus
+    bit-parity of the gradient and of a shortened solve on sampled instances."""
+    cfg_full = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml"))
+    cfg = cfg_full.replace(max_iter=12, max_no_improvement_iter=12)
+    model = synthetic_iris()
+    B = 24
+    x0, xref, noise, u = _problem(cfg, B, seed=50)
+    S, O = _solver(cfg, model, B), orc.Oracle(cfg, model)
+    cost, traj, xmean = S.rollout(x0, u, xref, noise, True, True)
+    assert np.all(np.isfinite(traj)) and np.abs(np.linalg.norm(traj[..., 6:10], axis=-1) - 1).max() < 1e-5
+    np.testing.assert_array_equal(traj[:, :, 0, :], np.repeat(x0[:, None, :], 128, axis=1))
+    np.testing.assert_allclose(xmean, traj.mean(axis=1), rtol=3e-5, atol=3e-6)
+    gc, grad = S.grad(x0, u, xref, noise)
+    assert bits_differ(gc, cost) == 0                                   # forward sweep of grad == rollout
+    u0 = np.tile(np.asarray(cfg.uref, np.float32), (B, 50, 1))
+    uopt, xevol, info = S.solve(x0, xref, noise, u0, np.full(B, 0.01, np.float32))
+    assert uopt.min() >= 1e-4 and uopt.max() <= 1.0
+    assert np.all(info[:, 6] <= info[:, 5]) and np.all(info[:, 2] == 12)
+    c_opt, _, xm = S.rollout(x0, uopt, xref, noise, False, True)
+    assert bits_differ(c_opt, info[:, 6]) == 0 and bits_differ(xm, xevol) == 0   # reported cost/trajectory belong to uopt
+    for b in (0, 11, 23):
+        c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
+        assert gc[b] == np.float32(c2) and bits_differ(grad[b], g2.astype(np.float32)) == 0
+        uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u0[b], 0.01)
+        _close(uopt[b], uo, "uopt")
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], inf) == 0
+    S.close()
+
+
+def test_device_resident_api_equals_host_api():
+    import torch
+    cfg = MPCConfig(horizon=10, num_short_dt=10, num_particles=40, u_slew_coeff=1.0, max_iter=4, max_no_improvement_iter=4)
+    model = synthetic_iris()
+    B = 5
+    x0, xref, noise, u = _problem(cfg, B, seed=8)
+    S = _solver(cfg, model, B)
+    u0 = np.tile(np.asarray(cfg.uref, np.float32), (B, 10, 1))
+    s0 = np.full(B, 0.01, np.float32)
+    ref = S.solve(x0, xref, noise, u0, s0)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    nd = t(S.noise_to_device_layout(noise))
+    tx0, txr, tu0, ts0 = t(x0), t(xref), t(u0), t(s0)
+    uopt = torch.empty((B, 10, 4), device=dev); xevol = torch.empty((B, 11, 13), device=dev); info = torch.empty((B, 8), device=dev)
+    S.solve_dev(B, tx0.data_ptr(), txr.data_ptr(), nd.data_ptr(), tu0.data_ptr(), ts0.data_ptr(), uopt.data_ptr(), xevol.data_ptr(), info.data_ptr(),
+                torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert S.last_kernel_ms() > 0
+    assert bits_differ(uopt.cpu().numpy(), ref[0]) == 0 and bits_differ(xevol.cpu().numpy(), ref[1]) == 0 and bits_differ(info.cpu().numpy(), ref[2]) == 0
+    S.close()
+
+
+def test_c5_long_horizon_shape_runs():
+    """C5 geometry (H=200, P=1024) through the f32 path: one gradient, parity on the cost and gradient."""
+    cfg = load_mpc_config(os.path.join(CDIR, "c5_iris_traj_h200_p1024.yaml"))
+    model = synthetic_iris()
+    x0, xref, noise, u = _problem(cfg, 1, seed=77)
+    S, O = _solver(cfg, model, 1), orc.Oracle(cfg, model)
+    gc, grad = S.grad(x0, u, xref, noise)
+    c2, g2 = O.grad(x0[0], u[0], xref[0], noise[0])
+    assert gc[0] == np.float32(c2) and bits_differ(grad[0], g2.astype(np.float32)) == 0
+    S.close()

@@ -1,0 +1,139 @@
+"""CPU tests of the oracle (oracle/sde_mpc_oracle.c): pins it against the committed golden vectors,
+checks the adjoint against finite differences (float64 build) and basic properties."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import orc
+from cases import bits_differ, golden_cases, load_golden
+from sde4mbrl_px4_amd import MPCConfig, synthetic_iris
+from sde4mbrl_px4_amd import workload as W
+
+
+def test_spec_functions_accuracy():
+    L = orc.lib()
+    fp = C.POINTER(C.c_float)
+    rng = np.random.default_rng(0)
+    xs = (rng.standard_normal((20000, 4)) * 4).astype(np.float32)
+    xs[:500] *= 5
+    out = np.zeros_like(xs)
+    for i in range(len(xs)):
+        L.orc_tanh4(xs[i].ctypes.data_as(fp), out[i].ctypes.data_as(fp))
+    assert np.abs(out - np.tanh(xs.astype(np.float64))).max() < 1e-6
+    assert np.all(np.abs(out) <= 1.0 + 1e-6)   # approximation may overshoot 1 by < 1e-6
+    x = np.linspace(-40, 40, 4001).astype(np.float32)
+    s = np.array([L.orc_sigmoid(float(v)) for v in x])
+    assert np.abs(s - 1 / (1 + np.exp(-x.astype(np.float64)))).max() < 2e-7
+    d = np.exp(np.linspace(0, 70, 4001)).astype(np.float32)
+    r = np.array([L.orc_rcp(float(v)) for v in d])
+    assert np.abs(r * d.astype(np.float64) - 1).max() < 2e-7
+    a = np.exp(np.linspace(-8, 8, 4001)).astype(np.float32)
+    r = np.array([L.orc_rsqrt(float(v)) for v in a])
+    assert np.abs(r * np.sqrt(a.astype(np.float64)) - 1).max() < 3e-7
+
+
+@pytest.mark.parametrize("name", list(golden_cases().keys()))
+def test_oracle_matches_golden(name):
+    """The restatement reproduces its committed vectors bit for bit (guards against drift)."""
+    cfg, model, seed, curr_t, pos = golden_cases()[name]
+    g = load_golden(name)
+    O = orc.Oracle(cfg, model)
+    cost, traj, xmean = O.rollout(g["x0"], g["u"], g["xref"], g["noise"], True, True)
+    assert np.float32(cost) == g["cost"]
+    assert bits_differ(traj[:, -1, :], g["traj_last"]) == 0 and bits_differ(traj[0], g["traj_p0"]) == 0
+    assert bits_differ(xmean, g["xmean"]) == 0
+    gc, grad = O.grad(g["x0"], g["u"], g["xref"], g["noise"])
+    assert np.float32(gc) == g["grad_cost"] and bits_differ(grad.astype(np.float32), g["grad"]) == 0
+    xn, eta = O.step(g["x0"], g["u"][0], g["noise"][0, 0], 0)
+    assert bits_differ(xn, g["step_xn"]) == 0 and np.float32(eta) == g["step_eta"]
+    uopt, xevol, info, tr = O.solve(g["x0"], g["xref"], g["noise"], g["u_init"], float(g["stepsize_in"]), trace_cap=cfg.max_iter)
+    assert bits_differ(uopt, g["uopt"]) == 0 and bits_differ(xevol, g["xevol"]) == 0 and bits_differ(info, g["info"]) == 0
+    assert bits_differ(tr, g["trace"]) == 0
+    # A8 post-processing (sde_control.py:428-432)
+    thrust = uopt.sum(axis=1) / uopt.shape[1]
+    wopt = np.stack([thrust, xevol[1:, 10], xevol[1:, 11], xevol[1:, 12]]).T
+    np.testing.assert_array_equal(wopt.astype(np.float64), g["wopt"])
+
+
+def _small_problem(H=8, P=5, m=4, seed=1, **kw):
+    cfg = MPCConfig(horizon=H, num_short_dt=max(1, H // 2), long_step_dt=0.08, num_particles=P, u_slew_coeff=0.7, discount=0.95,
+                    u_slew_constr=[[-0.05, 0.04]] * m, u_slew_constr_coeff=3.0, **kw)
+    model = synthetic_iris(seed)
+    x0 = W.random_initial_states(1, seed)[0]
+    xref = W.reference_window(0.3, cfg.time_steps)
+    noise = W.make_noise(1, P, H, seed)[0]
+    rng = np.random.default_rng(seed)
+    u = np.clip(0.71 + 0.1 * rng.standard_normal((H, m)), 1e-4, 1).astype(np.float32)
+    return cfg, model, x0, xref, noise, u
+
+
+def test_adjoint_matches_finite_differences_float64():
+    cfg, model, x0, xref, noise, u = _small_problem()
+    O64 = orc.Oracle(cfg, model, double=True)
+    c, g = O64.grad(x0, u, xref, noise)
+    u64 = u.astype(np.float64)
+    fd = np.zeros_like(g)
+    eps = 1e-6
+    for t in range(cfg.horizon):
+        for j in range(4):
+            up, um = u64.copy(), u64.copy()
+            up[t, j] += eps
+            um[t, j] -= eps
+            fd[t, j] = (O64.cost_du(x0, up, xref, noise) - O64.cost_du(x0, um, xref, noise)) / (2 * eps)
+    assert np.abs(fd - g).max() <= 1e-6 * max(1.0, np.abs(g).max())
+
+
+def test_float32_gradient_close_to_float64():
+    cfg, model, x0, xref, noise, u = _small_problem(H=20, P=32)
+    c32, g32 = orc.Oracle(cfg, model).grad(x0, u, xref, noise)
+    c64, g64 = orc.Oracle(cfg, model, double=True).grad(x0, u, xref, noise)
+    assert abs(c32 - c64) <= 1e-5 * abs(c64)
+    assert np.abs(g32 - g64).max() <= 2e-4 * np.abs(g64).max()
+
+
+def test_rollout_properties():
+    cfg, model, x0, xref, noise, u = _small_problem(H=25, P=33)
+    O = orc.Oracle(cfg, model)
+    cost, traj, xmean = O.rollout(x0, u, xref, noise, True, True)
+    assert np.isfinite(cost) and cost > 0
+    qn = np.linalg.norm(traj[:, :, 6:10], axis=-1)
+    assert np.abs(qn - 1).max() < 1e-5                       # quaternion renormalised every step
+    np.testing.assert_array_equal(traj[:, 0, :], np.tile(x0, (33, 1)))
+    np.testing.assert_allclose(xmean, traj.mean(axis=0), rtol=2e-5, atol=2e-6)
+    # zero diffusion amplitude -> all particles identical
+    model0 = synthetic_iris(1)
+    model0.sigma = np.zeros(6, np.float32)
+    _, traj0, _ = orc.Oracle(cfg, model0).rollout(x0, u, xref, noise, True, False)
+    assert np.abs(traj0 - traj0[:1]).max() == 0.0
+    # cost of identical particles does not depend on P (mean), up to rounding
+    cfgp1 = cfg.replace(num_particles=1)
+    c1, _, _ = orc.Oracle(cfgp1, model0).rollout(x0, u, xref, noise[:1], False, False)
+    c33, _, _ = orc.Oracle(cfg, model0).rollout(x0, u, xref, noise, False, False)
+    assert abs(c1 - c33) <= 1e-5 * abs(c1)
+
+
+def test_solve_is_monotone_bounded_and_deterministic():
+    cfg, model, x0, xref, noise, u = _small_problem(H=15, P=16, max_iter=30, max_no_improvement_iter=30)
+    O = orc.Oracle(cfg, model)
+    u0 = np.tile(np.float32(0.71), (15, 4))
+    uopt, xevol, info, tr = O.solve(x0, xref, noise, u0, cfg.ls_init_stepsize, trace_cap=30)
+    uopt2, xevol2, info2, _ = O.solve(x0, xref, noise, u0, cfg.ls_init_stepsize)
+    assert bits_differ(uopt, uopt2) == 0 and bits_differ(info, info2) == 0
+    assert uopt.min() >= 1e-4 and uopt.max() <= 1.0
+    assert info[6] <= info[5]                                  # opt_cost <= init_cost
+    c_opt, _, xm = O.rollout(x0, uopt, xref, noise, False, True)
+    assert np.float32(c_opt) == info[6]                        # reported cost is the cost of the returned controls
+    assert bits_differ(xm, xevol) == 0
+    n_it = int(info[2])
+    assert 1 <= n_it <= 30 and info[7] == tr[:n_it, 3].sum()
+    assert abs(info[0] - tr[:n_it, 3].mean()) < 1e-5
+
+
+def test_zero_iterations_returns_projected_warm_start():
+    cfg, model, x0, xref, noise, u = _small_problem(H=6, P=4, max_iter=0)
+    O = orc.Oracle(cfg, model)
+    u0 = (u + 0.6).astype(np.float32)                          # partly outside [1e-4, 1]
+    uopt, xevol, info, _ = O.solve(x0, xref, noise, u0, 0.01)
+    np.testing.assert_array_equal(uopt, np.clip(u0, np.float32(1e-4), np.float32(1.0)))
+    assert info[2] == 0 and info[5] == info[6]

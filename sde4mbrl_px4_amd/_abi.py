@@ -57,6 +57,10 @@ _LIB = None
 
 
 def lib_path():
+    """csrc/libsdempc.so; SDEMPC_LIB may name another build of the same library (kernel A/B runs)."""
+    override = os.environ.get("SDEMPC_LIB")
+    if override:
+        return os.path.abspath(override)
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libsdempc.so")
 
 

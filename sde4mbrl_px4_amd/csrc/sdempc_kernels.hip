@@ -32,6 +32,15 @@ namespace sdempc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 #define DI __device__ __forceinline__
+// phase fences for the instruction scheduler (SDEMPC_SB=0 lets hipcc interleave freely)
+#ifndef SDEMPC_SB
+#define SDEMPC_SB 1
+#endif
+#if SDEMPC_SB
+#define SCHED_PHASE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SCHED_PHASE() ((void)0)
+#endif
 
 constexpr int NX = 13, NN = 6, HID = 32, NT = 256, NW = 4;
 
@@ -313,7 +322,7 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
 #pragma unroll
     for (int j = 0; j < 3; ++j) z[j] = FMA(Rm[6 + j], x[5], FMA(Rm[3 + j], x[4], Rm[j] * x[3]));
     z[3] = x[10]; z[4] = x[11]; z[5] = x[12];
-    __builtin_amdgcn_sched_barrier(0);
+    SCHED_PHASE();
 
     // layer 1: C operand = per-step offsets (drift) / bias (density); K = 6 -> 3 MFMAs per tile
     f32x16 accD, accN;
@@ -330,14 +339,14 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
         accD = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1d[s], b, accD, 0, 0, 0);
         accN = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1n[s], b, accN, 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    SCHED_PHASE();
 
     tanh16(accD);
-    __builtin_amdgcn_sched_barrier(0);
+    SCHED_PHASE();
 
     tanh16(accN);
     A.h1d = accD; A.h1n = accN;
-    __builtin_amdgcn_sched_barrier(0);
+    SCHED_PHASE();
 
     // layer 2 (drift): B operand of k-step r is accumulator register r of layer 1
     f32x16 acc2;
@@ -354,11 +363,11 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, accD[4 * q + 2], acc2, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, accD[4 * q + 3], acc2, 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    SCHED_PHASE();
 
     tanh16(acc2);
     A.h2 = acc2;
-    __builtin_amdgcn_sched_barrier(0);
+    SCHED_PHASE();
 
     // output layers on the VALU: per-half partial chains, then (P0 + P1) + bias
     float o[6];
@@ -373,7 +382,7 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
                 float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
                 Po[i] = FMA(w4.x, acc2[4 * q], Po[i]); Po[i] = FMA(w4.y, acc2[4 * q + 1], Po[i]); Po[i] = FMA(w4.z, acc2[4 * q + 2], Po[i]); Po[i] = FMA(w4.w, acc2[4 * q + 3], Po[i]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            SCHED_PHASE();
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) o[i] = xor32_sum(Po[i]) + a.M.b3[i];
@@ -389,7 +398,7 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
         eta = sigmoid_spec(xor32_sum(P) + a.M.b3n);
     }
     A.eta = eta;
-    __builtin_amdgcn_sched_barrier(0);
+    SCHED_PHASE();
 
     // rigid body
     A.Fb[0] = a.M.sF[0] * o[0]; A.Fb[1] = a.M.sF[1] * o[1]; A.Fb[2] = FMA(a.M.sF[2], o[2], ust[32]);
@@ -502,7 +511,7 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     for (int i = 0; i < 3; ++i) { ob[i] = a.M.sF[i] * Fbb[i]; ob[3 + i] = a.M.sT[i] * taub_b[i]; }
     gq[M] = Fbb[2];
     gq[M + 1] = taub_b[0]; gq[M + 2] = taub_b[1]; gq[M + 3] = taub_b[2];
-    __builtin_amdgcn_sched_barrier(0);
+    SCHED_PHASE();
 
     // MLP VJP. Order chosen to keep few tiles live: density tile first (frees h1n), then the drift
     // tile: abar2 on the VALU, W2^T abar2 by MFMA in the accumulator layout.
@@ -526,7 +535,7 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
                 float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + HID + 8 * q + 4 * h);
                 Pz[k] = FMA(w4.x, an0, Pz[k]); Pz[k] = FMA(w4.y, an1, Pz[k]); Pz[k] = FMA(w4.z, an2, Pz[k]); Pz[k] = FMA(w4.w, an3, Pz[k]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            SCHED_PHASE();
         }
         // drift net
         f32x16 a2b;
@@ -542,7 +551,7 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
             a2b[4 * q + 1] = hb1 * FMA(-A.h2[4 * q + 1], A.h2[4 * q + 1], 1.0f);
             a2b[4 * q + 2] = hb2 * FMA(-A.h2[4 * q + 2], A.h2[4 * q + 2], 1.0f);
             a2b[4 * q + 3] = hb3 * FMA(-A.h2[4 * q + 3], A.h2[4 * q + 3], 1.0f);
-            __builtin_amdgcn_sched_barrier(0);
+            SCHED_PHASE();
         }
         f32x16 accB;
 #pragma unroll
@@ -555,7 +564,7 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, a2b[4 * q + 2], accB, 0, 0, 0);
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, a2b[4 * q + 3], accB, 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        SCHED_PHASE();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float ad0 = accB[4 * q] * FMA(-A.h1d[4 * q], A.h1d[4 * q], 1.0f);
@@ -572,14 +581,14 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
                 float4 w4 = *reinterpret_cast<const float4*>(sm.W1uT + jj * HID + 8 * q + 4 * h);
                 Pu[jj] = FMA(w4.x, ad0, Pu[jj]); Pu[jj] = FMA(w4.y, ad1, Pu[jj]); Pu[jj] = FMA(w4.z, ad2, Pu[jj]); Pu[jj] = FMA(w4.w, ad3, Pu[jj]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            SCHED_PHASE();
         }
 #pragma unroll
         for (int k = 0; k < NN; ++k) zb[k] = xor32_sum(Pz[k]);
 #pragma unroll
         for (int jj = 0; jj < M; ++jj) gq[jj] = xor32_sum(Pu[jj]);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    SCHED_PHASE();
 #pragma unroll
     for (int i = 0; i < 3; ++i) omb[i] = omb[i] + zb[3 + i];
     float vbar[3];
@@ -771,7 +780,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 #pragma unroll
                 for (int i = 0; i < NX; ++i) lam[i] = FMA(dsc, gx[i], lam[i]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            SCHED_PHASE();
             float lamn[NX], gq[12];
             step_fwd(a, sm, ww, t, h, lane, xt, xi, xn, A);
             float ebc = dsc * ((2.0f * a.C.res_mult) * A.eta);

@@ -89,13 +89,9 @@ def main():
     cfg = load_mpc_config(args.config)
     H, P, m, B = cfg.horizon, cfg.num_particles, cfg.num_motors, args.batch
     # shared model: rank 0 builds it, RCCL broadcast over xGMI (read-only weights are the only shared data)
-    blob = (synthetic_iris() if m == 4 else synthetic_hexa()).to_blob()
-    blob_t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
-    if world > 1:
-        if rank != 0:
-            blob_t.zero_()
-        dist.broadcast(blob_t, src=0)
-    blob = bytes(blob_t.cpu().numpy().tobytes())
+    from sde4mbrl_px4_amd.dist import broadcast_blob, max_over_ranks
+    blob = (synthetic_iris() if m == 4 else synthetic_hexa()).to_blob() if rank == 0 else b""
+    blob = broadcast_blob(blob, src=0, device=dev)
 
     solver = SdeMpcSolver(cfg, blob, max_batch=B, device=local_rank)
     # synthetic inputs, distinct per rank, resident in HBM before timing
@@ -131,19 +127,13 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(None)
-    # HIP-event duration of the last launch on its own stream (events recorded inside the C ABI)
     sync_all()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed, device=dev)
     # per-launch kernel duration from HIP events, measured live on the launch stream (separate launches)
     ev_ms = []
     for _ in range(min(args.steps, 3)):

@@ -1,0 +1,67 @@
+"""Multi-GPU plumbing: independent MPC problem instances sharded over ranks.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for
+tests). The only shared data are the read-only model weights: rank 0 broadcasts the blob once at
+start-up. There is no per-solve or per-iteration collective — each instance owns its decision
+variables — so scaling is weak: instances per GPU stay fixed as ranks are added.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def is_distributed() -> bool:
+    d = _dist()
+    return d.is_available() and d.is_initialized() and d.get_world_size() > 1
+
+
+def broadcast_blob(blob, src: int = 0, device=None) -> bytes:
+    """Rank `src` supplies the model blob (bytes); every rank returns the same bytes."""
+    import torch
+    if not is_distributed():
+        return bytes(blob)
+    d = _dist()
+    n = torch.tensor([len(blob) if d.get_rank() == src else 0], dtype=torch.int64, device=device)
+    d.broadcast(n, src=src)
+    buf = torch.zeros(int(n.item()), dtype=torch.uint8, device=device)
+    if d.get_rank() == src:
+        buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+    d.broadcast(buf, src=src)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous block partition of `total` instances; the first total%world ranks get one extra."""
+    q, r = divmod(total, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    import torch
+    if not is_distributed():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    _dist().all_reduce(t, op=_dist().ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_rows(local: np.ndarray, device=None) -> np.ndarray:
+    """Concatenate per-rank result rows (e.g. uopt [b, H, m]) in rank order on every rank (reporting only)."""
+    import torch
+    if not is_distributed():
+        return np.asarray(local)
+    d = _dist()
+    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(d.get_world_size())]
+    d.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=device))
+    mx = int(max(int(c.item()) for c in counts))
+    pad = np.zeros((mx,) + local.shape[1:], dtype=local.dtype)
+    pad[:local.shape[0]] = local
+    outs = [torch.zeros(pad.shape, dtype=torch.from_numpy(pad).dtype, device=device) for _ in range(d.get_world_size())]
+    d.all_gather(outs, torch.from_numpy(pad).to(device) if device is not None else torch.from_numpy(pad))
+    return np.concatenate([o.cpu().numpy()[:int(c.item())] for o, c in zip(outs, counts)], axis=0)

@@ -1,0 +1,155 @@
+"""Drop-in for `sde4mbrlExamples.rotor_uav.sde_mpc_design` (import site sde_control.py:12).
+
+`load_mpc_from_cfgfile(mpc_dir, convert_to_enu=True)` returns
+    cfg_dict, (m_reset, m_mpc), state_from_traj, None
+with the call signatures the reference node uses:
+    m_reset(x=, rng=, xdes=) -> opt_state                                     sde_control.py:702,706,345-346,389-394
+    m_mpc(x, rng, opt_state, curr_t=, xdes=) -> (uopt, opt_state, rng, xevol)  sde_control.py:713,717,349-350,400-416
+    state_from_traj(t) -> f32[13]  (None for position-control YAMLs)           sde_control.py:164,177,206,694
+    cfg_dict['_time_steps'][0] = dt                                            sde_control.py:167,174
+Returned arrays are numpy arrays wrapped so that `.block_until_ready()` exists (sde_control.py:420,707,718).
+opt_state exposes yk and the seven telemetry scalars read at sde_control.py:444-450,646-647.
+
+The solve itself runs in the HIP kernels behind include/sdempc.h; this module is host glue only.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from typing import Callable, NamedTuple, Optional
+
+import numpy as np
+
+from . import workload
+from .config import MPCConfig, load_mpc_config
+from .model import RotorSDEModel, synthetic_hexa, synthetic_iris
+from .utils import TrajectoryCSV
+
+
+class DeviceArray(np.ndarray):
+    """numpy array with the one JAX-array method the reference calls."""
+
+    def block_until_ready(self):
+        return self
+
+
+def _arr(a) -> DeviceArray:
+    return np.ascontiguousarray(a, dtype=np.float32).view(DeviceArray)
+
+
+class OptState(NamedTuple):
+    """Optimiser state threaded through successive m_mpc calls (sde_control.py:345,400-416,444-450)."""
+    yk: DeviceArray                # [H, m] warm start for the next solve
+    avg_linesearch: np.float32
+    stepsize: np.float32
+    num_steps: np.float32
+    grad_sqr: np.float32
+    avg_stepsize: np.float32
+    init_cost: np.float32
+    opt_cost: np.float32
+    num_ls_trials: np.float32 = np.float32(0.0)
+
+
+def _key_to_seed(rng) -> int:
+    k = np.asarray(rng).astype(np.uint64).reshape(-1)
+    return int((int(k[0]) << 32 | int(k[-1])) & 0x7FFFFFFFFFFFFFFF)
+
+
+def _next_key(rng):
+    """Advance a (2,) uint32 key. NOT JAX's threefry split: the noise stream of
+    this build is numpy PCG64 seeded from the key, so identical seeds give identical results between
+    this build's GPU path and its oracle, not with the original JAX path."""
+    g = np.random.default_rng(_key_to_seed(rng))
+    return g.integers(0, 2 ** 32, size=2, dtype=np.uint32), g
+
+
+@dataclass
+class MpcProblem:
+    """One loaded MPC YAML: config, model, solver handle (created lazily) and reference source."""
+    cfg: MPCConfig
+    model: RotorSDEModel
+    state_from_traj: Optional[Callable] = None
+    shift_warm_start: bool = True
+    _solver: object = field(default=None, repr=False)
+    _pid: int = field(default=-1, repr=False)
+
+    def solver(self):
+        # HIP contexts do not survive fork(): the reference builds its solvers in the parent and uses
+        # them in the forked mpc_process (sde_control.py:69-75,723-728); (re)create per process.
+        if self._solver is None or self._pid != os.getpid():
+            from .solver import SdeMpcSolver
+            self._solver = SdeMpcSolver(self.cfg, self.model, max_batch=1)
+            self._pid = os.getpid()
+        return self._solver
+
+    def xref(self, curr_t: float, xdes) -> np.ndarray:
+        if self.state_from_traj is not None:
+            return workload.reference_window(float(curr_t), self.cfg.time_steps, self.state_from_traj)
+        return workload.constant_reference(np.asarray(xdes, np.float32), self.cfg.horizon)
+
+    # ---- the two callables ------------------------------------------------------------------------
+    def m_reset(self, x=None, rng=None, xdes=None) -> OptState:
+        H, m = self.cfg.horizon, self.cfg.num_motors
+        yk = np.tile(np.asarray(self.cfg.uref, np.float32), (H, 1))
+        s0 = self.cfg.ls_init_stepsize if self.cfg.ls_maxls > 0 else self.cfg.stepsize
+        z = np.float32(0.0)
+        return OptState(_arr(yk), z, np.float32(s0), z, z, z, z, z, z)
+
+    def m_mpc(self, x, rng, opt_state: OptState, curr_t=0.0, xdes=None):
+        H, P = self.cfg.horizon, self.cfg.num_particles
+        x = np.asarray(x, np.float32).reshape(13)
+        xdes = x if xdes is None else np.asarray(xdes, np.float32).reshape(13)
+        new_rng, gen = _next_key(rng)
+        noise = gen.standard_normal((1, P, H, 6), dtype=np.float32)
+        xref = self.xref(float(curr_t), xdes)[None]
+        u0 = np.asarray(opt_state.yk, np.float32)[None]
+        uopt, xevol, info = self.solver().solve(x[None], xref, noise, u0, np.array([opt_state.stepsize], np.float32))
+        uo = uopt[0]
+        yk = np.concatenate([uo[1:], uo[-1:]], axis=0) if self.shift_warm_start else uo
+        i = info[0]
+        st = OptState(_arr(yk), np.float32(i[0]), np.float32(i[1]), np.float32(i[2]), np.float32(i[3]), np.float32(i[4]),
+                      np.float32(i[5]), np.float32(i[6]), np.float32(i[7]))
+        return _arr(uo), st, new_rng, _arr(xevol[0])
+
+
+def _pick_model(cfg: MPCConfig, model) -> RotorSDEModel:
+    if model is not None:
+        return model
+    # learned_model_params names a pickle of the external sde4mbrl repo (iris_sitl_traj_mpc.yaml:3) whose
+    # format is not in the reference; this build ships synthetic vehicles.
+    return synthetic_iris() if cfg.num_motors == 4 else synthetic_hexa()
+
+
+def load_mpc_problem(mpc_dir: str, convert_to_enu: bool = True, model=None, horizon=None, num_particles=None,
+                     trajectory=None, overrides=None) -> MpcProblem:
+    cfg = load_mpc_config(mpc_dir)
+    over = dict(overrides or {})
+    if horizon is not None:
+        over.update(horizon=int(horizon), num_short_dt=int(horizon))
+    if num_particles is not None:
+        over.update(num_particles=int(num_particles))
+    if over:
+        cfg = cfg.replace(**over)
+    sft = None
+    if trajectory is not None:
+        sft = trajectory
+    elif cfg.trajectory_path:
+        path = os.path.expanduser(cfg.trajectory_path)
+        if os.path.exists(path):
+            sft = TrajectoryCSV(path, ned=not convert_to_enu)
+        else:
+            # the shipped YAMLs point at CSVs of the external repo; fall back to the analytic lemniscate
+            sft = workload.lemniscate_state
+    return MpcProblem(cfg=cfg, model=_pick_model(cfg, model), state_from_traj=sft)
+
+
+def load_mpc_from_cfgfile(mpc_dir: str, convert_to_enu: bool = True, **kw):
+    """Reference-shaped factory (sde_control.py:685)."""
+    prob = load_mpc_problem(mpc_dir, convert_to_enu=convert_to_enu, **kw)
+    cfg_dict = {"_time_steps": prob.cfg.time_steps, "horizon": prob.cfg.horizon, "num_particles": prob.cfg.num_particles,
+                "cost_params": {"uref": list(prob.cfg.uref)}, "_problem": prob}
+    sft = None
+    if prob.state_from_traj is not None:
+        def sft(t, _f=prob.state_from_traj):
+            return _arr(np.asarray(_f(np.float64(t)), np.float32).reshape(13))
+    return cfg_dict, (prob.m_reset, prob.m_mpc), sft, None

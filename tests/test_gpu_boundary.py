@@ -1,0 +1,70 @@
+"""GPU tests of the Python boundary: the reference-shaped callables and the ROS-free worker loop."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from cases import CDIR, bits_differ
+from sde4mbrl_px4_amd import jax_shim
+from sde4mbrl_px4_amd import workload as W
+from sde4mbrl_px4_amd.sde_mpc_design import _next_key, load_mpc_problem
+from sde4mbrl_px4_amd.worker import CONTROL_STATE, KEY2INDEX_INFO, MpcWorker, select_command
+
+pytestmark = pytest.mark.gpu
+SMALL = dict(max_iter=6, max_no_improvement_iter=6)
+
+
+def test_m_mpc_matches_oracle_on_identical_seed():
+    prob = load_mpc_problem(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"), overrides=SMALL)
+    prob.shift_warm_start = False
+    x = W.random_initial_states(1, 4)[0]
+    xdes = W.HOVER.copy()
+    rng = jax_shim.random.PRNGKey(10)                                    # launch seed (iris_sdectrl.launch:8)
+    st = prob.m_reset(x=x, rng=rng, xdes=xdes)
+    uopt, st2, rng2, xevol = prob.m_mpc(x, rng, st, curr_t=0.0, xdes=xdes)
+    uopt.block_until_ready()
+    assert uopt.shape == (20, 4) and xevol.shape == (21, 13) and uopt.dtype == np.float32
+    _, gen = _next_key(rng)
+    noise = gen.standard_normal((1, 32, 20, 6), dtype=np.float32)[0]
+    O = orc.Oracle(prob.cfg, prob.model)
+    uo, xe, info, _ = O.solve(x, W.constant_reference(xdes, 20), noise, np.asarray(st.yk), float(st.stepsize))
+    np.testing.assert_allclose(uopt, uo, rtol=1e-4, atol=1e-6)
+    assert bits_differ(uopt, uo) == 0 and bits_differ(xevol, xe) == 0
+    assert float(st2.num_steps) == info[2] and float(st2.opt_cost) == info[6] and float(st2.init_cost) == info[5]
+    assert not np.array_equal(rng, rng2)
+    # same key -> same solution (identical seeds), new key -> different noise
+    uopt_b, _, _, _ = prob.m_mpc(x, rng, st, curr_t=0.0, xdes=xdes)
+    assert bits_differ(uopt, uopt_b) == 0
+
+
+def test_worker_replays_mode_sequence():
+    traj = load_mpc_problem(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml"), horizon=12, num_particles=32, trajectory=W.lemniscate_state, overrides=SMALL)
+    pos = load_mpc_problem(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"), horizon=10, overrides=SMALL)
+    wk = MpcWorker(traj, pos, seed=10)
+    wk.warm_up()
+    cs = CONTROL_STATE
+    x = W.random_initial_states(1, 1)[0]
+    tgt = W.lemniscate_state(0.0)
+    t_us = 1_000_000.0
+    seq = [("none", 0.0), ("pos", 0.0), ("idle", 0.0), ("idle", 0.0), ("idle", 0.0), ("traj", 0.0), ("traj", 0.05)]
+    traj_states = []
+    for mode, dur in seq:
+        uopt, wopt, st = wk.step(x, cs[mode], dur, tgt, t_us)
+        H = 12 if mode == "traj" else 10
+        assert uopt.shape == (H, 4) and wopt.shape == (H, 4) and wopt.dtype == np.float64
+        np.testing.assert_allclose(wopt[:, 0], uopt.mean(axis=1), rtol=1e-6)
+        assert uopt.min() >= 1e-4 and uopt.max() <= 1.0
+        sh = wk.shared
+        np.testing.assert_array_equal(sh.u_opt[:H], uopt)
+        np.testing.assert_array_equal(sh.w_opt[:H], wopt)
+        assert sh.opt_info[KEY2INDEX_INFO["sample_time_posmpc"]] == np.float32(t_us)
+        assert sh.opt_info[KEY2INDEX_INFO["num_steps"]] == float(st.num_steps) > 0
+        assert sh.opt_info[KEY2INDEX_INFO["costT"]] <= sh.opt_info[KEY2INDEX_INFO["cost0"]]
+        traj_states.append(float(wk.opt_state_traj.opt_cost))
+        t_us += 50_000.0
+    # idle alternation (sde_control.py:406-408): entering idle resets the traj solver and sets the toggle, so the
+    # traj problem is solved on the 2nd idle tick, skipped on the 3rd
+    assert traj_states[2] == 0.0 and traj_states[3] > 0.0 and traj_states[4] == traj_states[3]
+    sel = select_command(t_us + 60_000.0, t_us, wk.dt_usec_traj, wk.shared.u_opt, wk.shared.w_opt, 12)
+    assert sel[0] == 1 and sel[1].shape == (6,)

@@ -52,14 +52,17 @@ def test_worker_replays_mode_sequence():
     for mode, dur in seq:
         uopt, wopt, st = wk.step(x, cs[mode], dur, tgt, t_us)
         H = 12 if mode == "traj" else 10
-        assert uopt.shape == (H, 4) and wopt.shape == (H, 4) and wopt.dtype == np.float64
+        assert uopt.shape == (H, 4) and wopt.shape == (H, 4)
         np.testing.assert_allclose(wopt[:, 0], uopt.mean(axis=1), rtol=1e-6)
         assert uopt.min() >= 1e-4 and uopt.max() <= 1.0
         sh = wk.shared
         np.testing.assert_array_equal(sh.u_opt[:H], uopt)
-        np.testing.assert_array_equal(sh.w_opt[:H], wopt)
+        np.testing.assert_array_equal(sh.w_opt[:H], wopt.astype(np.float64))      # f32 values stored in the f64 block (:633-635)
+        assert sh.w_opt.dtype == np.float64
         assert sh.opt_info[KEY2INDEX_INFO["sample_time_posmpc"]] == np.float32(t_us)
-        assert sh.opt_info[KEY2INDEX_INFO["num_steps"]] == float(st.num_steps) > 0
+        assert sh.opt_info[KEY2INDEX_INFO["num_steps"]] == float(st.num_steps)
+        if mode != "idle":                       # in idle the logged state is the traj solver's (:435), solved every other tick
+            assert float(st.num_steps) > 0
         assert sh.opt_info[KEY2INDEX_INFO["costT"]] <= sh.opt_info[KEY2INDEX_INFO["cost0"]]
         traj_states.append(float(wk.opt_state_traj.opt_cost))
         t_us += 50_000.0

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 output directory (gpurun_out/<run>) into the committed summaries under profiles/.
+
+usage: tools/summarize_profile.py gpurun_out/r01b r01 [--batch 2048 --config c2_iris_traj_h50_p128.yaml]
+Writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json, updates profiles/pmc_traffic.json.
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: separate --pmc passes; FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request -> doubled (checked on this
+access pattern with the rollout kernel, whose only traffic is the known noise tensor: cal_* passes)."""
+import argparse, collections, csv, glob, json, os, shutil, sys
+
+ap = argparse.ArgumentParser()
+ap.add_argument("src"); ap.add_argument("tag")
+ap.add_argument("--batch", type=int, default=2048)
+ap.add_argument("--config", default="c2_iris_traj_h50_p128.yaml")
+a = ap.parse_args()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(ROOT, "profiles")
+os.makedirs(out, exist_ok=True)
+
+def counters(pattern, kname):
+    acc = collections.defaultdict(float); calls = collections.defaultdict(int)
+    for f in glob.glob(os.path.join(a.src, pattern, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if kname in r["Kernel_Name"]:
+                acc[r["Counter_Name"]] += float(r["Counter_Value"]); calls[r["Counter_Name"]] += 1
+    return {k: v / calls[k] for k, v in acc.items()}          # per launch
+
+ks = glob.glob(os.path.join(a.src, "trace", "*", "*kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(out, f"{a.tag}_kernel_stats.csv"))
+log = os.path.join(a.src, "bench_trace.log")
+bench = None
+if os.path.exists(log):
+    for line in open(log):
+        if line.startswith("{"):
+            bench = json.loads(line)
+solve = counters("pmc_*", "solve")
+cal_r = counters("cal_rollout_*", "rollout"); cal_g = counters("cal_grad_*", "grad")
+res = {"tag": a.tag, "batch": a.batch, "config": a.config, "solve_kernel_per_launch": solve, "bench_under_rocprof": bench}
+KiB = 1024.0
+if "FETCH_SIZE" in solve and "WRITE_SIZE" in solve:
+    rd, wr = 2.0 * solve["FETCH_SIZE"] * KiB, solve["WRITE_SIZE"] * KiB
+    res["hbm_bytes_per_launch"] = {"read_corrected": rd, "write": wr, "total": rd + wr, "per_solve": (rd + wr) / a.batch}
+    tf = os.path.join(out, "pmc_traffic.json")
+    rec = json.load(open(tf)) if os.path.exists(tf) else {}
+    rec[f"{a.config}:B{a.batch}"] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "source": f"profiles/{a.tag}_pmc.json"}
+    json.dump(rec, open(tf, "w"), indent=1)
+if cal_r:
+    res["calibration"] = {"rollout_kernel_FETCH_SIZE_KiB": cal_r.get("FETCH_SIZE"), "rollout_kernel_WRITE_SIZE_KiB": cal_r.get("WRITE_SIZE"),
+                          "grad_kernel_FETCH_SIZE_KiB": cal_g.get("FETCH_SIZE"), "grad_kernel_WRITE_SIZE_KiB": cal_g.get("WRITE_SIZE"),
+                          "known_rollout_read_bytes": a.batch * 4 * 50 * 6 * 32 * 4, "known_grad_write_bytes": a.batch * 4 * 51 * 13 * 32 * 4}
+if "GRBM_GUI_ACTIVE" in solve and "SQ_INSTS_VALU" in solve:
+    cyc = solve["GRBM_GUI_ACTIVE"] / 8.0
+    res["derived"] = {"kernel_cycles": cyc, "valu_insts_per_simd": solve["SQ_INSTS_VALU"] / 1024, "mfma_busy_frac": solve.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / cyc,
+                      "valu_issue_frac_at_2.8cyc": solve["SQ_INSTS_VALU"] / 1024 * 2.8 / cyc}
+json.dump(res, open(os.path.join(out, f"{a.tag}_pmc.json"), "w"), indent=1)
+print(json.dumps({k: res[k] for k in res if k in ("hbm_bytes_per_launch", "derived", "calibration")}, indent=1))

@@ -40,6 +40,7 @@ struct KArgs {
     const float* noise;        // [B][G][H][6][32]
     const float* stepsize_in;  // [B] (solve)
     float* traj;               // [B][G][H+1][13][32] workspace
+    float* act;                // [B][G][H][ACT_STRIDE] activation checkpoint of the gradient's forward sweep
     float* cost;               // [B]
     float* grad;               // [B][H][m]
     float* xmean;              // [B][H+1][13] or null
@@ -48,6 +49,7 @@ struct KArgs {
     int store_traj;
 };
 
+constexpr int ACT_STRIDE = 1280;  // floats per (instance, group, step): h2 tile 4 chunks x 64 lanes x 4 + step scalars 32 x 8
 size_t smem_bytes(int H, int m);
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st);

@@ -199,14 +199,14 @@ DI float dpp_f(float v) {
 // they alias (tools/lane_probe.hip), so the second operand is forced into its own VGPR.
 DI float xor32_sum(float v) {
     unsigned a = __builtin_bit_cast(unsigned, v), b;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(b) : "v"(a));            // (a tied "+v" copy gets folded away by LLVM)
+    asm("v_mov_b32 %0, %1" : "=v"(b) : "v"(a));   // opaque copy (a tied "+v" copy gets folded away by LLVM); not volatile: may be DCEd
     auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);   // r[0] = {lo,lo}, r[1] = {hi,hi}
     const unsigned r0 = r[0], r1 = r[1];   // (bit_cast straight from r[1] reads element 0: keep the temporaries)
     return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
 }
 DI float xor16_sum(float v) {
     unsigned a = __builtin_bit_cast(unsigned, v), b;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(b) : "v"(a));
+    asm("v_mov_b32 %0, %1" : "=v"(b) : "v"(a));
     auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);   // r[0] = {r0,r0,r2,r2}, r[1] = {r1,r1,r3,r3}
     const unsigned r0 = r[0], r1 = r[1];
     return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
@@ -438,6 +438,16 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     A.rn = rsqrt_spec(n2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { A.qn[i] = qt[i] * A.rn; xn[6 + i] = A.qn[i]; }
+}
+
+// rotation matrix of q (same expressions as in step_fwd)
+DI void rot_from_q(const float* x, float* Rm) {
+    const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const float xx = qx * qx, yy = qy * qy, zz = qz * qz;
+    const float xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
+    Rm[0] = FMA(-2.0f, yy + zz, 1.0f); Rm[1] = 2.0f * (xy - wz);          Rm[2] = 2.0f * (xz + wy);
+    Rm[3] = 2.0f * (xy + wz);          Rm[4] = FMA(-2.0f, xx + zz, 1.0f); Rm[5] = 2.0f * (yz - wx);
+    Rm[6] = 2.0f * (xz - wy);          Rm[7] = 2.0f * (yz + wx);          Rm[8] = FMA(-2.0f, xx + yy, 1.0f);
 }
 
 // SPEC.md §5.3 stage cost at x_{t+1}; GX: also the gradient
@@ -727,9 +737,11 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         const bool valid = (g * 32 + j) < P;
         const float* nz = a.noise + ((size_t)(b * G + g) * H) * NN * 32 + j;
         float* tj = a.traj + ((size_t)(b * G + g) * (H + 1)) * NX * 32 + j;
+        float* ac = a.act + ((size_t)(b * G + g) * H) * ACT_STRIDE;
+        const bool first_group = (g == wave);
         float x[NX], xn[NX], xi[NN];
         StepAux A;
-        // ---- forward sweep, x_t streamed to HBM ----
+        // ---- forward sweep, x_t and the hidden activations streamed to HBM ----
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = x0r[i];
 #pragma unroll
@@ -744,6 +756,17 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
                 for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
             }
             step_fwd(a, sm, ww, t, h, lane, x, xi, xn, A);
+            {   // activation checkpoint: second hidden layer (4 x 16-byte stores per lane) + step scalars once per particle;
+                // the adjoint sweep recomputes only layer 1 from x_t (balance between HBM traffic and vector work)
+                float* ap = ac + (size_t)t * ACT_STRIDE;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(ap + (q * 64 + lane) * 4) = make_float4(A.h2[4 * q], A.h2[4 * q + 1], A.h2[4 * q + 2], A.h2[4 * q + 3]);
+                if (h == 0) {
+                    *reinterpret_cast<float4*>(ap + 1024 + j * 8) = make_float4(A.eta, A.Fb[0], A.Fb[1], A.Fb[2]);
+                    ap[1024 + j * 8 + 4] = A.rn;
+                }
+            }
             float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
             l = FMA(a.C.res_mult * A.eta, A.eta, l);
             J = FMA(sm.disc[t], l, J);
@@ -762,16 +785,35 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         float lam[NX], xt[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) lam[i] = 0.0f;
-        // this wave's own stores of x_t must be visible to its loads (same CU: workgroup scope)
+        // this wave's own stores of x_t / activations must be visible to its loads (same CU: workgroup scope)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // software pipeline: the loads of step t-1 are issued while step t is being processed
+        float4 nh[4], ns4;
+        float nrn, nxt[NX], nxi[NN];
+        auto issue_loads = [&](int t) {
+            const float* ap = ac + (size_t)t * ACT_STRIDE;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nh[q] = *reinterpret_cast<const float4*>(ap + (q * 64 + lane) * 4);
+            ns4 = *reinterpret_cast<const float4*>(ap + 1024 + j * 8);
+            nrn = ap[1024 + j * 8 + 4];
+            const float* tp = tj + (size_t)t * NX * 32;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) nxt[i] = tp[i * 32];
+#pragma unroll
+            for (int i = 0; i < NN; ++i) nxi[i] = nz[(t * NN + i) * 32];
+        };
+        issue_loads(H - 1);
         for (int t = H - 1; t >= 0; --t) {
-            {
-                const float* tp = tj + (size_t)t * NX * 32;
+            // take ownership of the prefetched step
+            f32x16 h2l;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) xt[i] = tp[i * 32];
+            for (int q = 0; q < 4; ++q) { h2l[4 * q] = nh[q].x; h2l[4 * q + 1] = nh[q].y; h2l[4 * q + 2] = nh[q].z; h2l[4 * q + 3] = nh[q].w; }
+            const float eta_l = ns4.x, fb0 = ns4.y, fb1 = ns4.z, fb2 = ns4.w, rn_l = nrn;
 #pragma unroll
-                for (int i = 0; i < NN; ++i) xi[i] = nz[(t * NN + i) * 32];
-            }
+            for (int i = 0; i < NX; ++i) xt[i] = nxt[i];
+#pragma unroll
+            for (int i = 0; i < NN; ++i) xi[i] = nxi[i];
+            if (t > 0) issue_loads(t - 1);
             // x = x_{t+1}: fold the stage-cost gradient into the incoming adjoint
             const float dsc = sm.disc[t];
             {
@@ -782,15 +824,32 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
             }
             SCHED_PHASE();
             float lamn[NX], gq[12];
+            // recompute layer 1 only (R, v_body, 6 MFMAs, 32 tanh); everything downstream of it comes from the checkpoint
+            // (the unused remainder of step_fwd is dead code and is removed by the compiler)
             step_fwd(a, sm, ww, t, h, lane, xt, xi, xn, A);
+            A.h2 = h2l; A.eta = eta_l; A.Fb[0] = fb0; A.Fb[1] = fb1; A.Fb[2] = fb2; A.rn = rn_l;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) A.Jom[i] = a.M.J[i] * xt[10 + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A.qn[i] = x[6 + i];   // q_{t+1}
             float ebc = dsc * ((2.0f * a.C.res_mult) * A.eta);
             step_vjp<M>(a, sm, ww, t, h, lane, xt, xi, A, lam, ebc, lamn, gq);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { lam[i] = lamn[i]; x[i] = xt[i]; }
+            // particle sums of the nq per-step adjoint outputs: both lane halves hold the same values, so the lower
+            // half reduces value k and the upper half value k + nq/2 in one butterfly (halves never mix below xor 32)
+            {
+                constexpr int half = (nq + 1) / 2;
 #pragma unroll
-            for (int k = 0; k < nq; ++k) {
-                float s = group_bfly32(valid ? gq[k] : 0.0f);
-                if (lane == 0) Sq[t * 12 + k] = Sq[t * 12 + k] + s;
+                for (int k = 0; k < half; ++k) {
+                    const float lo = gq[k], hi = (k + half < nq) ? gq[k + half] : 0.0f;
+                    float s = group_bfly32(valid ? (h ? hi : lo) : 0.0f);
+                    if (j == 0 && (h == 0 || k + half < nq)) {
+                        const int idx = t * 12 + k + h * half;
+                        // first group of this wave: the slot still holds 0 -> "0 + s" without the LDS read
+                        Sq[idx] = (first_group ? 0.0f : Sq[idx]) + s;
+                    }
+                }
             }
         }
     }

@@ -37,6 +37,14 @@ def algorithmic_counts(cfg, n_it, n_ls):
     return bytes_solve, flops_solve, b_grad, b_ls
 
 
+def checkpoint_bytes(cfg, n_it):
+    """Implementation stream on top of the algorithmic bytes: the gradient's forward sweep checkpoints the
+    layer-2 activations + 5 step scalars per particle-step (1280 floats per 32-particle group and step),
+    written once and read once per gradient evaluation."""
+    G = (cfg.num_particles + 31) // 32
+    return int(n_it * 2 * G * cfg.horizon * 1280 * 4)
+
+
 def cpu_baseline(cfg, model, n_threads, x0, xref, noise, u0, s0):
     """Oracle (CPU restatement, kind 'port') on the host cores: one solve per thread, wall clock."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -184,7 +192,9 @@ def main():
                          "note": "f32-exact path: MLP contractions on v_mfma_f32_32x32x2_f32 (157.3 TF dense peak = f32 vector peak); "
                                  "algorithmic flops = SURVEY §8d MLP formula x P*H*(2*N_it+N_ls+2)"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
-                             "traffic": traffic, "bytes_per_solve": bytes_solve, "B_grad": b_grad, "B_ls": b_ls},
+                             "traffic": traffic, "bytes_per_solve": bytes_solve, "B_grad": b_grad, "B_ls": b_ls,
+                             "checkpoint_bytes_per_solve": checkpoint_bytes(cfg, n_it),
+                             "note": "achieved = SURVEY 8d algorithmic bytes / kernel time; measured traffic additionally contains the activation-checkpoint stream"},
         }
         if not args.no_cpu_baseline and world == 1:
             nthr = args.cpu_threads or min(os.cpu_count() or 1, 64)

@@ -73,6 +73,9 @@ EDGE = {
     "moment_scale": dict(horizon=10, num_short_dt=10, num_particles=32, moment_scale=0.5),
     "no_linesearch": dict(horizon=10, num_short_dt=10, num_particles=32, ls_maxls=0, stepsize=1e-4),
     "unbounded_u": dict(horizon=10, num_short_dt=10, num_particles=32, enforce_ubound=False),
+    "max_iter_0": dict(horizon=8, num_short_dt=8, num_particles=32, max_iter=0),
+    "max_no_improvement_1": dict(horizon=8, num_short_dt=8, num_particles=32, max_iter=12, max_no_improvement_iter=1),
+    "loose_tolerance_early_stop": dict(horizon=8, num_short_dt=8, num_particles=32, max_iter=40, max_no_improvement_iter=40, rtol=5e-2),
 }
 
 
@@ -98,6 +101,44 @@ def test_edge_cases_bit_exact(name):
         _close(grad[b], g2, "grad")
         assert gc[b] == np.float32(c2) and bits_differ(grad[b], g2.astype(np.float32)) == 0
         uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u0[b], float(s0[b]))
+        _close(uopt[b], uo, "uopt")
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], inf) == 0
+    S.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_configurations_bit_exact(seed):
+    """Randomised hyper-parameters (horizon, particles, motors, cost weights, time grid, optimiser knobs)."""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.choice([4, 6]))
+    H = int(rng.integers(2, 40))
+    kw = dict(horizon=H, num_short_dt=int(rng.integers(0, H + 1)), short_step_dt=float(rng.choice([0.02, 0.05])), long_step_dt=float(rng.choice([0.05, 0.1])),
+              num_particles=int(rng.integers(1, 200)), discount=float(rng.choice([1.0, 0.98, 0.9])),
+              uerr=float(rng.uniform(0, 2)), perr=list(rng.uniform(1, 200, 3)), verr=list(rng.uniform(0, 10, 3)), qerr=list(rng.uniform(0, 100, 3)),
+              werr=list(rng.uniform(0, 3, 3)), res_mult=float(rng.uniform(0, 0.1)), u_slew_coeff=float(rng.uniform(0, 2)),
+              max_iter=int(rng.integers(1, 9)), max_no_improvement_iter=int(rng.integers(1, 9)), beta_init=float(rng.uniform(0, 0.5)),
+              ls_init_stepsize=float(rng.choice([0.01, 0.001])), ls_max_stepsize=float(rng.choice([1.0, 10.0, 0.005])), ls_coef=float(rng.choice([0.01, 0.1])),
+              ls_decrease_factor=float(rng.uniform(0.3, 0.9)), ls_increase_factor=float(rng.uniform(1.0, 2.0)), ls_maxls=int(rng.integers(1, 6)),
+              ls_reset_option=str(rng.choice(["increase", "conservative"])))
+    if m == 6:
+        kw.update(input_id=list(range(6)), input_bound=[[1e-4, 1.0]] * 6, uref=[0.42] * 6)
+    if rng.random() < 0.5:
+        kw.update(u_slew_constr=[[-0.05, 0.05]] * m, u_slew_constr_coeff=float(rng.uniform(1, 20)))
+    cfg = MPCConfig(**kw)
+    model = synthetic_iris(seed) if m == 4 else synthetic_hexa(seed)
+    B = 2
+    x0, xref, noise, u = _problem(cfg, B, seed=300 + seed, pos=bool(seed % 2))
+    S, O = _solver(cfg, model, B), orc.Oracle(cfg, model)
+    cost, traj, xmean = S.rollout(x0, u, xref, noise, True, True)
+    gc, grad = S.grad(x0, u, xref, noise)
+    u0 = np.tile(np.asarray(cfg.uref, np.float32), (B, cfg.horizon, 1))
+    uopt, xevol, info = S.solve(x0, xref, noise, u0, np.full(B, cfg.ls_init_stepsize, np.float32))
+    for b in range(B):
+        c, t, xm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True)
+        assert cost[b] == np.float32(c) and bits_differ(traj[b], t) == 0 and bits_differ(xmean[b], xm) == 0
+        c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
+        assert gc[b] == np.float32(c2) and bits_differ(grad[b], g2.astype(np.float32)) == 0
+        uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u0[b], cfg.ls_init_stepsize)
         _close(uopt[b], uo, "uopt")
         assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], inf) == 0
     S.close()

@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--latency-reps", type=int, default=10)
+    ap.add_argument("--mlp-dtype", default="f32", choices=["f32", "f16"],
+                    help="f32: bit-reproducible path (default, the reported metric); f16: fp16-operand MLP contractions (SPEC.md 9)")
     args = ap.parse_args()
 
     import torch
@@ -94,7 +96,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cfg = load_mpc_config(args.config)
+    cfg = load_mpc_config(args.config).replace(mlp_dtype=args.mlp_dtype)
     H, P, m, B = cfg.horizon, cfg.num_particles, cfg.num_motors, args.batch
     # shared model: rank 0 builds it, RCCL broadcast over xGMI (read-only weights are the only shared data)
     from sde4mbrl_px4_amd.dist import broadcast_blob, max_over_ranks
@@ -181,7 +183,7 @@ def main():
             "metric": "MPC solves/sec, Iris H=50 P=128 (p50 solve latency in p50_solve_latency_ms)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.mlp_dtype == "f32" else "f16 MLP operands / f32 accumulate and state", "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.config)}: H={H} P={P} m={m}, {B} independent MPC instances per GPU per step, "
                                    f"cold-start solves from the hover guess, max_iter={cfg.max_iter} maxls={cfg.ls_maxls}",
                        "instances_per_gpu": B, "N_it_mean": n_it, "N_ls_mean": n_ls, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},

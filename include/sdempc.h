@@ -84,6 +84,10 @@ typedef struct sdempc_cfg {
     float ls_init_stepsize, ls_max_stepsize, ls_coef, ls_decrease_factor, ls_increase_factor;
     int32_t ls_reset_option;          /* 0 conservative, 1 increase */
     int32_t ls_maxls;
+    /* extension (not a reference YAML key): arithmetic of the MLP contractions in the forward rollout.
+     * 0 = f32 (v_mfma_f32_32x32x2_f32, bit-reproducible; default), 1 = fp16 operands rounded toward zero,
+     * f32 accumulate (v_mfma_f32_32x32x16_f16; BASELINE config C5). SPEC.md §9. */
+    int32_t mlp_dtype;
 } sdempc_cfg;
 
 /* Optimiser telemetry: the 7 scalars the reference reads from opt_state

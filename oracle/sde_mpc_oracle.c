@@ -118,13 +118,16 @@ double NAME(sigmoid)(double x) { return 1.0 / (1.0 + exp(-x)); }
 /* ------------------------------------------------------------------------------------------- */
 typedef struct {
     int m;
+    int f16;   /* SPEC.md §9: fp16-operand MLP contractions */
     real inv_mass, grav, J[3], iJ[3], ct2, ct1, ct0, cm2, cm1;
     real rx[MAXM], ry[MAXM], dir[MAXM];
     real sF[3], sT[3], sigma[NN];
     real W1z[2 * HID][NN], b1[2 * HID], W1u[HID][MAXM], W2[HID][HID], b2[HID], W3[6][HID], b3[6], w3n[HID], b3n;
 } model_t;
 
-static int parse_blob(const void* blob, model_t* M) {
+static real f16_rtz(real xv);
+
+static int parse_blob(const void* blob, model_t* M, int f16) {
     const int32_t* hd = (const int32_t*)blob;
     if (hd[0] != SDEMPC_BLOB_MAGIC || hd[1] != 1) return -1;
     M->m = hd[2];
@@ -157,7 +160,31 @@ static int parse_blob(const void* blob, model_t* M) {
     for (int k = 0; k < HID; ++k) M->w3n[k] = f[k];
     f += HID;
     M->b3n = f[0];
+    M->f16 = f16;
+    if (f16) { /* layer-1 (state inputs) and layer-2 weights live in fp16, forward and adjoint alike */
+        for (int r = 0; r < 2 * HID; ++r) for (int k = 0; k < NN; ++k) M->W1z[r][k] = f16_rtz(M->W1z[r][k]);
+        for (int r = 0; r < HID; ++r) for (int k = 0; k < HID; ++k) M->W2[r][k] = f16_rtz(M->W2[r][k]);
+    }
     return 0;
+}
+
+/* SPEC.md §9: round toward zero to the nearest IEEE binary16 value (result returned as real).
+ * Finite overflow saturates at 65504, subnormals keep the 2^-24 grid. */
+static real f16_rtz(real xv) {
+    float x = (float)xv;
+    uint32_t u; memcpy(&u, &x, 4);
+    uint32_t sign = u & 0x80000000u, mag = u & 0x7FFFFFFFu;
+    if (mag >= 0x7F800000u) return xv;                      /* inf / nan: unchanged */
+    int e = (int)(mag >> 23) - 127;
+    float r;
+    if (e > 15) { r = 65504.0f; }
+    else if (e >= -14) { uint32_t t = mag & ~((1u << 13) - 1u); memcpy(&r, &t, 4); }
+    else { /* subnormal half: multiples of 2^-24 */
+        float a; memcpy(&a, &mag, 4);
+        r = (float)floor((double)a * 16777216.0) / 16777216.0f;
+    }
+    uint32_t ru; memcpy(&ru, &r, 4); ru |= sign; memcpy(&r, &ru, 4);
+    return (real)r;
 }
 
 /* hidden-unit visiting order of SPEC.md §4: k(r,h) = (r&3) + 8*(r>>2) + 4*h, r = 0..15, h = 0..1 */
@@ -213,6 +240,7 @@ static void step_fwd(const model_t* M, const ustep_t* U, const real* x, const re
     /* body-frame velocity vb = R^T v */
     for (int j = 0; j < 3; ++j) A->vb[j] = FMA(Rm[6 + j], v[2], FMA(Rm[3 + j], v[1], Rm[j] * v[0]));
     real z[NN] = {A->vb[0], A->vb[1], A->vb[2], om[0], om[1], om[2]};
+    if (M->f16) for (int k = 0; k < NN; ++k) z[k] = f16_rtz(z[k]);   /* activations enter the contraction in fp16 */
     /* layer 1: drift rows 0..31 start from U->c, density rows 32..63 from b1 */
     real pre_d[HID], pre_n[HID], pre_2[HID];
     for (int r = 0; r < HID; ++r) {
@@ -224,7 +252,7 @@ static void step_fwd(const model_t* M, const ustep_t* U, const real* x, const re
     /* layer 2 (drift): k visited in rowmap order */
     for (int i = 0; i < HID; ++i) {
         real a = M->b2[i];
-        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int k = rowmap(r, h); a = FMA(M->W2[i][k], A->h1d[k], a); }
+        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int k = rowmap(r, h); a = FMA(M->W2[i][k], M->f16 ? f16_rtz(A->h1d[k]) : A->h1d[k], a); }
         pre_2[i] = a;
     }
     for (int r = 0; r < HID; r += 4) NAME(tanh4)(pre_2 + r, A->h2 + r);
@@ -459,7 +487,7 @@ typedef struct {
 
 static int ctx_init(ctx_t* X, const sdempc_cfg* C, const void* blob) {
     if (!C || C->struct_size != (int32_t)sizeof(sdempc_cfg)) return SDEMPC_EINVAL;
-    if (parse_blob(blob, &X->M)) return SDEMPC_EBLOB;
+    if (parse_blob(blob, &X->M, C->mlp_dtype == 1)) return SDEMPC_EBLOB;
     X->C = C; X->H = C->horizon; X->P = C->num_particles; X->m = C->num_motors;
     if (X->H < 1 || X->P < 1 || X->m != X->M.m) return SDEMPC_EINVAL;
     X->dt = (real*)malloc(sizeof(real) * X->H);
@@ -780,6 +808,9 @@ int NAME(solve_batch)(const sdempc_cfg* C, const void* blob, int B, const float*
     }
     return 0;
 }
+
+/* fp16 round-toward-zero quantiser, exposed for unit tests */
+double NAME(f16_rtz_value)(double x) { return (double)f16_rtz((real)x); }
 
 /* single EM step and its VJP, exposed for unit tests */
 int NAME(step)(const sdempc_cfg* C, const void* blob, const float* x, const float* u, const float* xi, int t, float* xn, float* eta) {

@@ -42,6 +42,7 @@ class SdempcCfg(C.Structure):
         ("ls_decrease_factor", C.c_float), ("ls_increase_factor", C.c_float),
         ("ls_reset_option", C.c_int32),
         ("ls_maxls", C.c_int32),
+        ("mlp_dtype", C.c_int32),
     ]
 
 

@@ -67,6 +67,8 @@ class MPCConfig:
     ls_increase_factor: float = 1.3
     ls_reset_option: str = "increase"
     ls_maxls: int = 4
+    # extension key (not in the reference schema): "f32" (default, bit-reproducible) or "f16" (SPEC.md §9)
+    mlp_dtype: str = "f32"
 
     @property
     def num_motors(self) -> int:
@@ -125,6 +127,9 @@ class MPCConfig:
             raise ValueError(f"linesearch.reset_option must be increase|conservative, got {self.ls_reset_option!r}")
         c.ls_reset_option = 1 if self.ls_reset_option == "increase" else 0
         c.ls_maxls = int(self.ls_maxls)
+        if self.mlp_dtype not in ("f32", "f16"):
+            raise ValueError(f"mlp_dtype must be f32|f16, got {self.mlp_dtype!r}")
+        c.mlp_dtype = 1 if self.mlp_dtype == "f16" else 0
         return c, ts
 
 
@@ -177,6 +182,7 @@ def mpc_config_from_dict(d: dict) -> MPCConfig:
         cfg.ls_maxls = int(ls.get("maxls", cfg.ls_maxls))
     else:
         cfg.ls_maxls = 0
+    cfg.mlp_dtype = str(d.get("mlp_dtype", "f32"))
     return cfg
 
 

@@ -8,6 +8,7 @@
 // runs on the host and there is no CPU fallback.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,6 +24,20 @@ using namespace sdempc;
 
 namespace {
 std::string g_create_error;
+
+// SPEC.md §9: round toward zero to the nearest IEEE binary16 value; overflow saturates at 65504.
+float f16_rtz_host(float x) {
+    uint32_t u; memcpy(&u, &x, 4);
+    const uint32_t sign = u & 0x80000000u, mag = u & 0x7FFFFFFFu;
+    if (mag >= 0x7F800000u) return x;
+    const int e = (int)(mag >> 23) - 127;
+    float r;
+    if (e > 15) r = 65504.0f;
+    else if (e >= -14) { uint32_t t = mag & ~0x1FFFu; memcpy(&r, &t, 4); }
+    else { float a; memcpy(&a, &mag, 4); r = floorf(a * 16777216.0f) / 16777216.0f; }
+    uint32_t ru; memcpy(&ru, &r, 4); ru |= sign; memcpy(&r, &ru, 4);
+    return r;
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -208,6 +223,11 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     h->cfg.time_steps = h->time_steps.data();
     const float* f = (const float*)(hd + SDEMPC_BLOB_HEADER_INTS);
     h->blob_f.assign(f, f + SDEMPC_BLOB_FLOATS);
+    if (cfg->mlp_dtype != 0 && cfg->mlp_dtype != 1) { delete h; return fail(nullptr, SDEMPC_EINVAL, "mlp_dtype must be 0 (f32) or 1 (f16)%s"); }
+    if (cfg->mlp_dtype == 1) {   // layer-1 state-input weights and layer-2 weights live in fp16 (forward and adjoint alike)
+        for (int i = 0; i < 64 * 6; ++i) h->blob_f[56 + i] = f16_rtz_host(h->blob_f[56 + i]);
+        for (int i = 0; i < 32 * 32; ++i) h->blob_f[760 + i] = f16_rtz_host(h->blob_f[760 + i]);
+    }
     // tables (SPEC.md §5: float32 host arithmetic)
     const float* sigma = f + 48;
     h->h_sdt.resize((size_t)h->H * SDEMPC_NNOISE);
@@ -229,6 +249,7 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     memset(&a, 0, sizeof a);
     a.H = h->H; a.P = h->P; a.m = m; a.G = h->G;
     a.invP = 1.0f / (float)h->P;
+    a.f16 = cfg->mlp_dtype == 1;
     a.M.inv_mass = f[0]; a.M.grav = f[1];
     for (int i = 0; i < 3; ++i) { a.M.J[i] = f[2 + i]; a.M.iJ[i] = f[5 + i]; }
     a.M.ct2 = f[8]; a.M.ct1 = f[9]; a.M.ct0 = f[10]; a.M.cm2 = f[11]; a.M.cm1 = f[12];

@@ -47,6 +47,7 @@ struct KArgs {
     float* uopt;               // [B][H][m]
     float* info;               // [B][8] raw: sum_ls, stepsize, nit, grad_sqr, sum_s, c_init, c_opt, nls_total
     int store_traj;
+    int f16;                   // SPEC.md §9: fp16-operand MLP contractions in the forward step
 };
 
 constexpr int ACT_STRIDE = 1280;  // floats per (instance, group, step): h2 tile 4 chunks x 64 lanes x 4 + step scalars 32 x 8

@@ -30,6 +30,7 @@
 namespace sdempc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 #define DI __device__ __forceinline__
 // phase fences for the instruction scheduler (SDEMPC_SB=0 lets hipcc interleave freely)
@@ -106,6 +107,7 @@ DI float sigmoid_spec(float x) {
 struct Smem {
     float *W3, *w3n, *b1n, *b2, *b1d, *W1zT, *W1uT;  // weights, row-major in hidden-unit index
     float *A2, *A2T;                                   // MFMA A operands of W2 / W2^T: [q][lane][4]
+    float *A2h;                                        // f16 mode: A operands of W2, [half][lane][8 x fp16]
     float *ust;                                        // [H][36]: c[32], Tz, tau[3]
     float *xref;                                       // [H+1][13]
     float *SX;                                         // max(4*H*12, 4*(H+1)*13): per-wave partials
@@ -127,6 +129,7 @@ DI Smem carve(float* base, int H, int m) {
     s.W1uT = p; p += 8 * HID;
     s.A2 = p; p += HID * HID;
     s.A2T = p; p += HID * HID;
+    s.A2h = p; p += 512;
     s.ust = p; p += H * UST;
     s.xref = p; p += ((H + 1) * NX + 3) & ~3;
     s.SX = p; p += 4 * (H + 1) * NX;
@@ -139,7 +142,7 @@ DI Smem carve(float* base, int H, int m) {
     return s;
 }
 size_t smem_bytes(int H, int m) {
-    size_t f = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + 2 * HID * HID + (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 4 * (H + 1) * NX +
+    size_t f = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + 2 * HID * HID + 512 + (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 4 * (H + 1) * NX +
                ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
     return f * sizeof(float);
 }
@@ -150,7 +153,8 @@ constexpr int OFF_W1Z = 56, OFF_B1 = OFF_W1Z + 384, OFF_W1U = OFF_B1 + 64, OFF_W
 
 // MFMA A operands kept in registers for the whole kernel
 struct WaveW {
-    float w1d[3], w1n[3];
+    float w1d[3], w1n[3];   // f32 mode: layer-1 A operands (3 k-steps per tile)
+    half8 h1d, h1n;         // f16 mode: layer-1 A operands (k slots 0..5 of lanes 0..31, rest zero)
 };
 
 DI int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
@@ -159,6 +163,7 @@ DI int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid) {
     const float* w = a.wts;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5;
     for (int i = tid; i < 6 * HID; i += NT) sm.W3[i] = w[OFF_W3 + i];
     for (int i = tid; i < HID; i += NT) {
         sm.w3n[i] = w[OFF_W3N + i];
@@ -171,7 +176,6 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid) {
     for (int i = tid; i < a.H; i += NT) sm.dt[i] = a.dt[i];
     for (int i = tid; i < a.H * NN; i += NT) sm.sdt[i] = a.sdt[i];
     for (int i = tid; i <= a.H; i += NT) sm.disc[i] = a.disc[i];
-    int lane = tid & 63, j = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int s = 0; s < 3; ++s) { ww.w1d[s] = w[OFF_W1Z + j * NN + 2 * s + h]; ww.w1n[s] = w[OFF_W1Z + (HID + j) * NN + 2 * s + h]; }
     // A operand of k-step r for lane l: W2[j][rowmap(r,h)] (forward) / W2[rowmap(r,h)][j] (transpose)
@@ -179,6 +183,18 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid) {
         int c = i & 3, l = (i >> 2) & 63, q = i >> 8, jj = l & 31, hh = l >> 5, r = 4 * q + c;
         sm.A2[i] = w[OFF_W2 + jj * HID + rowmap(r, hh)];
         sm.A2T[i] = w[OFF_W2 + rowmap(r, hh) * HID + jj];
+    }
+    if (a.f16) {   // weights are already fp16-representable (quantised on the host): the casts are exact
+        _Float16* ah = reinterpret_cast<_Float16*>(sm.A2h);
+        for (int i = tid; i < 2 * 64 * 8; i += NT) {
+            int e = i & 7, l = (i >> 3) & 63, hf = i >> 9, jj = l & 31, hh = l >> 5;
+            ah[i] = (_Float16)w[OFF_W2 + jj * HID + rowmap(8 * hf + e, hh)];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ww.h1d[e] = (e < NN && h == 0) ? (_Float16)w[OFF_W1Z + j * NN + e] : (_Float16)0.0f;
+            ww.h1n[e] = (e < NN && h == 0) ? (_Float16)w[OFF_W1Z + (HID + j) * NN + e] : (_Float16)0.0f;
+        }
     }
 }
 
@@ -308,6 +324,7 @@ struct StepAux {
 };
 
 
+template <bool F16>
 DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, float* xn, StepAux& A) {
     const float* ust = sm.ust + t * UST;
     const float dt = sm.dt[t];
@@ -333,11 +350,24 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
         accD[4 * q] = c4.x; accD[4 * q + 1] = c4.y; accD[4 * q + 2] = c4.z; accD[4 * q + 3] = c4.w;
         accN[4 * q] = n4.x; accN[4 * q + 1] = n4.y; accN[4 * q + 2] = n4.z; accN[4 * q + 3] = n4.w;
     }
+    if constexpr (F16) {
+        // fp16 operands (round toward zero), f32 accumulate: one v_mfma_f32_32x32x16_f16 per tile, k slots 0..5 live in lanes 0..31
+        half8 bv;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        float b = h ? z[2 * s + 1] : z[2 * s];
-        accD = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1d[s], b, accD, 0, 0, 0);
-        accN = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1n[s], b, accN, 0, 0, 0);
+        for (int e = 0; e < 3; ++e) {
+            auto pk = __builtin_amdgcn_cvt_pkrtz(h ? 0.0f : z[2 * e], h ? 0.0f : z[2 * e + 1]);
+            bv[2 * e] = (_Float16)pk[0]; bv[2 * e + 1] = (_Float16)pk[1];
+        }
+        bv[6] = (_Float16)0.0f; bv[7] = (_Float16)0.0f;
+        accD = __builtin_amdgcn_mfma_f32_32x32x16_f16(ww.h1d, bv, accD, 0, 0, 0);
+        accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(ww.h1n, bv, accN, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float b = h ? z[2 * s + 1] : z[2 * s];
+            accD = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1d[s], b, accD, 0, 0, 0);
+            accN = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1n[s], b, accN, 0, 0, 0);
+        }
     }
     SCHED_PHASE();
 
@@ -355,13 +385,28 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
         float4 b4 = *reinterpret_cast<const float4*>(sm.b2 + 8 * q + 4 * h);
         acc2[4 * q] = b4.x; acc2[4 * q + 1] = b4.y; acc2[4 * q + 2] = b4.z; acc2[4 * q + 3] = b4.w;
     }
+    if constexpr (F16) {
+        // two K=16 MFMAs: k slot e of lane half h <-> accumulator register 8*hf + e, i.e. hidden unit rowmap(8*hf + e, h)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float4 w4 = *reinterpret_cast<const float4*>(sm.A2 + (q * 64 + lane) * 4);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, accD[4 * q], acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, accD[4 * q + 1], acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, accD[4 * q + 2], acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, accD[4 * q + 3], acc2, 0, 0, 0);
+        for (int hf = 0; hf < 2; ++hf) {
+            half8 av = *reinterpret_cast<const half8*>(sm.A2h + (hf * 64 + lane) * 4);
+            half8 bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                auto pk = __builtin_amdgcn_cvt_pkrtz(accD[8 * hf + 2 * e], accD[8 * hf + 2 * e + 1]);
+                bv[2 * e] = (_Float16)pk[0]; bv[2 * e + 1] = (_Float16)pk[1];
+            }
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc2, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.A2 + (q * 64 + lane) * 4);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, accD[4 * q], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, accD[4 * q + 1], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, accD[4 * q + 2], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, accD[4 * q + 3], acc2, 0, 0, 0);
+        }
     }
     SCHED_PHASE();
 
@@ -637,6 +682,7 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
 // block-level rollout: expected cost of control sequence u (LDS). SPEC.md §5.3/§6/§7
 //   store_traj: stream x_t to a.traj; want_mean: particle mean trajectory -> xmean_out (global)
 // ------------------------------------------------------------------------------------------------
+template <bool F16>
 DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;
@@ -677,7 +723,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 #pragma unroll
                 for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
             }
-            step_fwd(a, sm, ww, t, h, lane, x, xi, xn, A);
+            step_fwd<F16>(a, sm, ww, t, h, lane, x, xi, xn, A);
             float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
             l = FMA(a.C.res_mult * A.eta, A.eta, l);
             J = FMA(sm.disc[t], l, J);
@@ -718,7 +764,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 // block-level cost + gradient (forward sweep with trajectory store, adjoint sweep). SPEC.md §5.4/§6
 //   y: control sequence in LDS; gout: gradient [H*m] in LDS
 // ------------------------------------------------------------------------------------------------
-template <int M>
+template <int M, bool F16>
 DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const float* y, float* gout, int b, int tid) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P, m = a.m;
@@ -755,7 +801,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 #pragma unroll
                 for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
             }
-            step_fwd(a, sm, ww, t, h, lane, x, xi, xn, A);
+            step_fwd<F16>(a, sm, ww, t, h, lane, x, xi, xn, A);
             {   // activation checkpoint: second hidden layer (4 x 16-byte stores per lane) + step scalars once per particle;
                 // the adjoint sweep recomputes only layer 1 from x_t (balance between HBM traffic and vector work)
                 float* ap = ac + (size_t)t * ACT_STRIDE;
@@ -826,7 +872,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
             float lamn[NX], gq[12];
             // recompute layer 1 only (R, v_body, 6 MFMAs, 32 tanh); everything downstream of it comes from the checkpoint
             // (the unused remainder of step_fwd is dead code and is removed by the compiler)
-            step_fwd(a, sm, ww, t, h, lane, xt, xi, xn, A);
+            step_fwd<F16>(a, sm, ww, t, h, lane, xt, xi, xn, A);
             A.h2 = h2l; A.eta = eta_l; A.Fb[0] = fb0; A.Fb[1] = fb1; A.Fb[2] = fb2; A.rn = rn_l;
 #pragma unroll
             for (int i = 0; i < 3; ++i) A.Jom[i] = a.M.J[i] * xt[10 + i];
@@ -895,6 +941,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ void __launch_bounds__(NT, 2) sdempc_rollout_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -904,11 +951,11 @@ __global__ void __launch_bounds__(NT, 2) sdempc_rollout_kernel(KArgs a) {
     load_common(a, sm, b, tid);
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += NT) sm.v[5][e] = a.u[(size_t)b * N + e];
-    float c = block_rollout(a, sm, ww, sm.v[5], b, tid, a.store_traj != 0, a.xmean ? a.xmean + (size_t)b * (a.H + 1) * NX : nullptr);
+    float c = block_rollout<F16>(a, sm, ww, sm.v[5], b, tid, a.store_traj != 0, a.xmean ? a.xmean + (size_t)b * (a.H + 1) * NX : nullptr);
     if (tid == 0) a.cost[b] = c;
 }
 
-template <int M>
+template <int M, bool F16>
 __global__ void __launch_bounds__(NT, 2) sdempc_grad_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -918,13 +965,13 @@ __global__ void __launch_bounds__(NT, 2) sdempc_grad_kernel(KArgs a) {
     load_common(a, sm, b, tid);
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += NT) sm.v[5][e] = a.u[(size_t)b * N + e];
-    float c = block_cost_grad<M>(a, sm, ww, sm.v[5], sm.v[3], b, tid);
+    float c = block_cost_grad<M, F16>(a, sm, ww, sm.v[5], sm.v[3], b, tid);
     if (tid == 0) a.cost[b] = c;
     for (int e = tid; e < N; e += NT) a.grad[(size_t)b * N + e] = sm.v[3][e];
 }
 
 // SPEC.md §8: monotone accelerated proximal gradient with Armijo backtracking, one instance per block
-template <int M>
+template <int M, bool F16>
 __global__ void __launch_bounds__(NT, 2) sdempc_solve_kernel(KArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -939,11 +986,11 @@ __global__ void __launch_bounds__(NT, 2) sdempc_solve_kernel(KArgs a) {
         float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
         xk[e] = v; yk[e] = v;
     }
-    const float c_init = block_rollout(a, sm, ww, xk, b, tid, false, nullptr);
+    const float c_init = block_rollout<F16>(a, sm, ww, xk, b, tid, false, nullptr);
     float c_x = c_init, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f;
     int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1;
     for (int k = 0; k < a.A.max_iter; ++k) {
-        const float c_y = block_cost_grad<M>(a, sm, ww, yk, g, b, tid);
+        const float c_y = block_cost_grad<M, F16>(a, sm, ww, yk, g, b, tid);
         gsq = block_dot(sm, g, g, N, tid);
         float c_n = 0.0f;
         int nls = 0;
@@ -957,7 +1004,7 @@ __global__ void __launch_bounds__(NT, 2) sdempc_solve_kernel(KArgs a) {
                     float v = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
                     xn[e] = v; d1[e] = v - yk[e];
                 }
-                c_n = block_rollout(a, sm, ww, xn, b, tid, false, nullptr);
+                c_n = block_rollout<F16>(a, sm, ww, xn, b, tid, false, nullptr);
                 float gd = block_dot(sm, g, d1, N, tid);
                 nls = jl + 1;
                 if (c_n <= FMA(a.A.coef, gd, c_y)) break;
@@ -967,7 +1014,7 @@ __global__ void __launch_bounds__(NT, 2) sdempc_solve_kernel(KArgs a) {
             s = a.A.stepsize;
             __syncthreads();
             for (int e = tid; e < N; e += NT) { int jj = e % m; xn[e] = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]); }
-            c_n = block_rollout(a, sm, ww, xn, b, tid, false, nullptr);
+            c_n = block_rollout<F16>(a, sm, ww, xn, b, tid, false, nullptr);
             nls = 1;
         }
         sum_ls = sum_ls + (float)nls; sum_s = sum_s + s; nit = k + 1; nls_tot += nls;
@@ -996,7 +1043,7 @@ __global__ void __launch_bounds__(NT, 2) sdempc_solve_kernel(KArgs a) {
     }
     __syncthreads();
     for (int e = tid; e < N; e += NT) a.uopt[(size_t)b * N + e] = xk[e];
-    block_rollout(a, sm, ww, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
+    block_rollout<F16>(a, sm, ww, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
     if (tid == 0) {
         float* inf = a.info + (size_t)b * 8;
         const float fn = (float)nit;
@@ -1012,38 +1059,52 @@ static hipError_t set_smem_attr(const void* fn, size_t bytes) {
     if (bytes > 64 * 1024) return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     return hipSuccess;
 }
+template <bool F16>
+static hipError_t launch_rollout_t(const KArgs& a, int B, hipStream_t st, size_t sb) {
+    hipError_t e = set_smem_attr((const void*)sdempc_rollout_kernel<F16>, sb);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sdempc_rollout_kernel<F16>, dim3(B), dim3(NT), sb, st, a);
+    return hipGetLastError();
+}
+template <int M, bool F16>
+static hipError_t launch_grad_t(const KArgs& a, int B, hipStream_t st, size_t sb) {
+    hipError_t e = set_smem_attr((const void*)sdempc_grad_kernel<M, F16>, sb);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sdempc_grad_kernel<M, F16>), dim3(B), dim3(NT), sb, st, a);
+    return hipGetLastError();
+}
+template <int M, bool F16>
+static hipError_t launch_solve_t(const KArgs& a, int B, hipStream_t st, size_t sb) {
+    hipError_t e = set_smem_attr((const void*)sdempc_solve_kernel<M, F16>, sb);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sdempc_solve_kernel<M, F16>), dim3(B), dim3(NT), sb, st, a);
+    return hipGetLastError();
+}
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) {
     size_t sb = smem_bytes(a.H, a.m);
-    hipError_t e = set_smem_attr((const void*)sdempc_rollout_kernel, sb);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sdempc_rollout_kernel, dim3(B), dim3(NT), sb, st, a);
-    return hipGetLastError();
-}
-template <int M>
-static hipError_t launch_grad_t(const KArgs& a, int B, hipStream_t st, size_t sb) {
-    hipError_t e = set_smem_attr((const void*)sdempc_grad_kernel<M>, sb);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sdempc_grad_kernel<M>, dim3(B), dim3(NT), sb, st, a);
-    return hipGetLastError();
-}
-template <int M>
-static hipError_t launch_solve_t(const KArgs& a, int B, hipStream_t st, size_t sb) {
-    hipError_t e = set_smem_attr((const void*)sdempc_solve_kernel<M>, sb);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sdempc_solve_kernel<M>, dim3(B), dim3(NT), sb, st, a);
-    return hipGetLastError();
+    return a.f16 ? launch_rollout_t<true>(a, B, st, sb) : launch_rollout_t<false>(a, B, st, sb);
 }
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st) {
     size_t sb = smem_bytes(a.H, a.m);
-    if (a.m == 4) return launch_grad_t<4>(a, B, st, sb);
-    if (a.m == 6) return launch_grad_t<6>(a, B, st, sb);
-    return launch_grad_t<8>(a, B, st, sb);
+    if (a.f16) {
+        if (a.m == 4) return launch_grad_t<4, true>(a, B, st, sb);
+        if (a.m == 6) return launch_grad_t<6, true>(a, B, st, sb);
+        return launch_grad_t<8, true>(a, B, st, sb);
+    }
+    if (a.m == 4) return launch_grad_t<4, false>(a, B, st, sb);
+    if (a.m == 6) return launch_grad_t<6, false>(a, B, st, sb);
+    return launch_grad_t<8, false>(a, B, st, sb);
 }
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st) {
     size_t sb = smem_bytes(a.H, a.m);
-    if (a.m == 4) return launch_solve_t<4>(a, B, st, sb);
-    if (a.m == 6) return launch_solve_t<6>(a, B, st, sb);
-    return launch_solve_t<8>(a, B, st, sb);
+    if (a.f16) {
+        if (a.m == 4) return launch_solve_t<4, true>(a, B, st, sb);
+        if (a.m == 6) return launch_solve_t<6, true>(a, B, st, sb);
+        return launch_solve_t<8, true>(a, B, st, sb);
+    }
+    if (a.m == 4) return launch_solve_t<4, false>(a, B, st, sb);
+    if (a.m == 6) return launch_solve_t<6, false>(a, B, st, sb);
+    return launch_solve_t<8, false>(a, B, st, sb);
 }
 
 }  // namespace sdempc

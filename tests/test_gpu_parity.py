@@ -264,3 +264,47 @@ def test_c5_long_horizon_shape_runs():
     c2, g2 = O.grad(x0[0], u[0], xref[0], noise[0])
     assert gc[0] == np.float32(c2) and bits_differ(grad[0], g2.astype(np.float32)) == 0
     S.close()
+
+
+# ---- fp16-operand MLP mode (SPEC.md §9, BASELINE config C5): tolerance parity -------------------------------
+# v_mfma_f32_32x32x16_f16 accumulates its 16 exact products in a hardware-specific order (tools/mfma_f16_probe.hip),
+# so this mode is compared with the oracle's emulation (same RTZ quantisation, sequential f32 accumulation) within
+# tolerances instead of bit for bit.
+def test_f16_mode_matches_oracle_emulation():
+    cfg = MPCConfig(horizon=24, num_short_dt=24, num_particles=70, u_slew_coeff=1.0, max_iter=8, max_no_improvement_iter=8, mlp_dtype="f16")
+    model = synthetic_iris()
+    B = 4
+    x0, xref, noise, u = _problem(cfg, B, seed=61)
+    S, O = _solver(cfg, model, B), orc.Oracle(cfg, model)
+    cost, traj, xmean = S.rollout(x0, u, xref, noise, True, True)
+    cost_again, _, _ = S.rollout(x0, u, xref, noise, False, False)
+    assert bits_differ(cost, cost_again) == 0                            # deterministic
+    gc, grad = S.grad(x0, u, xref, noise)
+    assert bits_differ(gc, cost) == 0
+    u0 = np.tile(np.asarray(cfg.uref, np.float32), (B, cfg.horizon, 1))
+    uopt, xevol, info = S.solve(x0, xref, noise, u0, np.full(B, 0.01, np.float32))
+    assert uopt.min() >= 1e-4 and uopt.max() <= 1.0 and np.all(info[:, 6] <= info[:, 5])
+    for b in range(B):
+        c, t, xm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True)
+        np.testing.assert_allclose(cost[b], c, rtol=2e-6)
+        np.testing.assert_allclose(traj[b], t, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(xmean[b], xm, rtol=1e-4, atol=2e-5)
+        c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
+        np.testing.assert_allclose(grad[b], g2, rtol=1e-4, atol=1e-5 * np.abs(g2).max())
+        uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u0[b], 0.01)
+        np.testing.assert_allclose(info[b, 5], inf[5], rtol=2e-6)        # initial cost
+        np.testing.assert_allclose(info[b, 6], inf[6], rtol=1e-3)        # optimised cost (decisions may differ by rounding)
+    S.close()
+
+
+def test_c5_f16_mlp_path():
+    """BASELINE config C5: H=200, P=1024 with the fp16 drift-MLP MFMA path; gradient against the oracle emulation."""
+    cfg = load_mpc_config(os.path.join(CDIR, "c5_iris_traj_h200_p1024.yaml")).replace(mlp_dtype="f16")
+    model = synthetic_iris()
+    x0, xref, noise, u = _problem(cfg, 1, seed=78)
+    S, O = _solver(cfg, model, 1), orc.Oracle(cfg, model)
+    gc, grad = S.grad(x0, u, xref, noise)
+    c2, g2 = O.grad(x0[0], u[0], xref[0], noise[0])
+    np.testing.assert_allclose(gc[0], c2, rtol=1e-5)
+    np.testing.assert_allclose(grad[0], g2, rtol=1e-3, atol=1e-4 * np.abs(g2).max())
+    S.close()

@@ -137,3 +137,29 @@ def test_zero_iterations_returns_projected_warm_start():
     uopt, xevol, info, _ = O.solve(x0, xref, noise, u0, 0.01)
     np.testing.assert_array_equal(uopt, np.clip(u0, np.float32(1e-4), np.float32(1.0)))
     assert info[2] == 0 and info[5] == info[6]
+
+
+def test_f16_rtz_quantiser_matches_numpy_semantics():
+    L = orc.lib()
+    L.orc_f16_rtz_value.argtypes, L.orc_f16_rtz_value.restype = [C.c_double], C.c_double
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.standard_normal(4000) * np.exp2(rng.integers(-28, 18, 4000)), [0.0, -0.0, 65504.0, 65520.0, 1e6, -1e6, 6.1e-5, 5.9e-8, 2.0 ** -25]]).astype(np.float32)
+    for x in xs:
+        q = np.float32(L.orc_f16_rtz_value(float(x)))
+        with np.errstate(over="ignore"):
+            h = np.float16(x)                               # round to nearest
+        if np.isinf(h):
+            h = np.float16(np.sign(x) * 65504.0)
+        elif abs(np.float32(h)) > abs(x):                   # nearest went away from zero: step back toward zero
+            h = np.nextafter(h, np.float16(0.0))
+        assert q == np.float32(h), (x, q, h)
+        assert abs(q) <= abs(x) and np.float32(np.float16(q)) == q
+
+
+def test_f16_mode_is_close_to_f32_mode():
+    cfg, model, x0, xref, noise, u = _small_problem(H=20, P=32)
+    c32, g32 = orc.Oracle(cfg, model).grad(x0, u, xref, noise)
+    c16, g16 = orc.Oracle(cfg.replace(mlp_dtype="f16"), model).grad(x0, u, xref, noise)
+    assert c16 != c32                                       # the quantisation is really applied
+    assert abs(c16 - c32) <= 1e-3 * abs(c32)
+    assert np.abs(g16 - g32).max() <= 2e-2 * np.abs(g32).max()

@@ -192,6 +192,7 @@ static inline int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; 
 
 /* ------------------------------------------------------------------------------------------- */
 /* per-step control-dependent constants (SPEC.md §5.1)                                         */
+/* serves: rollout inside m_mpc (call sites sde_control.py:400-416); body NOT IN REFERENCE      */
 /* ------------------------------------------------------------------------------------------- */
 typedef struct {
     real c[HID];      /* drift layer-1 pre-activation offset b1 + W1u u_t */
@@ -222,6 +223,7 @@ static void ustep_eval(const model_t* M, const real* u, ustep_t* U) {
 
 /* ------------------------------------------------------------------------------------------- */
 /* one Euler–Maruyama step (SPEC.md §5.2) and its vector-Jacobian product (§5.4)               */
+/* SURVEY.md §8a A4/A6; knobs launch/iris_sitl_traj_mpc.yaml:44-52; body NOT IN REFERENCE      */
 /* ------------------------------------------------------------------------------------------- */
 typedef struct { /* values the VJP re-uses; recomputed from x_t in the backward sweep */
     real Rm[9], vb[3], h1d[HID], h1n[HID], h2[HID], o[6], eta, Fb[3], Jom[3], qt[4], rn, qn[4];
@@ -302,7 +304,8 @@ static void step_fwd(const model_t* M, const ustep_t* U, const real* x, const re
     for (int i = 0; i < 4; ++i) { A->qn[i] = A->qt[i] * A->rn; xn[6 + i] = A->qn[i]; }
 }
 
-/* stage state cost at x_{t+1} (SPEC.md §5.3): returns l, optionally the gradient wrt x_{t+1} */
+/* stage state cost at x_{t+1} (SPEC.md §5.3): returns l, optionally the gradient wrt x_{t+1}.
+ * SURVEY.md §8a A5; weights = cost_params of launch/iris_sitl_traj_mpc.yaml:32-41 */
 static real stage_cost(const sdempc_cfg* C, const real* x, const real* xr, real* gx) {
     real l = 0;
     for (int i = 0; i < 3; ++i) {
@@ -507,7 +510,8 @@ static int ctx_init(ctx_t* X, const sdempc_cfg* C, const void* blob) {
 }
 static void ctx_free(ctx_t* X) { free(X->dt); free(X->sdt); free(X->disc); }
 
-/* control cost and its gradient (SPEC.md §5.5): element e = t*m + j */
+/* control cost and its gradient (SPEC.md §5.5): element e = t*m + j.
+ * keys uref/uerr/u_slew_coeff/u_slew_constr(_coeff): launch/iris_sitl_posctrl_mpc.yaml:30-41 */
 static real ucost(const ctx_t* X, const real* u, real* gcu) {
     const sdempc_cfg* C = X->C;
     int H = X->H, m = X->m, N = H * m;
@@ -648,6 +652,8 @@ static real cost_grad(const ctx_t* X, const real* x0, const real* u, const real*
 
 /* ------------------------------------------------------------------------------------------- */
 /* accelerated proximal gradient with Armijo backtracking (SPEC.md §8)                         */
+/* = m_mpc (sde_control.py:713-719,400-416); knobs apg_mpc: launch/iris_sitl_traj_mpc.yaml:55-85; */
+/* telemetry read at sde_control.py:444-450                                                    */
 /* ------------------------------------------------------------------------------------------- */
 static inline real clampr(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
 

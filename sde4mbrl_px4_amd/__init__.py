@@ -7,6 +7,6 @@ hand-written HIP kernels (``csrc/``) behind the C ABI declared in ``include/sdem
 CPU fallback: importing the solver without the built extension raises.
 """
 from .config import MPCConfig, load_mpc_config
-from .model import RotorSDEModel, synthetic_iris, synthetic_hexa
+from .model import RotorSDEModel, synthetic_iris, synthetic_hexa, synthetic_multirotor
 
-__all__ = ["MPCConfig", "load_mpc_config", "RotorSDEModel", "synthetic_iris", "synthetic_hexa"]
+__all__ = ["MPCConfig", "load_mpc_config", "RotorSDEModel", "synthetic_iris", "synthetic_hexa", "synthetic_multirotor"]

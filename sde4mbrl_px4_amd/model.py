@@ -135,3 +135,25 @@ def synthetic_hexa(seed: int = 10) -> RotorSDEModel:
         res_torque_scale=np.array([0.006, 0.006, 0.003], np.float32),
         sigma=np.array([0.15, 0.15, 0.15, 0.3, 0.3, 0.3], np.float32),
         W1z=W1z, b1=b1, W1u=W1u, W2=W2, b2=b2, W3=W3, b3=b3, w3n=w3n, b3n=0.0)
+
+
+def synthetic_multirotor(num_motors: int, seed: int = 10, hover_u: float = 0.6) -> RotorSDEModel:
+    """Generic synthetic vehicle with `num_motors` rotors evenly spaced on a circle (1..8 motors): exercises the
+    motor-count-generic kernel instantiation. Hover thrust is reached at u = hover_u."""
+    m = int(num_motors)
+    assert 1 <= m <= MAX_MOTORS
+    rng = np.random.default_rng(seed + 77 * m)
+    W1z, b1, W1u, W2, b2, W3, b3, w3n = _mlp_weights(rng, m)
+    ang = 2.0 * np.pi * (np.arange(m) + 0.5) / m
+    mass, grav, arm = 1.2 + 0.2 * m, 9.81, 0.25
+    t_hover = mass * grav / m
+    ct2 = 0.8 * t_hover / hover_u ** 2
+    ct1 = 0.2 * t_hover / hover_u
+    return RotorSDEModel(
+        num_motors=m, mass=mass, grav=grav, inertia=np.array([0.03, 0.03, 0.05], np.float32) * (1 + 0.1 * m),
+        thrust_poly=np.array([ct2, ct1, 0.0], np.float32), moment_poly=np.array([0.016 * ct2, 0.016 * ct1], np.float32),
+        rotor_x=(arm * np.cos(ang)).astype(np.float32), rotor_y=(arm * np.sin(ang)).astype(np.float32),
+        rotor_dir=np.where(np.arange(m) % 2 == 0, 1.0, -1.0).astype(np.float32),
+        res_force_scale=np.array([0.3, 0.3, 0.5], np.float32), res_torque_scale=np.array([0.004, 0.004, 0.002], np.float32),
+        sigma=np.array([0.15, 0.15, 0.15, 0.3, 0.3, 0.3], np.float32),
+        W1z=W1z, b1=b1, W1u=W1u, W2=W2, b2=b2, W3=W3, b3=b3, w3n=w3n, b3n=0.0)

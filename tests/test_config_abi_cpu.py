@@ -110,7 +110,19 @@ def test_handle_lifecycle_and_errors_without_gpu():
     dummy = np.zeros(8, np.float32).ctypes.data_as(fp)
     assert lib.sdempc_rollout_batch(h, 5, dummy, dummy, dummy, dummy, dummy, None, None) == -5
     assert b"max_batch" in lib.sdempc_last_error(h)
+    assert lib.sdempc_rollout_batch(h, 0, dummy, dummy, dummy, dummy, dummy, None, None) == -1          # empty batch
     lib.sdempc_destroy(h)
+    # horizon limits: one workgroup's LDS (160 KiB) bounds H; 256 still fits for 4 motors, 400 does not
+    for H, ok in ((256, True), (400, False), (0, False)):
+        cl, k2 = cfg_py.replace(horizon=H, num_short_dt=H).to_cfg() if H > 0 else (None, None)
+        if H == 0:
+            cl = _abi.SdempcCfg.from_buffer_copy(cfg)
+            cl.horizon = 0
+        hh = C.c_void_p()
+        rc = lib.sdempc_create(C.byref(cl), buf, len(blob), 1, C.byref(hh))
+        assert (rc == 0) == ok, (H, rc, lib.sdempc_last_error(None))
+        if rc == 0:
+            lib.sdempc_destroy(hh)
     # bad arguments
     h2 = C.c_void_p()
     bad = _abi.SdempcCfg.from_buffer_copy(cfg)

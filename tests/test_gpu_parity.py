@@ -10,7 +10,7 @@ import pytest
 
 import orc
 from cases import CDIR, bits_differ, golden_cases, load_golden
-from sde4mbrl_px4_amd import MPCConfig, load_mpc_config, synthetic_hexa, synthetic_iris
+from sde4mbrl_px4_amd import MPCConfig, load_mpc_config, synthetic_hexa, synthetic_iris, synthetic_multirotor
 from sde4mbrl_px4_amd import workload as W
 
 pytestmark = pytest.mark.gpu
@@ -140,6 +140,26 @@ def test_random_configurations_bit_exact(seed):
         assert gc[b] == np.float32(c2) and bits_differ(grad[b], g2.astype(np.float32)) == 0
         uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u0[b], cfg.ls_init_stepsize)
         _close(uopt[b], uo, "uopt")
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], inf) == 0
+    S.close()
+
+
+@pytest.mark.parametrize("m", [1, 3, 5, 8])
+def test_generic_motor_count_bit_exact(m):
+    """Motor counts other than 4 / 6 run the generic (8-slot, zero-padded) kernel instantiation."""
+    cfg = MPCConfig(horizon=9, num_short_dt=9, num_particles=45, input_id=list(range(m)), input_bound=[[1e-4, 1.0]] * m, uref=[0.6] * m,
+                    u_slew_coeff=0.5, max_iter=5, max_no_improvement_iter=5)
+    model = synthetic_multirotor(m)
+    B = 2
+    x0, xref, noise, u = _problem(cfg, B, seed=40 + m)
+    S, O = _solver(cfg, model, B), orc.Oracle(cfg, model)
+    gc, grad = S.grad(x0, u, xref, noise)
+    u0 = np.tile(np.asarray(cfg.uref, np.float32), (B, cfg.horizon, 1))
+    uopt, xevol, info = S.solve(x0, xref, noise, u0, np.full(B, 0.01, np.float32))
+    for b in range(B):
+        c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
+        assert gc[b] == np.float32(c2) and bits_differ(grad[b], g2.astype(np.float32)) == 0
+        uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u0[b], 0.01)
         assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], inf) == 0
     S.close()
 

@@ -90,11 +90,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test hooks (single-GPU boxes): SDEMPC_BENCH_DEVICE pins every rank to one ordinal, SDEMPC_BENCH_BACKEND=gloo
+    # replaces RCCL; the driver's multi-GPU runs use neither (one GPU per rank, backend nccl = RCCL over xGMI)
+    dev_ord = int(os.environ.get("SDEMPC_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("SDEMPC_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_ord)
+    dev = torch.device("cuda", dev_ord)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = load_mpc_config(args.config).replace(mlp_dtype=args.mlp_dtype)
     H, P, m, B = cfg.horizon, cfg.num_particles, cfg.num_motors, args.batch
@@ -103,7 +110,7 @@ def main():
     blob = (synthetic_iris() if m == 4 else synthetic_hexa()).to_blob() if rank == 0 else b""
     blob = broadcast_blob(blob, src=0, device=dev)
 
-    solver = SdeMpcSolver(cfg, blob, max_batch=B, device=local_rank)
+    solver = SdeMpcSolver(cfg, blob, max_batch=B, device=dev_ord)
     # synthetic inputs, distinct per rank, resident in HBM before timing
     seed0 = rank * B
     x0_h = W.random_initial_states(B, seed0)

@@ -39,6 +39,29 @@ class RotorSDEModel:
     w3n: np.ndarray                # [32]     density net output weights
     b3n: float = 0.0
 
+    _ARRAY_FIELDS = ("inertia", "thrust_poly", "moment_poly", "rotor_x", "rotor_y", "rotor_dir", "res_force_scale", "res_torque_scale",
+                     "sigma", "W1z", "b1", "W1u", "W2", "b2", "W3", "b3", "w3n")
+
+    def save_npz(self, path: str) -> None:
+        """Portable container for user-supplied weights (the reference's *.pkl format lives in the external repo)."""
+        np.savez(path, num_motors=self.num_motors, mass=self.mass, grav=self.grav, b3n=self.b3n,
+                 **{k: np.asarray(getattr(self, k), np.float32) for k in self._ARRAY_FIELDS})
+
+    @classmethod
+    def load_npz(cls, path: str) -> "RotorSDEModel":
+        d = np.load(path)
+        m = int(d["num_motors"])
+        shapes = {"inertia": (3,), "thrust_poly": (3,), "moment_poly": (2,), "rotor_x": (m,), "rotor_y": (m,), "rotor_dir": (m,),
+                  "res_force_scale": (3,), "res_torque_scale": (3,), "sigma": (6,), "W1z": (64, 6), "b1": (64,), "W1u": (32, m),
+                  "W2": (32, 32), "b2": (32,), "W3": (6, 32), "b3": (6,), "w3n": (32,)}
+        kw = {}
+        for k, shp in shapes.items():
+            a = np.asarray(d[k], np.float32)
+            if a.shape != shp:
+                raise ValueError(f"{path}: array {k} has shape {a.shape}, expected {shp}")
+            kw[k] = a
+        return cls(num_motors=m, mass=float(d["mass"]), grav=float(d["grav"]), b3n=float(d["b3n"]), **kw)
+
     def to_blob(self) -> bytes:
         m = self.num_motors
         assert 1 <= m <= MAX_MOTORS

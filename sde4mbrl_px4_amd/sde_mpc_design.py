@@ -115,6 +115,12 @@ class MpcProblem:
 def _pick_model(cfg: MPCConfig, model) -> RotorSDEModel:
     if model is not None:
         return model
+    lm = os.path.expanduser(cfg.learned_model_params) if cfg.learned_model_params else None
+    if lm and lm.endswith(".npz") and os.path.exists(lm):
+        m = RotorSDEModel.load_npz(lm)
+        if m.num_motors != cfg.num_motors:
+            raise ValueError(f"{lm}: model has {m.num_motors} motors, config has {cfg.num_motors}")
+        return m
     # learned_model_params names a pickle of the external sde4mbrl repo (iris_sitl_traj_mpc.yaml:3) whose
     # format is not in the reference; this build ships synthetic vehicles.
     return synthetic_iris() if cfg.num_motors == 4 else synthetic_hexa()

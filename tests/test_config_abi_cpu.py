@@ -74,6 +74,19 @@ def test_model_blob_layout():
     assert abs(T - m.mass * m.grav) < 0.02 * m.mass * m.grav
 
 
+def test_model_npz_round_trip(tmp_path):
+    from sde4mbrl_px4_amd import RotorSDEModel
+    m = synthetic_hexa(3)
+    f = str(tmp_path / "model.npz")
+    m.save_npz(f)
+    assert RotorSDEModel.load_npz(f).to_blob() == m.to_blob()
+    d = dict(np.load(f))
+    d["W2"] = np.zeros((32, 31), np.float32)
+    np.savez(f, **d)
+    with pytest.raises(ValueError, match="W2"):
+        RotorSDEModel.load_npz(f)
+
+
 def _header_symbols():
     txt = open(os.path.join(ROOT, "include", "sdempc.h")).read()
     return sorted(set(re.findall(r"\b(sdempc_[a-z_0-9]+)\s*\(", txt)))

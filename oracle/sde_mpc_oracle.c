@@ -486,6 +486,8 @@ typedef struct {
     real* sdt;   /* [H][6] sigma_i * sqrt(dt) */
     real* disc;  /* [H+1] */
     real invP;
+    /* per-context workspace (no allocation inside rollouts / gradients) */
+    void* wsU; real *wsJp, *wsTraj, *wsQ, *wsG, *wsCe, *wsDw, *wsCol, *wsXs;
 } ctx_t;
 
 static int ctx_init(ctx_t* X, const sdempc_cfg* C, const void* blob) {
@@ -506,17 +508,32 @@ static int ctx_init(ctx_t* X, const sdempc_cfg* C, const void* blob) {
     float d = 1.0f / (float)X->H;
     for (int t = 0; t <= X->H; ++t) { X->disc[t] = d; d = d * C->discount; }
     X->invP = (real)(1.0f / (float)X->P);
+    {
+        size_t H = X->H, P = X->P, m = X->m;
+        X->wsU = malloc(sizeof(ustep_t) * H);
+        X->wsJp = (real*)malloc(sizeof(real) * P);
+        X->wsTraj = (real*)malloc(sizeof(real) * P * (H + 1) * NX);
+        X->wsQ = (real*)malloc(sizeof(real) * H * (m + 4) * P);
+        X->wsG = (real*)malloc(sizeof(real) * H * m);
+        X->wsCe = (real*)malloc(sizeof(real) * H * m);
+        X->wsDw = (real*)malloc(sizeof(real) * H * m);
+        X->wsCol = (real*)malloc(sizeof(real) * P);
+        X->wsXs = (real*)malloc(sizeof(real) * P * (H + 1) * NX);
+    }
     return 0;
 }
-static void ctx_free(ctx_t* X) { free(X->dt); free(X->sdt); free(X->disc); }
+static void ctx_free(ctx_t* X) {
+    free(X->dt); free(X->sdt); free(X->disc);
+    free(X->wsU); free(X->wsJp); free(X->wsTraj); free(X->wsQ); free(X->wsG); free(X->wsCe); free(X->wsDw); free(X->wsCol); free(X->wsXs);
+}
 
 /* control cost and its gradient (SPEC.md §5.5): element e = t*m + j.
  * keys uref/uerr/u_slew_coeff/u_slew_constr(_coeff): launch/iris_sitl_posctrl_mpc.yaml:30-41 */
 static real ucost(const ctx_t* X, const real* u, real* gcu) {
     const sdempc_cfg* C = X->C;
     int H = X->H, m = X->m, N = H * m;
-    real* ce = (real*)malloc(sizeof(real) * N);
-    real* dw = (real*)malloc(sizeof(real) * N);
+    real* ce = X->wsCe;
+    real* dw = X->wsDw;
     for (int t = 0; t < H; ++t) for (int j = 0; j < m; ++j) {
         int e = t * m + j;
         real du = u[e] - (real)C->uref[j];
@@ -545,20 +562,17 @@ static real ucost(const ctx_t* X, const real* u, real* gcu) {
             if (t + 1 < H) g = FMA(-X->disc[t + 1], dw[e + m], g);
             gcu[e] = g;
         }
-    real tot = dot256(ce, NULL, N);
-    free(ce); free(dw);
-    return tot;
+    return dot256(ce, NULL, N);
 }
 
 /* rollout: expected cost; optional traj [P][H+1][13], xmean [H+1][13] (SPEC.md §5.3, §7) */
 static real rollout(const ctx_t* X, const real* x0, const real* u, const real* xref, const real* noise,
                     real* traj, real* xmean) {
     int H = X->H, P = X->P, m = X->m;
-    ustep_t* U = (ustep_t*)malloc(sizeof(ustep_t) * H);
+    ustep_t* U = (ustep_t*)X->wsU;
     for (int t = 0; t < H; ++t) ustep_eval(&X->M, u + t * m, &U[t]);
-    real* Jp = (real*)malloc(sizeof(real) * P);
-    real* xs = NULL;
-    if (xmean) xs = (real*)malloc(sizeof(real) * P * (H + 1) * NX);
+    real* Jp = X->wsJp;
+    real* xs = xmean ? X->wsXs : NULL;
     stepaux_t A;
     for (int p = 0; p < P; ++p) {
         real x[NX], xn[NX];
@@ -582,14 +596,12 @@ static real rollout(const ctx_t* X, const real* x0, const real* u, const real* x
     real tot = preduce(Jp, P);
     real cu = ucost(X, u, NULL);
     if (xmean) {
-        real* col = (real*)malloc(sizeof(real) * P);
+        real* col = X->wsCol;
         for (int t = 0; t <= H; ++t) for (int i = 0; i < NX; ++i) {
             for (int p = 0; p < P; ++p) col[p] = xs[((size_t)p * (H + 1) + t) * NX + i];
             xmean[t * NX + i] = preduce(col, P) * X->invP;
         }
-        free(col); free(xs);
     }
-    free(U); free(Jp);
     return FMA(tot, X->invP, cu);
 }
 
@@ -597,13 +609,13 @@ static real rollout(const ctx_t* X, const real* x0, const real* u, const real* x
 static real cost_grad(const ctx_t* X, const real* x0, const real* u, const real* xref, const real* noise, real* grad) {
     int H = X->H, P = X->P, m = X->m;
     const model_t* M = &X->M;
-    ustep_t* U = (ustep_t*)malloc(sizeof(ustep_t) * H);
+    ustep_t* U = (ustep_t*)X->wsU;
     for (int t = 0; t < H; ++t) ustep_eval(M, u + t * m, &U[t]);
-    real* traj = (real*)malloc(sizeof(real) * (size_t)P * (H + 1) * NX);
-    real* Jp = (real*)malloc(sizeof(real) * P);
+    real* traj = X->wsTraj;
+    real* Jp = X->wsJp;
     /* per-particle, per-step adjoint outputs: [H][m+4][P] */
     int nq = m + 4;
-    real* Q = (real*)malloc(sizeof(real) * (size_t)H * nq * P);
+    real* Q = X->wsQ;
     stepaux_t A;
     for (int p = 0; p < P; ++p) {
         real* tp = traj + (size_t)p * (H + 1) * NX;
@@ -632,7 +644,7 @@ static real cost_grad(const ctx_t* X, const real* x0, const real* u, const real*
         }
     }
     real tot = preduce(Jp, P);
-    real* gcu = (real*)malloc(sizeof(real) * H * m);
+    real* gcu = X->wsG;
     real cu = ucost(X, u, gcu);
     for (int t = 0; t < H; ++t) {
         real S[MAXM + 4];
@@ -646,7 +658,6 @@ static real cost_grad(const ctx_t* X, const real* x0, const real* u, const real*
             grad[t * m + j] = FMA(a, X->invP, gcu[t * m + j]);
         }
     }
-    free(U); free(traj); free(Jp); free(Q); free(gcu);
     return FMA(tot, X->invP, cu);
 }
 

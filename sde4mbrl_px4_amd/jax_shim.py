@@ -7,7 +7,27 @@ run unmodified apart from its import lines:
 
 Nothing is traced or compiled here: the solver callables already dispatch to pre-built HIP kernels.
 Key splitting is NOT threefry-compatible."""
+import os
+
 import numpy as np
+
+
+class _Compiled:
+    """What `.lower(...).compile()` returns. With SDEMPC_PREFORK=shape in the environment, calls made by the process that
+    "compiled" the callable are treated as the reference's pre-fork warm-up / shape probes (sde_control.py:706,717): they are
+    answered by the callable's `shape_probe` (no HIP call, outputs of the right shapes only); calls from any other process
+    (the forked `mpc_process`, sde_control.py:723-728) run the real solver. Without the variable every call is real."""
+
+    def __init__(self, f):
+        self._f = f
+        self._pid = os.getpid()
+
+    def __call__(self, *a, **k):
+        if os.environ.get("SDEMPC_PREFORK") == "shape" and os.getpid() == self._pid:
+            probe = getattr(getattr(self._f, "__self__", None), "shape_probe_" + getattr(self._f, "__name__", ""), None)
+            if probe is not None:
+                return probe(*a, **k)
+        return self._f(*a, **k)
 
 
 class _Lowered:
@@ -15,7 +35,7 @@ class _Lowered:
         self._f = f
 
     def compile(self):
-        return self._f
+        return _Compiled(self._f)
 
 
 class _Jitted:

@@ -95,6 +95,12 @@ class MpcProblem:
         z = np.float32(0.0)
         return OptState(_arr(yk), z, np.float32(s0), z, z, z, z, z, z)
 
+    def shape_probe_m_mpc(self, x, rng, opt_state: OptState, curr_t=0.0, xdes=None):
+        """Outputs with the shapes/dtypes of m_mpc and no device work (see jax_shim._Compiled): the warm start as uopt,
+        the current state repeated as xevol. Used only for the reference's pre-fork warm-up calls."""
+        x = np.asarray(x, np.float32).reshape(13)
+        return _arr(np.asarray(opt_state.yk, np.float32)), opt_state, rng, _arr(np.tile(x, (self.cfg.horizon + 1, 1)))
+
     def m_mpc(self, x, rng, opt_state: OptState, curr_t=0.0, xdes=None):
         H, P = self.cfg.horizon, self.cfg.num_particles
         x = np.asarray(x, np.float32).reshape(13)

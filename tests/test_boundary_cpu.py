@@ -73,6 +73,23 @@ def test_jax_facade_matches_call_patterns():
     np.testing.assert_array_equal(jax_shim.random.split(k, 3), jax_shim.random.split(k, 3))
 
 
+def test_prefork_shape_probe_touches_no_device(monkeypatch):
+    """load_single_mpc's warm-up calls (sde_control.py:706,717) under SDEMPC_PREFORK=shape: right shapes, no solver created."""
+    monkeypatch.setenv("SDEMPC_PREFORK", "shape")
+    cfg_dict, (m_reset, m_mpc), _, _ = load_mpc_from_cfgfile(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"))
+    prob = cfg_dict["_problem"]
+    x0 = HOVER.copy()
+    rng = jax_shim.random.PRNGKey(10)
+    reset_c = jax_shim.jit(m_reset).lower(x=x0, rng=rng, xdes=x0).compile()
+    st = reset_c(x=x0, rng=rng, xdes=x0)
+    st.yk.block_until_ready()
+    mpc_c = jax_shim.jit(m_mpc).lower(x0, rng, st, curr_t=0.01, xdes=x0).compile()
+    uopt, st2, rng2, xevol = mpc_c(x0, rng, st, curr_t=0.01, xdes=x0)
+    uopt.block_until_ready()
+    assert np.array(uopt).shape == (20, 4) and xevol.shape == (21, 13) and st2 is st
+    assert prob._solver is None                                           # nothing touched the GPU library
+
+
 def test_shared_block_layouts_and_command_selection():
     _, (m_reset, _), _, _ = load_mpc_from_cfgfile(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"))
     sh = SharedBlocks.create(50, 20, 4, m_reset())

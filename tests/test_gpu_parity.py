@@ -164,6 +164,35 @@ def test_generic_motor_count_bit_exact(m):
     S.close()
 
 
+def test_saturating_activations_and_violent_states_bit_exact():
+    """Weights scaled up so that tanh / sigmoid arguments exceed their clamp ranges (|x| > 9, > 30), fast tumbling initial
+    states and strong diffusion: exercises the clamped branches of SPEC.md §3 and large-magnitude arithmetic."""
+    model = synthetic_iris(5)
+    model.W1z = (model.W1z * 25.0).astype(np.float32)
+    model.W2 = (model.W2 * 6.0).astype(np.float32)
+    model.w3n = (model.w3n * 40.0).astype(np.float32)
+    model.sigma = (model.sigma * 8.0).astype(np.float32)
+    cfg = MPCConfig(horizon=15, num_short_dt=15, num_particles=64, u_slew_coeff=1.0, max_iter=6, max_no_improvement_iter=6)
+    B = 3
+    x0, xref, noise, u = _problem(cfg, B, seed=90)
+    x0[:, 3:6] *= 30.0
+    x0[:, 10:13] *= 60.0
+    S, O = _solver(cfg, model, B), orc.Oracle(cfg, model)
+    cost, traj, xmean = S.rollout(x0, u, xref, noise, True, True)
+    gc, grad = S.grad(x0, u, xref, noise)
+    u0 = np.tile(np.asarray(cfg.uref, np.float32), (B, cfg.horizon, 1))
+    uopt, xevol, info = S.solve(x0, xref, noise, u0, np.full(B, 0.01, np.float32))
+    assert np.all(np.isfinite(traj)) and np.all(np.isfinite(grad))
+    for b in range(B):
+        c, t, xm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True)
+        assert cost[b] == np.float32(c) and bits_differ(traj[b], t) == 0 and bits_differ(xmean[b], xm) == 0
+        c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
+        assert gc[b] == np.float32(c2) and bits_differ(grad[b], g2.astype(np.float32)) == 0
+        uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u0[b], 0.01)
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], inf) == 0
+    S.close()
+
+
 def test_hexa_six_motors_bit_exact():
     cfg = load_mpc_config(os.path.join(CDIR, "c3_hexa_traj_h50_p256.yaml")).replace(horizon=14, num_short_dt=14, num_particles=96, max_iter=6, max_no_improvement_iter=6)
     model = synthetic_hexa()

@@ -71,3 +71,48 @@ def test_worker_replays_mode_sequence():
     assert traj_states[2] == 0.0 and traj_states[3] > 0.0 and traj_states[4] == traj_states[3]
     sel = select_command(t_us + 60_000.0, t_us, wk.dt_usec_traj, wk.shared.u_opt, wk.shared.w_opt, 12)
     assert sel[0] == 1 and sel[1].shape == (6,)
+
+
+FORK_SCRIPT = r"""
+import os, sys, json, multiprocessing as mp
+sys.path.insert(0, os.environ["REPO"])
+os.environ["SDEMPC_PREFORK"] = "shape"
+import numpy as np
+from sde4mbrl_px4_amd import jax_shim as jax
+from sde4mbrl_px4_amd.sde_mpc_design import load_mpc_from_cfgfile
+from sde4mbrl_px4_amd.workload import HOVER, random_initial_states
+
+cfg_dict, (m_reset, m_mpc), _, _ = load_mpc_from_cfgfile(os.path.join(os.environ["REPO"], "configs", "c1_iris_posctrl_h20_p32.yaml"),
+                                                       overrides=dict(max_iter=5, max_no_improvement_iter=5))
+x0 = HOVER.copy(); rng = jax.random.PRNGKey(10)
+reset_c = jax.jit(m_reset).lower(x=x0, rng=rng, xdes=x0).compile()           # parent, pre-fork (sde_control.py:702-707)
+st = reset_c(x=x0, rng=rng, xdes=x0)
+mpc_c = jax.jit(m_mpc).lower(x0, rng, st, curr_t=0.01, xdes=x0).compile()     # :713
+u_probe, _, _, _ = mpc_c(x0, rng, st, curr_t=0.01, xdes=x0)                    # :717 warm-up -> shape probe, no HIP
+
+def worker(q):                                                                 # mpc_process_fn (:328) in the forked child
+    x = random_initial_states(1, 2)[0]
+    u, st2, r2, xe = mpc_c(x, rng, st, curr_t=0.0, xdes=HOVER)
+    u.block_until_ready()
+    q.put({"shape": list(np.array(u).shape), "num_steps": float(st2.num_steps), "opt": float(st2.opt_cost), "init": float(st2.init_cost),
+           "moved": bool(np.abs(np.array(u) - 0.71).max() > 1e-6)})
+
+ctx = mp.get_context("fork")
+q = ctx.Queue(); p = ctx.Process(target=worker, args=(q,)); p.start(); res = q.get(timeout=120); p.join(30)
+print(json.dumps({"probe_is_warm_start": bool(np.all(np.array(u_probe) == np.float32(0.71))), "child": res, "exit": p.exitcode}))
+"""
+
+
+def test_forked_worker_solves_after_prefork_shape_probe(tmp_path):
+    """The reference's process model: solvers built and warmed up in the parent, used in the forked mpc_process."""
+    import json
+    import subprocess
+    import sys
+    from cases import ROOT
+    f = tmp_path / "fork_flow.py"
+    f.write_text(FORK_SCRIPT)
+    out = subprocess.run([sys.executable, str(f)], env=dict(os.environ, REPO=ROOT), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["probe_is_warm_start"] and res["exit"] == 0
+    assert res["child"]["shape"] == [20, 4] and res["child"]["num_steps"] == 5 and res["child"]["moved"] and res["child"]["opt"] <= res["child"]["init"]

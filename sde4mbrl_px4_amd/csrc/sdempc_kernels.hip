@@ -11,18 +11,23 @@
 //     lane l <-> particle column j = l&31, lane half h = l>>5; accumulator register r holds hidden
 //     unit rowmap(r,h) = (r&3) + 8*(r>>2) + 4*h of that particle.
 //   * MLP layers are chained MFMAs: the layer-1 accumulator registers ARE the B operands of layer 2
-//     (k-step r <-> register r), so activations never leave registers; weights (A operands) stay
-//     resident in VGPRs for the whole solve. f32 MFMA is bit-exactly a k-ordered fmaf chain
-//     (tools/mfma_probe.hip), which is what lets the CPU oracle reproduce these kernels bit for bit.
+//     (k-step r <-> register r), so activations never leave registers. Layer-1 A operands stay in VGPRs,
+//     the W2 / W2^T A operands are read from LDS in lane order right before their MFMA chain.
+//     f32 MFMA is bit-exactly a k-ordered fmaf chain (tools/mfma_probe.hip), which is what lets the CPU
+//     oracle reproduce these kernels bit for bit. On gfx950 f32 MFMA and f32 VALU share the vector
+//     datapath (tools/mfma_valu_overlap.hip): the cost model is VALU cycles + 64 cycles per MFMA.
 //   * activations / rigid-body physics / cost run on the VALU with the explicit operation order of
 //     SPEC.md; tanh uses the batched-reciprocal form (4 values share one Newton reciprocal).
-//   * the particle x horizon tensor (x_t for every particle) is streamed to HBM in the forward sweep
-//     and read back in the adjoint sweep, layout [instance][group][t][13][32] (128-byte rows);
-//     the noise tensor uses [instance][group][t][6][32].
+//   * HBM streams, all in 128-byte rows: noise [instance][group][t][6][32]; particle x horizon tensor
+//     [instance][group][t][13][32] written by the forward sweep of a gradient evaluation and read back by
+//     the adjoint sweep; activation checkpoint [instance][group][t][1280] (layer-2 activations + 5 step
+//     scalars) so that the adjoint recomputes only layer 1. The adjoint's loads are issued one step ahead.
 //   * per-step control-dependent terms (W1u u_t + b1, rotor thrust/torques) are computed once per
 //     rollout per instance into LDS and enter the MFMA as its C operand.
-//   * reductions over particles use xor butterflies inside the 32-lane groups and a fixed slot order
-//     across waves; no atomics anywhere, results are run-to-run deterministic.
+//   * reductions over particles: v_permlane16/32_swap + DPP adds inside the 32-lane groups (bitwise equal
+//     to the xor butterflies of SPEC.md §6), fixed slot order across waves; no atomics anywhere, results are
+//     run-to-run deterministic and independent of the batch slot.
+//   * template <bool F16>: optional fp16-operand contractions on v_mfma_f32_32x32x16_f16 (SPEC.md §9).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "sdempc_kernels.h"

@@ -163,3 +163,16 @@ def test_no_cpu_fallback_compute_fails_loudly_without_gpu():
     with pytest.raises(SdempcError, match="no HIP device|failed"):
         S.rollout(W.random_initial_states(1), np.full((1, 4, 4), 0.7, np.float32), W.reference_window(0, cfg.time_steps)[None], W.make_noise(1, 2, 4))
     S.close()
+
+
+def test_entry_scripts_are_valid_python():
+    import ast
+    for name in ("bench.py", "__graft_entry__.py", "tools/prof_solve.py", "tools/summarize_profile.py", "tests/golden/make_golden.py"):
+        ast.parse(open(os.path.join(ROOT, name)).read(), filename=name)
+    import bench
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml"))
+    nbytes, nflops, b_grad, b_ls = bench.algorithmic_counts(cfg, 200, 375)
+    assert b_grad == 990364 and b_ls == 157052                      # SURVEY.md §8d formulas with n_w = 6
+    assert nflops == 3520 * 128 * 50 * (2 * 200 + 375 + 2)
+    assert bench.checkpoint_bytes(cfg, 200) == 200 * 2 * 4 * 50 * 1280 * 4
+    assert bench.effective_cores() >= 1

@@ -214,7 +214,7 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     if (cfg->max_iter < 0 || cfg->ls_maxls < 0 || cfg->max_no_improvement_iter < 1) return fail(nullptr, SDEMPC_EINVAL, "apg parameters invalid%s");
     for (int t = 0; t < cfg->horizon; ++t)
         if (!(cfg->time_steps[t] > 0.0f)) return fail(nullptr, SDEMPC_EINVAL, "time_steps must be positive%s");
-    if (smem_bytes(cfg->horizon, m) > 160 * 1024) return fail(nullptr, SDEMPC_EINVAL, "horizon too large for one workgroup's LDS (160 KiB)%s");
+    if (smem_bytes(cfg->horizon, m, team_ipb((cfg->num_particles + 31) / 32, cfg->horizon, m)) > 160 * 1024) return fail(nullptr, SDEMPC_EINVAL, "horizon too large for one workgroup's LDS (160 KiB)%s");
     sdempc_handle* h = new (std::nothrow) sdempc_handle();
     if (!h) return fail(nullptr, SDEMPC_ENOMEM, "out of memory%s");
     h->cfg = *cfg;

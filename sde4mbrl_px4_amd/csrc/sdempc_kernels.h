@@ -23,6 +23,7 @@ struct ApgK {
 };
 struct KArgs {
     int H, P, m, G;
+    int B;                     // instances in this launch (set by the launcher)
     float invP;
     ModelK M;
     CostK C;
@@ -51,7 +52,8 @@ struct KArgs {
 };
 
 constexpr int ACT_STRIDE = 1280;  // floats per (instance, group, step): h2 tile 4 chunks x 64 lanes x 4 + step scalars 32 x 8
-size_t smem_bytes(int H, int m);
+size_t smem_bytes(int H, int m, int ipb);   // ipb: instances (teams) per workgroup
+int team_ipb(int G, int H, int m);            // 4 when one wave owns an instance (G == 1 and LDS permits), else 1
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st);

@@ -48,7 +48,25 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define SCHED_PHASE() ((void)0)
 #endif
 
-constexpr int NX = 13, NN = 6, HID = 32, NT = 256, NW = 4;
+constexpr int NX = 13, NN = 6, HID = 32, BNT = 256;   // BNT: threads per workgroup (4 waves)
+
+// A "team" is the set of waves that owns one MPC instance.
+//   TeamBlock: the whole workgroup (4 waves, up to 4 particle groups in flight)           -- P > 32
+//   TeamWave : one wave per instance, 4 instances per workgroup sharing the LDS weights  -- P <= 32
+// Reduction semantics (SPEC.md §6) are identical: dot256 walks its 256 virtual lanes in 256/NT passes.
+struct TeamBlock {
+    static constexpr int NT = 256, NWAVES = 4, IPB = 1;
+    DI static int tid() { return threadIdx.x; }
+    DI static int team() { return 0; }
+    DI static void sync() { __syncthreads(); }
+};
+struct TeamWave {
+    static constexpr int NT = 64, NWAVES = 1, IPB = 4;
+    DI static int tid() { return threadIdx.x & 63; }
+    DI static int team() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }   // wave-uniform -> SGPR
+    // LDS operations of one wave execute in order; the fence keeps the compiler from moving them and drains lgkmcnt
+    DI static void sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+};
 
 // ------------------------------------------------------------------------------------------------
 // SPEC.md §3: elementary functions (bit-reproducible: only fma / mul / add / integer ops)
@@ -122,9 +140,10 @@ struct Smem {
 };
 constexpr int UST = 36;
 
-DI Smem carve(float* base, int H, int m) {
+DI Smem carve(float* base, int H, int m, int team) {
     Smem s;
     float* p = base;
+    // ---- shared by every team of the workgroup ----
     s.W3 = p; p += 6 * HID;
     s.w3n = p; p += HID;
     s.b1n = p; p += HID;
@@ -135,21 +154,24 @@ DI Smem carve(float* base, int H, int m) {
     s.A2 = p; p += HID * HID;
     s.A2T = p; p += HID * HID;
     s.A2h = p; p += 512;
-    s.ust = p; p += H * UST;
-    s.xref = p; p += ((H + 1) * NX + 3) & ~3;
-    s.SX = p; p += 4 * (H + 1) * NX;
     s.dt = p; p += (H + 3) & ~3;
     s.sdt = p; p += (H * NN + 3) & ~3;
     s.disc = p; p += (H + 1 + 3) & ~3;
+    // ---- per team ----
+    const int nv = (H * m + 3) & ~3;
+    const int per_team = H * UST + (((H + 1) * NX + 3) & ~3) + 4 * (H + 1) * NX + 16 + 6 * nv;
+    p += team * per_team;
+    s.ust = p; p += H * UST;
+    s.xref = p; p += ((H + 1) * NX + 3) & ~3;
+    s.SX = p; p += 4 * (H + 1) * NX;
     s.red = p; p += 16;
-    int nv = (H * m + 3) & ~3;
     for (int i = 0; i < 6; ++i) { s.v[i] = p; p += nv; }
     return s;
 }
-size_t smem_bytes(int H, int m) {
-    size_t f = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + 2 * HID * HID + 512 + (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 4 * (H + 1) * NX +
-               ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
-    return f * sizeof(float);
+size_t smem_bytes(int H, int m, int ipb) {
+    size_t shared = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + 2 * HID * HID + 512 + ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3);
+    size_t per_team = (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 4 * (H + 1) * NX + 16 + 6 * (size_t)((H * m + 3) & ~3);
+    return (shared + ipb * per_team) * sizeof(float);
 }
 
 // blob float payload offsets (SPEC.md §2)
@@ -166,32 +188,33 @@ DI int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
 DI int opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
 DI int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// cooperative (all BNT threads of the workgroup); caller issues __syncthreads() afterwards
 DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid) {
     const float* w = a.wts;
     const int lane = tid & 63, j = lane & 31, h = lane >> 5;
-    for (int i = tid; i < 6 * HID; i += NT) sm.W3[i] = w[OFF_W3 + i];
-    for (int i = tid; i < HID; i += NT) {
+    for (int i = tid; i < 6 * HID; i += BNT) sm.W3[i] = w[OFF_W3 + i];
+    for (int i = tid; i < HID; i += BNT) {
         sm.w3n[i] = w[OFF_W3N + i];
         sm.b1d[i] = w[OFF_B1 + i];
         sm.b1n[i] = w[OFF_B1 + HID + i];
         sm.b2[i] = w[OFF_B2 + i];
     }
-    for (int i = tid; i < NN * 2 * HID; i += NT) { int k = i / (2 * HID), r = i % (2 * HID); sm.W1zT[i] = w[OFF_W1Z + r * NN + k]; }
-    for (int i = tid; i < 8 * HID; i += NT) { int j = i / HID, r = i % HID; sm.W1uT[i] = w[OFF_W1U + r * 8 + j]; }
-    for (int i = tid; i < a.H; i += NT) sm.dt[i] = a.dt[i];
-    for (int i = tid; i < a.H * NN; i += NT) sm.sdt[i] = a.sdt[i];
-    for (int i = tid; i <= a.H; i += NT) sm.disc[i] = a.disc[i];
+    for (int i = tid; i < NN * 2 * HID; i += BNT) { int k = i / (2 * HID), r = i % (2 * HID); sm.W1zT[i] = w[OFF_W1Z + r * NN + k]; }
+    for (int i = tid; i < 8 * HID; i += BNT) { int j = i / HID, r = i % HID; sm.W1uT[i] = w[OFF_W1U + r * 8 + j]; }
+    for (int i = tid; i < a.H; i += BNT) sm.dt[i] = a.dt[i];
+    for (int i = tid; i < a.H * NN; i += BNT) sm.sdt[i] = a.sdt[i];
+    for (int i = tid; i <= a.H; i += BNT) sm.disc[i] = a.disc[i];
 #pragma unroll
     for (int s = 0; s < 3; ++s) { ww.w1d[s] = w[OFF_W1Z + j * NN + 2 * s + h]; ww.w1n[s] = w[OFF_W1Z + (HID + j) * NN + 2 * s + h]; }
     // A operand of k-step r for lane l: W2[j][rowmap(r,h)] (forward) / W2[rowmap(r,h)][j] (transpose)
-    for (int i = tid; i < HID * HID; i += NT) {
+    for (int i = tid; i < HID * HID; i += BNT) {
         int c = i & 3, l = (i >> 2) & 63, q = i >> 8, jj = l & 31, hh = l >> 5, r = 4 * q + c;
         sm.A2[i] = w[OFF_W2 + jj * HID + rowmap(r, hh)];
         sm.A2T[i] = w[OFF_W2 + rowmap(r, hh) * HID + jj];
     }
     if (a.f16) {   // weights are already fp16-representable (quantised on the host): the casts are exact
         _Float16* ah = reinterpret_cast<_Float16*>(sm.A2h);
-        for (int i = tid; i < 2 * 64 * 8; i += NT) {
+        for (int i = tid; i < 2 * 64 * 8; i += BNT) {
             int e = i & 7, l = (i >> 3) & 63, hf = i >> 9, jj = l & 31, hh = l >> 5;
             ah[i] = (_Float16)w[OFF_W2 + jj * HID + rowmap(8 * hf + e, hh)];
         }
@@ -241,15 +264,32 @@ DI float group_bfly32(float v) {
     return v;
 }
 DI float wave_bfly64(float v) { return group_bfly32(xor32_sum(v)); }
-// SPEC.md §6.2 dot256: lane chains e = tid, tid+256, ...; butterflies; ((w0+w1)+w2)+w3
+// SPEC.md §6.2 dot256: virtual lane i < 256 chains e = i, i+256, ...; butterflies inside each 64-lane virtual wave;
+// ((w0+w1)+w2)+w3. A team of NT threads walks the 256 virtual lanes in 256/NT passes.
+template <class Team, class F>
+DI float team_reduce256(const Smem& sm, int N, int tid, F&& elem) {
+    if constexpr (Team::NT == 256) {
+        float acc = 0.0f;
+        for (int e = tid; e < N; e += 256) acc = elem(e, acc);
+        acc = wave_bfly64(acc);
+        Team::sync();
+        if ((tid & 63) == 0) sm.red[tid >> 6] = acc;
+        Team::sync();
+        return ((sm.red[0] + sm.red[1]) + sm.red[2]) + sm.red[3];
+    } else {
+        float w[4];
+#pragma unroll
+        for (int vw = 0; vw < 4; ++vw) {
+            float acc = 0.0f;
+            for (int e = vw * 64 + tid; e < N; e += 256) acc = elem(e, acc);
+            w[vw] = wave_bfly64(acc);
+        }
+        return ((w[0] + w[1]) + w[2]) + w[3];
+    }
+}
+template <class Team>
 DI float block_dot(const Smem& sm, const float* x, const float* y, int N, int tid) {
-    float acc = 0.0f;
-    for (int e = tid; e < N; e += NT) acc = FMA(x[e], y ? y[e] : 1.0f, acc);
-    acc = wave_bfly64(acc);
-    __syncthreads();
-    if ((tid & 63) == 0) sm.red[tid >> 6] = acc;
-    __syncthreads();
-    return ((sm.red[0] + sm.red[1]) + sm.red[2]) + sm.red[3];
+    return team_reduce256<Team>(sm, N, tid, [&](int e, float acc) { return FMA(x[e], y ? y[e] : 1.0f, acc); });
 }
 
 // SPEC.md §5.5: control cost element and d/du pieces
@@ -284,27 +324,22 @@ DI float ucost_elem(const KArgs& a, const Smem& sm, const float* u, int e, int m
     }
     return sm.disc[t] * c;
 }
+template <class Team>
 DI float block_ucost(const KArgs& a, const Smem& sm, const float* u, int tid) {
-    int N = a.H * a.m;
-    float acc = 0.0f;
-    for (int e = tid; e < N; e += NT) acc = FMA(ucost_elem(a, sm, u, e, a.m), 1.0f, acc);
-    acc = wave_bfly64(acc);
-    __syncthreads();
-    if ((tid & 63) == 0) sm.red[tid >> 6] = acc;
-    __syncthreads();
-    return ((sm.red[0] + sm.red[1]) + sm.red[2]) + sm.red[3];
+    return team_reduce256<Team>(sm, a.H * a.m, tid, [&](int e, float acc) { return FMA(ucost_elem(a, sm, u, e, a.m), 1.0f, acc); });
 }
 
 // SPEC.md §5.1: per-step control-dependent constants into sm.ust
+template <class Team>
 DI void block_prepass(const KArgs& a, const Smem& sm, const float* u, int tid) {
     const int H = a.H, m = a.m;
-    for (int e = tid; e < H * HID; e += NT) {
+    for (int e = tid; e < H * HID; e += Team::NT) {
         int t = e >> 5, r = e & 31;
         float c = sm.b1d[r];
         for (int j = 0; j < m; ++j) c = FMA(sm.W1uT[j * HID + r], u[t * m + j], c);
         sm.ust[t * UST + r] = c;
     }
-    for (int t = tid; t < H; t += NT) {
+    for (int t = tid; t < H; t += Team::NT) {
         float Tz = 0.0f, t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
         for (int j = 0; j < m; ++j) {
             float uj = u[t * m + j];
@@ -687,26 +722,27 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
 // block-level rollout: expected cost of control sequence u (LDS). SPEC.md §5.3/§6/§7
 //   store_traj: stream x_t to a.traj; want_mean: particle mean trajectory -> xmean_out (global)
 // ------------------------------------------------------------------------------------------------
-template <bool F16>
+template <class Team, bool F16>
 DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;
-    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;   // wave index inside the team
     const bool want_mean = xmean_out != nullptr;
-    __syncthreads();
-    block_prepass(a, sm, u, tid);
+    Team::sync();
+    block_prepass<Team>(a, sm, u, tid);
     if (want_mean)
-        for (int i = tid; i < 4 * (H + 1) * NX; i += NT) sm.SX[i] = 0.0f;
-    float cu = block_ucost(a, sm, u, tid);  // contains barriers: prepass results visible afterwards
+        for (int i = tid; i < 4 * (H + 1) * NX; i += Team::NT) sm.SX[i] = 0.0f;
+    float cu = block_ucost<Team>(a, sm, u, tid);  // contains barriers: prepass results visible afterwards
     float x0r[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x0r[i] = a.x0[b * NX + i];
     float Sw = 0.0f;
-    float* xm = sm.SX + wave * (H + 1) * NX;
-    for (int g = wave; g < G; g += NW) {
+    
+    for (int g = wave; g < G; g += Team::NWAVES) {
         const bool valid = (g * 32 + j) < P;
         const float* nz = a.noise + ((size_t)(b * G + g) * H) * NN * 32 + j;
         float* tj = a.traj + ((size_t)(b * G + g) * (H + 1)) * NX * 32 + j;
+        float* xm = sm.SX + (g & 3) * (H + 1) * NX;   // reduction slot g % 4 (SPEC.md §6.1)
         float x[NX], xn[NX], xi[NN];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = x0r[i];
@@ -751,12 +787,14 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         float T = group_bfly32(valid ? J : 0.0f);
         Sw = Sw + T;
     }
-    __syncthreads();
-    if (lane == 0) sm.red[8 + wave] = Sw;
-    __syncthreads();
+    Team::sync();
+    if (tid < 4) sm.red[8 + tid] = 0.0f;
+    Team::sync();
+    if (lane == 0 && wave < G) sm.red[8 + wave] = Sw;   // wave w owns slot w (TeamBlock) / slot 0 (TeamWave, G == 1)
+    Team::sync();
     float tot = ((sm.red[8] + sm.red[9]) + sm.red[10]) + sm.red[11];
     if (want_mean) {
-        for (int i = tid; i < (H + 1) * NX; i += NT) {
+        for (int i = tid; i < (H + 1) * NX; i += Team::NT) {
             const int st = (H + 1) * NX;
             float s = ((sm.SX[i] + sm.SX[st + i]) + sm.SX[2 * st + i]) + sm.SX[3 * st + i];
             xmean_out[i] = s * a.invP;
@@ -769,27 +807,28 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 // block-level cost + gradient (forward sweep with trajectory store, adjoint sweep). SPEC.md §5.4/§6
 //   y: control sequence in LDS; gout: gradient [H*m] in LDS
 // ------------------------------------------------------------------------------------------------
-template <int M, bool F16>
+template <class Team, int M, bool F16>
 DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const float* y, float* gout, int b, int tid) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P, m = a.m;
     constexpr int nq = M + 4;
-    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
-    __syncthreads();
-    block_prepass(a, sm, y, tid);
-    for (int i = tid; i < 4 * H * 12; i += NT) sm.SX[i] = 0.0f;
-    float cu = block_ucost(a, sm, y, tid);
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;   // wave index inside the team
+    Team::sync();
+    block_prepass<Team>(a, sm, y, tid);
+    for (int i = tid; i < 4 * H * 12; i += Team::NT) sm.SX[i] = 0.0f;
+    float cu = block_ucost<Team>(a, sm, y, tid);
     float x0r[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x0r[i] = a.x0[b * NX + i];
     float Sw = 0.0f;
-    float* Sq = sm.SX + wave * H * 12;
-    for (int g = wave; g < G; g += NW) {
+    
+    for (int g = wave; g < G; g += Team::NWAVES) {
         const bool valid = (g * 32 + j) < P;
         const float* nz = a.noise + ((size_t)(b * G + g) * H) * NN * 32 + j;
         float* tj = a.traj + ((size_t)(b * G + g) * (H + 1)) * NX * 32 + j;
         float* ac = a.act + ((size_t)(b * G + g) * H) * ACT_STRIDE;
-        const bool first_group = (g == wave);
+        const bool first_group = (g < 4);
+        float* Sq = sm.SX + (g & 3) * H * 12;        // reduction slot g % 4 (SPEC.md §6.1)
         float x[NX], xn[NX], xi[NN];
         StepAux A;
         // ---- forward sweep, x_t and the hidden activations streamed to HBM ----
@@ -904,13 +943,15 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
             }
         }
     }
-    __syncthreads();
-    if (lane == 0) sm.red[8 + wave] = Sw;
-    __syncthreads();
+    Team::sync();
+    if (tid < 4) sm.red[8 + tid] = 0.0f;
+    Team::sync();
+    if (lane == 0 && wave < G) sm.red[8 + wave] = Sw;   // wave w owns slot w (TeamBlock) / slot 0 (TeamWave, G == 1)
+    Team::sync();
     float tot = ((sm.red[8] + sm.red[9]) + sm.red[10]) + sm.red[11];
     // gradient assembly (SPEC.md §6.3)
     const int N = H * m, st = H * 12;
-    for (int e = tid; e < N; e += NT) {
+    for (int e = tid; e < N; e += Team::NT) {
         int t = e / m, jj = e - t * m;
         float S[5];
         int idx[5] = {jj, M, M + 1, M + 2, M + 3};
@@ -935,120 +976,117 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         if (t + 1 < H) { float dwn = slew_dw(a, y, t + 1, jj, m, ctmp); gcu = FMA(-sm.disc[t + 1], dwn, gcu); }
         gout[e] = FMA(acc, a.invP, gcu);
     }
-    __syncthreads();
+    Team::sync();
     return FMA(tot, a.invP, cu);
 }
 
+template <class Team>
 DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
-    for (int i = tid; i < (a.H + 1) * NX; i += NT) sm.xref[i] = a.xref[(size_t)b * (a.H + 1) * NX + i];
+    for (int i = tid; i < (a.H + 1) * NX; i += Team::NT) sm.xref[i] = a.xref[(size_t)b * (a.H + 1) * NX + i];
 }
 
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-template <bool F16>
-__global__ void __launch_bounds__(NT, 2) sdempc_rollout_kernel(KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    Smem sm = carve(smem, a.H, a.m);
-    WaveW ww;
-    load_weights(a, sm, ww, tid);
-    load_common(a, sm, b, tid);
+// Common kernel prologue: carve LDS, stage weights (whole workgroup), then each team takes its instance.
+#define SDEMPC_KERNEL_PROLOGUE()                                                     \
+    extern __shared__ __attribute__((aligned(16))) float smem[];                     \
+    const int tid = Team::tid(), b = __builtin_amdgcn_readfirstlane(blockIdx.x * Team::IPB + Team::team()); \
+    Smem sm = carve(smem, a.H, a.m, Team::team());                                   \
+    WaveW ww;                                                                        \
+    load_weights(a, sm, ww, threadIdx.x);                                            \
+    __syncthreads();                                                                 \
+    if (b >= a.B) return; /* no workgroup-wide barrier below this line in TeamWave */ \
+    load_common<Team>(a, sm, b, tid);
+
+template <class Team, bool F16>
+__global__ void __launch_bounds__(BNT, 2) sdempc_rollout_kernel(KArgs a) {
+    SDEMPC_KERNEL_PROLOGUE();
     const int N = a.H * a.m;
-    for (int e = tid; e < N; e += NT) sm.v[5][e] = a.u[(size_t)b * N + e];
-    float c = block_rollout<F16>(a, sm, ww, sm.v[5], b, tid, a.store_traj != 0, a.xmean ? a.xmean + (size_t)b * (a.H + 1) * NX : nullptr);
+    for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
+    float c = block_rollout<Team, F16>(a, sm, ww, sm.v[5], b, tid, a.store_traj != 0, a.xmean ? a.xmean + (size_t)b * (a.H + 1) * NX : nullptr);
     if (tid == 0) a.cost[b] = c;
 }
 
-template <int M, bool F16>
-__global__ void __launch_bounds__(NT, 2) sdempc_grad_kernel(KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    Smem sm = carve(smem, a.H, a.m);
-    WaveW ww;
-    load_weights(a, sm, ww, tid);
-    load_common(a, sm, b, tid);
+template <class Team, int M, bool F16>
+__global__ void __launch_bounds__(BNT, 2) sdempc_grad_kernel(KArgs a) {
+    SDEMPC_KERNEL_PROLOGUE();
     const int N = a.H * a.m;
-    for (int e = tid; e < N; e += NT) sm.v[5][e] = a.u[(size_t)b * N + e];
-    float c = block_cost_grad<M, F16>(a, sm, ww, sm.v[5], sm.v[3], b, tid);
+    for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
+    float c = block_cost_grad<Team, M, F16>(a, sm, ww, sm.v[5], sm.v[3], b, tid);
     if (tid == 0) a.cost[b] = c;
-    for (int e = tid; e < N; e += NT) a.grad[(size_t)b * N + e] = sm.v[3][e];
+    for (int e = tid; e < N; e += Team::NT) a.grad[(size_t)b * N + e] = sm.v[3][e];
 }
 
 // SPEC.md §8: monotone accelerated proximal gradient with Armijo backtracking, one instance per block
-template <int M, bool F16>
-__global__ void __launch_bounds__(NT, 2) sdempc_solve_kernel(KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    Smem sm = carve(smem, a.H, a.m);
-    WaveW ww;
-    load_weights(a, sm, ww, tid);
-    load_common(a, sm, b, tid);
+template <class Team, int M, bool F16>
+__global__ void __launch_bounds__(BNT, 2) sdempc_solve_kernel(KArgs a) {
+    SDEMPC_KERNEL_PROLOGUE();
     const int m = a.m, N = a.H * m;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
-    for (int e = tid; e < N; e += NT) {
+    for (int e = tid; e < N; e += Team::NT) {
         int jj = e % m;
         float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
         xk[e] = v; yk[e] = v;
     }
-    const float c_init = block_rollout<F16>(a, sm, ww, xk, b, tid, false, nullptr);
+    const float c_init = block_rollout<Team, F16>(a, sm, ww, xk, b, tid, false, nullptr);
     float c_x = c_init, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f;
     int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1;
     for (int k = 0; k < a.A.max_iter; ++k) {
-        const float c_y = block_cost_grad<M, F16>(a, sm, ww, yk, g, b, tid);
-        gsq = block_dot(sm, g, g, N, tid);
+        const float c_y = block_cost_grad<Team, M, F16>(a, sm, ww, yk, g, b, tid);
+        gsq = block_dot<Team>(sm, g, g, N, tid);
         float c_n = 0.0f;
         int nls = 0;
         if (a.A.maxls > 0) {
             if (k > 0 && a.A.reset_inc) s = s * a.A.inc;
             if (s > a.A.smax) s = a.A.smax;
             for (int jl = 0; jl < a.A.maxls; ++jl) {
-                __syncthreads();
-                for (int e = tid; e < N; e += NT) {
+                Team::sync();
+                for (int e = tid; e < N; e += Team::NT) {
                     int jj = e % m;
                     float v = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
                     xn[e] = v; d1[e] = v - yk[e];
                 }
-                c_n = block_rollout<F16>(a, sm, ww, xn, b, tid, false, nullptr);
-                float gd = block_dot(sm, g, d1, N, tid);
+                c_n = block_rollout<Team, F16>(a, sm, ww, xn, b, tid, false, nullptr);
+                float gd = block_dot<Team>(sm, g, d1, N, tid);
                 nls = jl + 1;
                 if (c_n <= FMA(a.A.coef, gd, c_y)) break;
                 if (jl < a.A.maxls - 1) s = s * a.A.dec;
             }
         } else {
             s = a.A.stepsize;
-            __syncthreads();
-            for (int e = tid; e < N; e += NT) { int jj = e % m; xn[e] = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]); }
-            c_n = block_rollout<F16>(a, sm, ww, xn, b, tid, false, nullptr);
+            Team::sync();
+            for (int e = tid; e < N; e += Team::NT) { int jj = e % m; xn[e] = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]); }
+            c_n = block_rollout<Team, F16>(a, sm, ww, xn, b, tid, false, nullptr);
             nls = 1;
         }
         sum_ls = sum_ls + (float)nls; sum_s = sum_s + s; nit = k + 1; nls_tot += nls;
         int stop = (__builtin_fabsf(c_n - c_x) <= FMA(a.A.rtol, __builtin_fabsf(c_x), a.A.atol));
-        __syncthreads();
+        Team::sync();
         if (c_n < c_x) {
-            for (int e = tid; e < N; e += NT) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
-            float rs = block_dot(sm, d1, d2, N, tid);
+            for (int e = tid; e < N; e += Team::NT) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
+            float rs = block_dot<Team>(sm, d1, d2, N, tid);
             if (rs > 0.0f) {
                 kr = 0; plain = 1;
-                for (int e = tid; e < N; e += NT) { yk[e] = xn[e]; xk[e] = xn[e]; }
+                for (int e = tid; e < N; e += Team::NT) { yk[e] = xn[e]; xk[e] = xn[e]; }
             } else {
                 float bt = a.beta[kr];
-                for (int e = tid; e < N; e += NT) { int jj = e % m; yk[e] = clampf(FMA(bt, d2[e], xn[e]), a.C.ulo[jj], a.C.uhi[jj]); xk[e] = xn[e]; }
+                for (int e = tid; e < N; e += Team::NT) { int jj = e % m; yk[e] = clampf(FMA(bt, d2[e], xn[e]), a.C.ulo[jj], a.C.uhi[jj]); xk[e] = xn[e]; }
                 kr = kr + 1; plain = 0;
             }
             c_x = c_n; noimp = 0;
         } else {
             if (!plain) stop = 0;
             kr = 0; plain = 1;
-            for (int e = tid; e < N; e += NT) yk[e] = xk[e];
+            for (int e = tid; e < N; e += Team::NT) yk[e] = xk[e];
             noimp = noimp + 1;
         }
         if (noimp >= a.A.max_noimp) stop = 1;
         if (stop) break;
     }
-    __syncthreads();
-    for (int e = tid; e < N; e += NT) a.uopt[(size_t)b * N + e] = xk[e];
-    block_rollout<F16>(a, sm, ww, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
+    Team::sync();
+    for (int e = tid; e < N; e += Team::NT) a.uopt[(size_t)b * N + e] = xk[e];
+    block_rollout<Team, F16>(a, sm, ww, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
     if (tid == 0) {
         float* inf = a.info + (size_t)b * 8;
         const float fn = (float)nit;
@@ -1064,52 +1102,48 @@ static hipError_t set_smem_attr(const void* fn, size_t bytes) {
     if (bytes > 64 * 1024) return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     return hipSuccess;
 }
-template <bool F16>
-static hipError_t launch_rollout_t(const KArgs& a, int B, hipStream_t st, size_t sb) {
-    hipError_t e = set_smem_attr((const void*)sdempc_rollout_kernel<F16>, sb);
+// One wave per instance only when the whole instance is a single particle group AND four instances' LDS fits
+// twice per CU (keeps 2 workgroups resident); long horizons fall back to the workgroup-wide team.
+static bool use_wave_team(int G, int H, int m) { return G == 1 && smem_bytes(H, m, TeamWave::IPB) <= 80 * 1024; }
+int team_ipb(int G, int H, int m) { return use_wave_team(G, H, m) ? TeamWave::IPB : TeamBlock::IPB; }
+
+template <class Kern>
+static hipError_t launch_k(Kern k, const KArgs& a, hipStream_t st, int ipb) {
+    const size_t sb = smem_bytes(a.H, a.m, ipb);
+    hipError_t e = set_smem_attr((const void*)k, sb);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sdempc_rollout_kernel<F16>, dim3(B), dim3(NT), sb, st, a);
+    hipLaunchKernelGGL(k, dim3((a.B + ipb - 1) / ipb), dim3(BNT), sb, st, a);
     return hipGetLastError();
 }
-template <int M, bool F16>
-static hipError_t launch_grad_t(const KArgs& a, int B, hipStream_t st, size_t sb) {
-    hipError_t e = set_smem_attr((const void*)sdempc_grad_kernel<M, F16>, sb);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sdempc_grad_kernel<M, F16>), dim3(B), dim3(NT), sb, st, a);
-    return hipGetLastError();
+template <class Team>
+static hipError_t launch_rollout_team(const KArgs& a, hipStream_t st) {
+    return a.f16 ? launch_k(sdempc_rollout_kernel<Team, true>, a, st, Team::IPB) : launch_k(sdempc_rollout_kernel<Team, false>, a, st, Team::IPB);
 }
-template <int M, bool F16>
-static hipError_t launch_solve_t(const KArgs& a, int B, hipStream_t st, size_t sb) {
-    hipError_t e = set_smem_attr((const void*)sdempc_solve_kernel<M, F16>, sb);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sdempc_solve_kernel<M, F16>), dim3(B), dim3(NT), sb, st, a);
-    return hipGetLastError();
+template <class Team, bool F16>
+static hipError_t launch_grad_team(const KArgs& a, hipStream_t st) {
+    if (a.m == 4) return launch_k(sdempc_grad_kernel<Team, 4, F16>, a, st, Team::IPB);
+    if (a.m == 6) return launch_k(sdempc_grad_kernel<Team, 6, F16>, a, st, Team::IPB);
+    return launch_k(sdempc_grad_kernel<Team, 8, F16>, a, st, Team::IPB);
+}
+template <class Team, bool F16>
+static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
+    if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16>, a, st, Team::IPB);
+    if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, F16>, a, st, Team::IPB);
+    return launch_k(sdempc_solve_kernel<Team, 8, F16>, a, st, Team::IPB);
 }
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) {
-    size_t sb = smem_bytes(a.H, a.m);
-    return a.f16 ? launch_rollout_t<true>(a, B, st, sb) : launch_rollout_t<false>(a, B, st, sb);
+    KArgs k = a; k.B = B;
+    return use_wave_team(k.G, k.H, k.m) ? launch_rollout_team<TeamWave>(k, st) : launch_rollout_team<TeamBlock>(k, st);
 }
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st) {
-    size_t sb = smem_bytes(a.H, a.m);
-    if (a.f16) {
-        if (a.m == 4) return launch_grad_t<4, true>(a, B, st, sb);
-        if (a.m == 6) return launch_grad_t<6, true>(a, B, st, sb);
-        return launch_grad_t<8, true>(a, B, st, sb);
-    }
-    if (a.m == 4) return launch_grad_t<4, false>(a, B, st, sb);
-    if (a.m == 6) return launch_grad_t<6, false>(a, B, st, sb);
-    return launch_grad_t<8, false>(a, B, st, sb);
+    KArgs k = a; k.B = B;
+    if (use_wave_team(k.G, k.H, k.m)) return k.f16 ? launch_grad_team<TeamWave, true>(k, st) : launch_grad_team<TeamWave, false>(k, st);
+    return k.f16 ? launch_grad_team<TeamBlock, true>(k, st) : launch_grad_team<TeamBlock, false>(k, st);
 }
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st) {
-    size_t sb = smem_bytes(a.H, a.m);
-    if (a.f16) {
-        if (a.m == 4) return launch_solve_t<4, true>(a, B, st, sb);
-        if (a.m == 6) return launch_solve_t<6, true>(a, B, st, sb);
-        return launch_solve_t<8, true>(a, B, st, sb);
-    }
-    if (a.m == 4) return launch_solve_t<4, false>(a, B, st, sb);
-    if (a.m == 6) return launch_solve_t<6, false>(a, B, st, sb);
-    return launch_solve_t<8, false>(a, B, st, sb);
+    KArgs k = a; k.B = B;
+    if (use_wave_team(k.G, k.H, k.m)) return k.f16 ? launch_solve_team<TeamWave, true>(k, st) : launch_solve_team<TeamWave, false>(k, st);
+    return k.f16 ? launch_solve_team<TeamBlock, true>(k, st) : launch_solve_team<TeamBlock, false>(k, st);
 }
 
 }  // namespace sdempc

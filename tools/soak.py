@@ -1,0 +1,42 @@
+"""Randomised soak: GPU (C ABI) vs CPU oracle, bit for bit, over many random configurations."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from sde4mbrl_px4_amd import MPCConfig, synthetic_multirotor, workload as W
+from sde4mbrl_px4_amd.solver import SdeMpcSolver
+import orc
+from cases import bits_differ
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = 0; t0 = time.time()
+for it in range(n):
+    rng = np.random.default_rng(seed0 + it)
+    m = int(rng.integers(1, 9)); H = int(rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 55, 70])); P = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 65, 100, 128, 130, 257]))
+    kw = dict(horizon=H, num_short_dt=int(rng.integers(0, H + 1)), short_step_dt=float(rng.choice([0.01, 0.05])), long_step_dt=float(rng.choice([0.05, 0.1])),
+              num_particles=P, discount=float(rng.choice([1.0, 0.95])), input_id=list(range(m)), input_bound=[[1e-4, 1.0]] * m, uref=[float(rng.uniform(0.3, 0.8))] * m,
+              uerr=float(rng.uniform(0, 2)), perr=list(rng.uniform(0, 200, 3)), verr=list(rng.uniform(0, 10, 3)), qerr=list(rng.uniform(0, 100, 3)), werr=list(rng.uniform(0, 3, 3)),
+              res_mult=float(rng.choice([0.0, 0.01, 0.5])), u_slew_coeff=float(rng.choice([0.0, 1.0])), max_iter=int(rng.integers(0, 7)), max_no_improvement_iter=int(rng.integers(1, 7)),
+              beta_init=float(rng.uniform(0, 0.9)), rtol=float(rng.choice([1e-6, 1e-3])), ls_init_stepsize=float(rng.choice([0.01, 1e-4])),
+              ls_max_stepsize=float(rng.choice([1.0, 1e-3])), ls_coef=float(rng.choice([0.01, 0.3])), ls_decrease_factor=float(rng.uniform(0.2, 0.9)),
+              ls_increase_factor=float(rng.uniform(1.0, 3.0)), ls_maxls=int(rng.integers(0, 6)), stepsize=1e-4, ls_reset_option=str(rng.choice(["increase", "conservative"])),
+              enforce_ubound=bool(rng.random() < 0.85))
+    if rng.random() < 0.4: kw.update(u_slew_constr=[[-float(rng.uniform(0.01, 0.1)), float(rng.uniform(0.01, 0.1))]] * m, u_slew_constr_coeff=float(rng.uniform(1, 20)))
+    if rng.random() < 0.3: kw.update(moment_scale=float(rng.uniform(0.1, 1.0)))
+    cfg = MPCConfig(**kw); model = synthetic_multirotor(m, seed=it)
+    B = int(rng.integers(1, 6))
+    x0 = W.random_initial_states(B, 1000 + it); xref = np.stack([W.reference_window(0.2 * b, cfg.time_steps) for b in range(B)]); noise = W.make_noise(B, P, H, it)
+    u = np.clip(np.asarray(cfg.uref, np.float32) + 0.15 * rng.standard_normal((B, H, m)), 1e-4, 1).astype(np.float32)
+    S = SdeMpcSolver(cfg, model, max_batch=B); O = orc.Oracle(cfg, model)
+    cost, traj, xm = S.rollout(x0, u, xref, noise, True, True); gc, g = S.grad(x0, u, xref, noise)
+    uopt, xe, info = S.solve(x0, xref, noise, u, np.full(B, cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize, np.float32))
+    nb = 0
+    for b in range(B):
+        c, t, mm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True); c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
+        uo, xo, io, _ = O.solve(x0[b], xref[b], noise[b], u[b], float(cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize))
+        nb += (cost[b] != np.float32(c)) + bits_differ(traj[b], t) + bits_differ(xm[b], mm) + (gc[b] != np.float32(c2)) + bits_differ(g[b], g2.astype(np.float32)) \
+              + bits_differ(uopt[b], uo) + bits_differ(xe[b], xo) + bits_differ(info[b], io)
+    if nb: print(f"MISMATCH case {seed0+it}: m={m} H={H} P={P} B={B} words={nb} cfg={kw}"); bad += 1
+    S.close()
+print(f"soak: {n} configurations, {bad} with mismatches, {time.time()-t0:.1f} s")
+sys.exit(1 if bad else 0)

@@ -666,7 +666,8 @@ static real cost_grad(const ctx_t* X, const real* x0, const real* u, const real*
 /* = m_mpc (sde_control.py:713-719,400-416); knobs apg_mpc: launch/iris_sitl_traj_mpc.yaml:55-85; */
 /* telemetry read at sde_control.py:444-450                                                    */
 /* ------------------------------------------------------------------------------------------- */
-static inline real clampr(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* SPEC.md §3.6: median of three = fmin(fmax(v,lo),hi); a NaN maps to lo and -0 to +0 when lo = +0, as v_med3_f32 does */
+static inline real clampr(real v, real lo, real hi) { return !(v > lo) ? lo : (v > hi ? hi : v); }
 
 static void solve(const ctx_t* X, const real* x0, const real* xref, const real* noise,
                   const real* u_init, real s_in, real* uopt, real* xevol, real* info, real* trace, int trace_cap) {
@@ -689,6 +690,7 @@ static void solve(const ctx_t* X, const real* x0, const real* xref, const real* 
     for (int k = 0; k < C->max_iter; ++k) {
         real c_y = cost_grad(X, x0, yk, xref, noise, g);
         gsq = dot256(g, g, N);
+        if (!(gsq < (real)INFINITY)) break; /* SPEC.md §8 non-finite guard: no step is taken on a NaN/inf gradient */
         real c_n = 0;
         int nls = 0;
         if (C->ls_maxls > 0) {

@@ -1035,6 +1035,7 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_solve_kernel(KArgs a) {
     for (int k = 0; k < a.A.max_iter; ++k) {
         const float c_y = block_cost_grad<Team, M, F16>(a, sm, ww, yk, g, b, tid);
         gsq = block_dot<Team>(sm, g, g, N, tid);
+        if (!(gsq < __builtin_inff())) break;   // SPEC.md §8 non-finite guard (team-uniform): keep xk, report gsq
         float c_n = 0.0f;
         int nls = 0;
         if (a.A.maxls > 0) {

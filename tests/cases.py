@@ -3,7 +3,8 @@ import os
 
 import numpy as np
 
-from sde4mbrl_px4_amd import load_mpc_config, synthetic_hexa, synthetic_iris
+from sde4mbrl_px4_amd import MPCConfig, load_mpc_config, synthetic_hexa, synthetic_iris, synthetic_multirotor
+from sde4mbrl_px4_amd import workload as W
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CDIR = os.path.join(ROOT, "configs")
@@ -31,7 +32,30 @@ def load_golden(name):
 
 
 def bits_differ(a, b):
-    a = np.ascontiguousarray(a, np.float32).view(np.uint32)
-    b = np.ascontiguousarray(b, np.float32).view(np.uint32)
-    assert a.shape == b.shape, (a.shape, b.shape)
-    return int((a != b).sum())
+    """Number of f32 words whose bit patterns differ. NaNs are compared as a class (a NaN must sit at the
+    same position on both sides, but its sign/payload is not specified: x86 SSE produces 0xFFC00000, gfx950
+    0x7FC00000 for the same invalid operation — SPEC.md §3); everything else, including the sign of zero and
+    infinities, is compared bit for bit."""
+    fa = np.ascontiguousarray(a, np.float32)
+    fb = np.ascontiguousarray(b, np.float32)
+    assert fa.shape == fb.shape, (fa.shape, fb.shape)
+    both_nan = np.isnan(fa) & np.isnan(fb)
+    return int(((fa.view(np.uint32) != fb.view(np.uint32)) & ~both_nan).sum())
+
+
+def diverging_single_rotor_case(P=32):
+    """A single-rotor vehicle over a 55-step horizon: it tumbles and the explicit-Euler state overflows f32 around t = 53 — cost NaN
+    (instance 0) / +inf (instance 1) and a NaN gradient (found by tools/soak.py, case 5495); instance 2 repeats instance 0 at low
+    throttle, which stays finite. Exercises SPEC.md §3.7 and the §8 non-finite guard in a mixed batch."""
+    B = 2
+    m, H, it = 1, 55, 495
+    cfg = MPCConfig(horizon=H, num_short_dt=6, short_step_dt=0.05, long_step_dt=0.1, num_particles=P, input_id=[0], input_bound=[[1e-4, 1.0]],
+                    uref=[0.55], u_slew_coeff=1.0, max_iter=3, max_no_improvement_iter=6, ls_maxls=5)
+    model = synthetic_multirotor(m, seed=it)
+    x0 = W.random_initial_states(B, 1000 + it)
+    xref = np.stack([W.reference_window(0.2 * b, cfg.time_steps) for b in range(B)])
+    noise = W.make_noise(B, P, H, it)
+    u = np.clip(0.55 + 0.15 * np.random.default_rng(it).standard_normal((B, H, m)), 1e-4, 1).astype(np.float32)
+    x0, xref, noise = (np.concatenate([a, a[:1]]) for a in (x0, xref, noise))
+    u = np.concatenate([u, np.full_like(u[:1], 0.02)])
+    return cfg, model, x0, xref, noise, u

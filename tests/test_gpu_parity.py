@@ -164,6 +164,32 @@ def test_generic_motor_count_bit_exact(m):
     S.close()
 
 
+@pytest.mark.parametrize("P", [32, 100])
+def test_diverging_rollout_non_finite_parity(P):
+    """A rollout that overflows f32 (single-rotor vehicle, H=55): infinities and NaN positions agree with the oracle word for word,
+    the solve takes no step on a NaN gradient (SPEC.md §8 guard) and the finite instance beside it is unaffected. P=32 runs the
+    one-wave team, P=100 the four-wave team. Found by tools/soak.py."""
+    from cases import diverging_single_rotor_case
+    cfg, model, x0, xref, noise, u = diverging_single_rotor_case(P=P)
+    B = len(x0)
+    un = u.copy(); un[2, 3, 0] = np.nan                          # NaN in a warm start is projected to the lower bound
+    S, O = _solver(cfg, model, B), orc.Oracle(cfg, model)
+    cost, traj, xm = S.rollout(x0, u, xref, noise, True, True)
+    gc, grad = S.grad(x0, u, xref, noise)
+    uopt, xevol, info = S.solve(x0, xref, noise, un, np.full(B, 0.01, np.float32))
+    assert np.isinf(gc[1]) and np.isnan(grad[1]).sum() >= 50
+    for b in range(B):
+        c, t, mm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True)
+        c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
+        uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], un[b], 0.01)
+        assert bits_differ(cost[b], c) == 0 and bits_differ(traj[b], t) == 0 and bits_differ(xm[b], mm) == 0
+        assert bits_differ(gc[b], c2) == 0 and bits_differ(grad[b], g2.astype(np.float32)) == 0
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], inf) == 0
+    assert np.array_equal(uopt[1], u[1]) and info[1][2] == 0 and not np.isfinite(info[1][3])
+    assert info[2][2] >= 1 and np.isfinite(uopt[2]).all() and np.isfinite(xevol[2]).all()
+    S.close()
+
+
 def test_saturating_activations_and_violent_states_bit_exact():
     """Weights scaled up so that tanh / sigmoid arguments exceed their clamp ranges (|x| > 9, > 30), fast tumbling initial
     states and strong diffusion: exercises the clamped branches of SPEC.md §3 and large-magnitude arithmetic."""

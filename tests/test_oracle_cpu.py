@@ -139,6 +139,26 @@ def test_zero_iterations_returns_projected_warm_start():
     assert info[2] == 0 and info[5] == info[6]
 
 
+def test_non_finite_gradient_terminates_without_a_step():
+    """SPEC.md §8 guard: +inf cost / NaN gradient -> the solve returns the projected warm start, num_steps = 0, grad_sqr non-finite;
+    a NaN in the warm start is projected to the lower bound (SPEC.md §3.6)."""
+    from cases import diverging_single_rotor_case
+    cfg, model, x0, xref, noise, u = diverging_single_rotor_case()
+    O = orc.Oracle(cfg, model)
+    c, g = O.grad(x0[1], u[1], xref[1], noise[1])
+    assert np.isinf(c) and np.isnan(g).sum() >= 50
+    uopt, xevol, info, _ = O.solve(x0[1], xref[1], noise[1], u[1], 0.01)
+    np.testing.assert_array_equal(uopt, u[1])
+    assert info[2] == 0 and not np.isfinite(info[3]) and np.isinf(info[5]) and np.isinf(info[6]) and info[7] == 0
+    # the well-behaved instance next to it still iterates
+    _, _, info2, _ = O.solve(x0[2], xref[2], noise[2], u[2], 0.01)
+    assert info2[2] >= 1 and np.isfinite(info2[3])
+    un = u[2].copy(); un[3, 0] = np.nan
+    cfg0 = cfg.replace(max_iter=0)
+    uo, _, _, _ = orc.Oracle(cfg0, model).solve(x0[2], xref[2], noise[2], un, 0.01)
+    assert uo[3, 0] == np.float32(1e-4) and np.array_equal(np.delete(uo, 3, 0), np.delete(u[2], 3, 0))
+
+
 def test_f16_rtz_quantiser_matches_numpy_semantics():
     L = orc.lib()
     L.orc_f16_rtz_value.argtypes, L.orc_f16_rtz_value.restype = [C.c_double], C.c_double

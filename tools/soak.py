@@ -9,7 +9,7 @@ import orc
 from cases import bits_differ
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-bad = 0; t0 = time.time()
+bad = 0; nonfinite = 0; t0 = time.time()
 for it in range(n):
     rng = np.random.default_rng(seed0 + it)
     m = int(rng.integers(1, 9)); H = int(rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 55, 70])); P = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 65, 100, 128, 130, 257]))
@@ -30,13 +30,13 @@ for it in range(n):
     S = SdeMpcSolver(cfg, model, max_batch=B); O = orc.Oracle(cfg, model)
     cost, traj, xm = S.rollout(x0, u, xref, noise, True, True); gc, g = S.grad(x0, u, xref, noise)
     uopt, xe, info = S.solve(x0, xref, noise, u, np.full(B, cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize, np.float32))
-    nb = 0
+    nb = 0; nonfinite += int(not (np.isfinite(traj).all() and np.isfinite(g).all()))
     for b in range(B):
         c, t, mm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True); c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
         uo, xo, io, _ = O.solve(x0[b], xref[b], noise[b], u[b], float(cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize))
-        nb += (cost[b] != np.float32(c)) + bits_differ(traj[b], t) + bits_differ(xm[b], mm) + (gc[b] != np.float32(c2)) + bits_differ(g[b], g2.astype(np.float32)) \
+        nb += bits_differ(cost[b], c) + bits_differ(traj[b], t) + bits_differ(xm[b], mm) + bits_differ(gc[b], c2) + bits_differ(g[b], g2.astype(np.float32)) \
               + bits_differ(uopt[b], uo) + bits_differ(xe[b], xo) + bits_differ(info[b], io)
     if nb: print(f"MISMATCH case {seed0+it}: m={m} H={H} P={P} B={B} words={nb} cfg={kw}"); bad += 1
     S.close()
-print(f"soak: {n} configurations, {bad} with mismatches, {time.time()-t0:.1f} s")
+print(f"soak: {n} configurations ({nonfinite} with non-finite trajectories), {bad} with mismatches, {time.time()-t0:.1f} s")
 sys.exit(1 if bad else 0)

@@ -143,6 +143,14 @@ int sdempc_solve_batch(sdempc_handle* h, int32_t B, const float* x0, const float
 size_t sdempc_noise_dev_floats(const sdempc_handle* h, int32_t B);
 size_t sdempc_traj_dev_floats(const sdempc_handle* h, int32_t B);
 int sdempc_noise_to_device_layout(const sdempc_handle* h, int32_t B, const float* noise_host, float* out_host);
+/* The same conversion on the device: canonical f32[B][P][H][6] at noise_canonical_dev -> device layout at
+ * noise_out_dev (sdempc_noise_dev_floats(h, B) floats; padded particles are written as zeros). */
+int sdempc_noise_to_device_layout_dev(sdempc_handle* h, int32_t B, const void* noise_canonical_dev,
+                                      void* noise_out_dev, void* stream);
+/* Copies the particle x horizon tensor that the last sdempc_rollout_batch_dev(store_traj=1)
+ * or sdempc_grad_batch_dev of the first B instances left in the handle to traj_out_dev as canonical
+ * f32[B][P][H+1][13]. Enqueue it on the stream of that call. */
+int sdempc_traj_to_canonical_dev(sdempc_handle* h, int32_t B, void* traj_out_dev, void* stream);
 int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* xref_dev,
                            const void* noise_dev, const void* u_init_dev, const void* stepsize_dev,
                            void* uopt_dev, void* xevol_dev, void* info_dev /*f32[B][8]*/,

@@ -94,6 +94,8 @@ def load_library():
     lib.sdempc_traj_dev_floats.argtypes = [vp, i32]
     lib.sdempc_traj_dev_floats.restype = C.c_size_t
     lib.sdempc_noise_to_device_layout.argtypes = [vp, i32, fp, fp]
+    lib.sdempc_noise_to_device_layout_dev.argtypes = [vp, i32, vp, vp, vp]
+    lib.sdempc_traj_to_canonical_dev.argtypes = [vp, i32, vp, vp]
     lib.sdempc_solve_batch_dev.argtypes = [vp, i32] + [vp] * 9
     lib.sdempc_rollout_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.sdempc_grad_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
@@ -101,7 +103,7 @@ def load_library():
     lib.sdempc_last_kernel_ms.restype = C.c_float
     for name in ("sdempc_set_device", "sdempc_reset", "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch",
                  "sdempc_noise_to_device_layout", "sdempc_solve_batch_dev", "sdempc_rollout_batch_dev",
-                 "sdempc_grad_batch_dev"):
+                 "sdempc_grad_batch_dev", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev"):
         getattr(lib, name).restype = C.c_int
     _LIB = lib
     return lib
@@ -111,5 +113,5 @@ EXPORTED_SYMBOLS = [
     "sdempc_create", "sdempc_destroy", "sdempc_last_error", "sdempc_abi_version", "sdempc_set_device", "sdempc_reset",
     "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch", "sdempc_noise_dev_floats",
     "sdempc_traj_dev_floats", "sdempc_noise_to_device_layout", "sdempc_solve_batch_dev", "sdempc_rollout_batch_dev",
-    "sdempc_grad_batch_dev", "sdempc_last_kernel_ms",
+    "sdempc_grad_batch_dev", "sdempc_last_kernel_ms", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev",
 ]

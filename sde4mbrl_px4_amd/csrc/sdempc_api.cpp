@@ -60,10 +60,11 @@ struct sdempc_handle {
     DevBuf d_dt, d_sdt, d_disc, d_beta, d_wts;
     // workspace + staging (sized for max_batch)
     DevBuf d_act, d_traj, d_x0, d_u, d_xref, d_noise, d_step, d_cost, d_grad, d_xmean, d_uopt, d_info;
+    // canonical-layout staging of the host-pointer entry points (allocated on their first use)
+    DevBuf d_noise_canon, d_traj_canon;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    std::vector<float> h_noise_stage, h_traj_stage;
 };
 
 namespace {
@@ -171,12 +172,14 @@ void noise_to_dev_layout(const sdempc_handle* h, int B, const float* in, float* 
 
 int stage_common(sdempc_handle* h, int B, const float* x0, const float* u, const float* xref, const float* noise) {
     const int H = h->H, m = h->m;
+    int rc;
+    if (!h->d_noise_canon.p && (rc = dev_alloc(h, h->d_noise_canon, sizeof(float) * (size_t)h->max_batch * h->P * H * SDEMPC_NNOISE))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_x0.p, x0, sizeof(float) * B * SDEMPC_NX, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_u.p, u, sizeof(float) * B * H * m, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_xref.p, xref, sizeof(float) * B * (H + 1) * SDEMPC_NX, hipMemcpyHostToDevice, h->stream));
-    h->h_noise_stage.resize(noise_floats(h, B));
-    noise_to_dev_layout(h, B, noise, h->h_noise_stage.data());
-    HIPCHK(h, hipMemcpyAsync(h->d_noise.p, h->h_noise_stage.data(), sizeof(float) * noise_floats(h, B), hipMemcpyHostToDevice, h->stream));
+    // the caller's canonical [B][P][H][6] tensor goes up as it is; the particle-minor layout is made on the device
+    HIPCHK(h, hipMemcpyAsync(h->d_noise_canon.p, noise, sizeof(float) * (size_t)B * h->P * H * SDEMPC_NNOISE, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, launch_relayout(true, (const float*)h->d_noise_canon.p, (float*)h->d_noise.p, B, h->P, h->G, H * SDEMPC_NNOISE, h->stream));
     return 0;
 }
 
@@ -277,7 +280,7 @@ void sdempc_destroy(sdempc_handle* h) {
     if (!h) return;
     if (h->dev_ready) {
         (void)hipSetDevice(h->device);
-        for (DevBuf* b : {&h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise,
+        for (DevBuf* b : {&h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon,
                           &h->d_step, &h->d_cost, &h->d_grad, &h->d_xmean, &h->d_uopt, &h->d_info})
             dev_free(*b);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -311,6 +314,26 @@ size_t sdempc_traj_dev_floats(const sdempc_handle* h, int32_t B) { return h ? tr
 int sdempc_noise_to_device_layout(const sdempc_handle* h, int32_t B, const float* noise_host, float* out_host) {
     if (!h || !noise_host || !out_host || B < 1) return SDEMPC_EINVAL;
     noise_to_dev_layout(h, B, noise_host, out_host);
+    return SDEMPC_OK;
+}
+
+int sdempc_noise_to_device_layout_dev(sdempc_handle* h, int32_t B, const void* noise_canonical_dev, void* noise_out_dev, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!noise_canonical_dev || !noise_out_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    HIPCHK(h, launch_relayout(true, (const float*)noise_canonical_dev, (float*)noise_out_dev, B, h->P, h->G, h->H * SDEMPC_NNOISE, st));
+    return SDEMPC_OK;
+}
+
+int sdempc_traj_to_canonical_dev(sdempc_handle* h, int32_t B, void* traj_out_dev, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!traj_out_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    HIPCHK(h, launch_relayout(false, (const float*)h->d_traj.p, (float*)traj_out_dev, B, h->P, h->G, (h->H + 1) * SDEMPC_NX, st));
     return SDEMPC_OK;
 }
 
@@ -371,22 +394,16 @@ int sdempc_rollout_batch(sdempc_handle* h, int32_t B, const float* x0, const flo
     if ((rc = stage_common(h, B, x0, u, xref, noise))) return rc;
     rc = sdempc_rollout_batch_dev(h, B, h->d_x0.p, h->d_u.p, h->d_xref.p, h->d_noise.p, h->d_cost.p, xmean ? h->d_xmean.p : nullptr, traj ? 1 : 0, h->stream);
     if (rc) return rc;
-    const int H = h->H, P = h->P, G = h->G;
+    const int H = h->H, P = h->P;
     HIPCHK(h, hipMemcpyAsync(cost, h->d_cost.p, sizeof(float) * B, hipMemcpyDeviceToHost, h->stream));
     if (xmean) HIPCHK(h, hipMemcpyAsync(xmean, h->d_xmean.p, sizeof(float) * B * (H + 1) * SDEMPC_NX, hipMemcpyDeviceToHost, h->stream));
     if (traj) {
-        h->h_traj_stage.resize(traj_floats(h, B));
-        HIPCHK(h, hipMemcpyAsync(h->h_traj_stage.data(), h->d_traj.p, sizeof(float) * traj_floats(h, B), hipMemcpyDeviceToHost, h->stream));
+        const size_t nf = (size_t)P * (H + 1) * SDEMPC_NX;
+        if (!h->d_traj_canon.p && (rc = dev_alloc(h, h->d_traj_canon, sizeof(float) * h->max_batch * nf))) return rc;
+        if ((rc = sdempc_traj_to_canonical_dev(h, B, h->d_traj_canon.p, h->stream))) return rc;
+        HIPCHK(h, hipMemcpyAsync(traj, h->d_traj_canon.p, sizeof(float) * B * nf, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (traj) {
-        const float* s = h->h_traj_stage.data();
-        for (int b = 0; b < B; ++b)
-            for (int p = 0; p < P; ++p)
-                for (int t = 0; t <= H; ++t)
-                    for (int i = 0; i < SDEMPC_NX; ++i)
-                        traj[(((size_t)b * P + p) * (H + 1) + t) * SDEMPC_NX + i] = s[((((size_t)b * G + p / 32) * (H + 1) + t) * SDEMPC_NX + i) * 32 + p % 32];
-    }
     return SDEMPC_OK;
 }
 

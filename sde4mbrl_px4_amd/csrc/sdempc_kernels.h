@@ -57,5 +57,7 @@ int team_ipb(int G, int H, int m);            // 4 when one wave owns an instanc
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st);
+// canonical [B][P][C] <-> device [B][G][C][32] (to_dev: zero-pads particles >= P)
+hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int P, int G, int C, hipStream_t st);
 
 }  // namespace sdempc

@@ -1147,4 +1147,49 @@ hipError_t launch_solve(const KArgs& a, int B, hipStream_t st) {
     return k.f16 ? launch_solve_team<TeamBlock, true>(k, st) : launch_solve_team<TeamBlock, false>(k, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// layout conversion between the canonical tensors of include/sdempc.h ([B][P][C], C = H*6 for the noise,
+// (H+1)*13 for the particle x horizon tensor) and the particle-minor device layout [B][G][C][32] the
+// kernels stream. HBM-bound transpose through a 32x33 LDS tile: both sides coalesced.
+// Padded particles (p >= P) are written as zeros on the way in and skipped on the way out.
+// ------------------------------------------------------------------------------------------------
+template <bool TO_DEV>
+__global__ void __launch_bounds__(256) sdempc_relayout_kernel(const float* __restrict__ in, float* __restrict__ out, int P, int G, int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, g = blockIdx.y, b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (TO_DEV) {
+        for (int r = ty; r < 32; r += 8) {                      // tile[particle][column]
+            const int p = g * 32 + r, c = c0 + tx;
+            tile[r][tx] = (p < P && c < C) ? in[((size_t)b * P + p) * C + c] : 0.0f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r;
+            if (c < C) out[(((size_t)b * G + g) * C + c) * 32 + tx] = tile[tx][r];
+        }
+    } else {
+        for (int r = ty; r < 32; r += 8) {                      // tile[column][particle]
+            const int c = c0 + r;
+            tile[r][tx] = c < C ? in[(((size_t)b * G + g) * C + c) * 32 + tx] : 0.0f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int p = g * 32 + r, c = c0 + tx;
+            if (p < P && c < C) out[((size_t)b * P + p) * C + c] = tile[tx][r];
+        }
+    }
+}
+hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int P, int G, int C, hipStream_t st) {
+    if (B < 1 || G < 1 || G > 65535 || C < 1 || P < 1 || P > G * 32) return hipErrorInvalidValue;
+    const size_t canon = (size_t)P * C, dev = (size_t)G * C * 32;       // floats per instance on either side
+    for (int b0 = 0; b0 < B; b0 += 65535) {                             // gridDim.z limit
+        const int nb = B - b0 < 65535 ? B - b0 : 65535;
+        dim3 grid((C + 31) / 32, G, nb);
+        if (to_dev) sdempc_relayout_kernel<true><<<grid, 256, 0, st>>>(in + b0 * canon, out + b0 * dev, P, G, C);
+        else sdempc_relayout_kernel<false><<<grid, 256, 0, st>>>(in + b0 * dev, out + b0 * canon, P, G, C);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace sdempc

@@ -117,6 +117,14 @@ class SdeMpcSolver:
         self._check(self.lib.sdempc_noise_to_device_layout(self._h, B, _fp(noise), _fp(out)))
         return out.reshape(B, (self.P + 31) // 32, self.H, 6, 32)
 
+    def noise_to_device_layout_dev(self, B, noise_canonical, noise_out, stream=0):
+        """Device pointers: canonical f32[B][P][H][6] -> f32[B][G][H][6][32] (LDS-tiled transpose on the GPU)."""
+        self._check(self.lib.sdempc_noise_to_device_layout_dev(self._h, B, noise_canonical, noise_out, C.c_void_p(stream)))
+
+    def traj_to_canonical_dev(self, B, traj_out, stream=0):
+        """Particle x horizon tensor of the last rollout_dev(store_traj=True) / grad_dev -> canonical f32[B][P][H+1][13]."""
+        self._check(self.lib.sdempc_traj_to_canonical_dev(self._h, B, traj_out, C.c_void_p(stream)))
+
     def solve_dev(self, B, x0, xref, noise_dev, u_init, stepsize, uopt, xevol, info, stream=0):
         """All arguments are device pointers (ints). info: f32[B][8]."""
         self._check(self.lib.sdempc_solve_batch_dev(self._h, B, x0, xref, noise_dev, u_init, stepsize, uopt, xevol, info,

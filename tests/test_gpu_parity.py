@@ -326,6 +326,19 @@ def test_device_resident_api_equals_host_api():
     torch.cuda.synchronize()
     assert S.last_kernel_ms() > 0
     assert bits_differ(uopt.cpu().numpy(), ref[0]) == 0 and bits_differ(xevol.cpu().numpy(), ref[1]) == 0 and bits_differ(info.cpu().numpy(), ref[2]) == 0
+    # layout conversion on the device == the host conversion; ragged P (40 = 32 + 8): padded lanes are zeros
+    st = torch.cuda.current_stream().cuda_stream
+    nd2 = torch.full_like(nd, 7.0)
+    S.noise_to_device_layout_dev(B, t(noise).data_ptr(), nd2.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(nd, nd2)
+    # particle x horizon tensor through the device API, canonical layout
+    tu = t(u); cost = torch.empty(B, device=dev); traj = torch.empty((B, 40, 11, 13), device=dev)
+    S.rollout_dev(B, tx0.data_ptr(), tu.data_ptr(), txr.data_ptr(), nd.data_ptr(), cost.data_ptr(), None, True, st)
+    S.traj_to_canonical_dev(B, traj.data_ptr(), st)
+    torch.cuda.synchronize()
+    c_ref, traj_ref, _ = S.rollout(x0, u, xref, noise, True, True)
+    assert bits_differ(cost.cpu().numpy(), c_ref) == 0 and bits_differ(traj.cpu().numpy(), traj_ref) == 0
     S.close()
 
 

@@ -134,15 +134,18 @@ def main():
     seed0 = rank * B
     x0_h = W.random_initial_states(B, seed0)
     xref_h = np.stack([W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(B)])
-    rng = np.random.default_rng(12345 + rank)
+    # noise: drawn on the device from per-instance threefry keys (SPEC.md §7; the m_mpc path), launch seed 10
+    # (iris_sdectrl.launch:8) split into one key per instance of the whole job
+    from sde4mbrl_px4_amd import prng
+    keys = prng.split(prng.PRNGKey(10), world * B)[rank * B:(rank + 1) * B]
     nd = solver.lib.sdempc_noise_dev_floats(solver._h, B)
-    noise_dev_h = rng.standard_normal(nd, dtype=np.float32)  # generated directly in the device layout
     yk, info0 = solver.reset()
     u0_h = np.tile(yk[None], (B, 1, 1))
     s0 = float(info0["stepsize"])
     x0 = torch.from_numpy(x0_h).to(dev)
     xref = torch.from_numpy(xref_h).to(dev)
-    noise = torch.from_numpy(noise_dev_h).to(dev)
+    noise = torch.empty(nd, dtype=torch.float32, device=dev)
+    solver.noise_from_keys_dev(keys, noise.data_ptr(), torch.cuda.current_stream().cuda_stream)
     u0 = torch.from_numpy(u0_h).to(dev)
     step_in = torch.full((B,), s0, dtype=torch.float32, device=dev)
     uopt = torch.empty((B, H, m), dtype=torch.float32, device=dev)
@@ -212,7 +215,7 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.mlp_dtype == "f32" else "f16 MLP operands / f32 accumulate and state", "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.config)}: H={H} P={P} m={m}, {B} independent MPC instances per GPU per step, "
                                    f"cold-start solves from the hover guess, max_iter={cfg.max_iter} maxls={cfg.ls_maxls}",
-                       "instances_per_gpu": B, "N_it_mean": n_it, "N_ls_mean": n_ls, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+                       "instances_per_gpu": B, "noise": "threefry2x32 keys (seed 10 split per instance), normal draws generated on the device", "N_it_mean": n_it, "N_ls_mean": n_ls, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "p50_solve_latency_ms": float(np.median(lat)),
             "p50_batch_latency_ms": float(np.median(ev_ms)),
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,

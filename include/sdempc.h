@@ -162,6 +162,20 @@ int sdempc_grad_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const
                           const void* xref_dev, const void* noise_dev, void* cost_dev,
                           void* grad_dev, void* stream);
 
+/* ---- key-derived noise (SPEC.md §7) ---------------------------------------------------------- */
+/* The reference threads a JAX PRNG key through every solver call: jax.random.PRNGKey(seed) and its 3-way split
+ * (sde_control.py:338-341), `rng` in and out of m_reset / m_mpc (sde_control.py:345-350,400-416,698,706,717). A key is
+ * uint32[2] with JAX's threefry2x32 conventions (PRNGKey(seed) = {seed >> 32, seed & 0xffffffff}; the host-side split lives in
+ * sde4mbrl_px4_amd/prng.py). These entry points draw the noise tensor of instance b as normal(keys[b], (P, H, 6)) on the
+ * device, so only 8 bytes per instance cross the boundary. keys is a HOST pointer, u32[B][2], in all three. */
+int sdempc_noise_from_keys_dev(sdempc_handle* h, int32_t B, const uint32_t* keys, void* noise_out_dev /* device layout,
+                               sdempc_noise_dev_floats(h, B) floats */, void* stream);
+int sdempc_noise_from_keys(sdempc_handle* h, int32_t B, const uint32_t* keys, float* noise /* host, canonical [B][P][H][6] */);
+/* A3 with key-derived noise: what m_mpc(x, rng, opt_state, ...) maps to. */
+int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const float* xref, const uint32_t* keys,
+                            const float* u_init /*[B][H][m]*/, const float* stepsize_in /*[B]*/,
+                            float* uopt /*[B][H][m]*/, float* xevol /*[B][H+1][13]*/, sdempc_info* info /*[B]*/);
+
 /* Times the last *_dev launch on its own stream with HIP events (ms); <0 if unavailable. */
 float sdempc_last_kernel_ms(const sdempc_handle* h);
 

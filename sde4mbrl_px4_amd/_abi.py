@@ -99,11 +99,16 @@ def load_library():
     lib.sdempc_solve_batch_dev.argtypes = [vp, i32] + [vp] * 9
     lib.sdempc_rollout_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.sdempc_grad_batch_dev.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    u32p = C.POINTER(C.c_uint32)
+    lib.sdempc_noise_from_keys_dev.argtypes = [vp, i32, u32p, vp, vp]
+    lib.sdempc_noise_from_keys.argtypes = [vp, i32, u32p, fp]
+    lib.sdempc_solve_batch_keys.argtypes = [vp, i32, fp, fp, u32p, fp, fp, fp, fp, C.POINTER(SdempcInfo)]
     lib.sdempc_last_kernel_ms.argtypes = [vp]
     lib.sdempc_last_kernel_ms.restype = C.c_float
     for name in ("sdempc_set_device", "sdempc_reset", "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch",
                  "sdempc_noise_to_device_layout", "sdempc_solve_batch_dev", "sdempc_rollout_batch_dev",
-                 "sdempc_grad_batch_dev", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev"):
+                 "sdempc_grad_batch_dev", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev",
+                 "sdempc_noise_from_keys_dev", "sdempc_noise_from_keys", "sdempc_solve_batch_keys"):
         getattr(lib, name).restype = C.c_int
     _LIB = lib
     return lib
@@ -114,4 +119,5 @@ EXPORTED_SYMBOLS = [
     "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch", "sdempc_noise_dev_floats",
     "sdempc_traj_dev_floats", "sdempc_noise_to_device_layout", "sdempc_solve_batch_dev", "sdempc_rollout_batch_dev",
     "sdempc_grad_batch_dev", "sdempc_last_kernel_ms", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev",
+    "sdempc_noise_from_keys_dev", "sdempc_noise_from_keys", "sdempc_solve_batch_keys",
 ]

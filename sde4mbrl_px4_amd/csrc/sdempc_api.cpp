@@ -61,7 +61,7 @@ struct sdempc_handle {
     // workspace + staging (sized for max_batch)
     DevBuf d_act, d_traj, d_x0, d_u, d_xref, d_noise, d_step, d_cost, d_grad, d_xmean, d_uopt, d_info;
     // canonical-layout staging of the host-pointer entry points (allocated on their first use)
-    DevBuf d_noise_canon, d_traj_canon;
+    DevBuf d_noise_canon, d_traj_canon, d_keys;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -183,6 +183,15 @@ int stage_common(sdempc_handle* h, int B, const float* x0, const float* u, const
     return 0;
 }
 
+// keys (host u32[B][2]) -> device staging -> noise in the device layout at out_dev, on stream st
+int noise_from_keys(sdempc_handle* h, int B, const uint32_t* keys, float* out_dev, hipStream_t st) {
+    int rc;
+    if (!h->d_keys.p && (rc = dev_alloc(h, h->d_keys, sizeof(uint32_t) * 2 * (size_t)h->max_batch))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_keys.p, keys, sizeof(uint32_t) * 2 * (size_t)B, hipMemcpyHostToDevice, st));
+    HIPCHK(h, launch_noise_from_keys((const uint32_t*)h->d_keys.p, out_dev, B, h->P, h->G, h->H, st));
+    return 0;
+}
+
 template <class F>
 int timed_launch(sdempc_handle* h, hipStream_t st, F&& f) {
     HIPCHK(h, hipEventRecord(h->ev0, st));
@@ -280,7 +289,7 @@ void sdempc_destroy(sdempc_handle* h) {
     if (!h) return;
     if (h->dev_ready) {
         (void)hipSetDevice(h->device);
-        for (DevBuf* b : {&h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon,
+        for (DevBuf* b : {&h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys,
                           &h->d_step, &h->d_cost, &h->d_grad, &h->d_xmean, &h->d_uopt, &h->d_info})
             dev_free(*b);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -377,6 +386,28 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
     return timed_launch(h, st, [&] { return launch_solve(a, B, st); });
 }
 
+int sdempc_noise_from_keys_dev(sdempc_handle* h, int32_t B, const uint32_t* keys, void* noise_out_dev, void* stream) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!keys || !noise_out_dev) return fail(h, SDEMPC_EINVAL, "NULL pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    return noise_from_keys(h, B, keys, (float*)noise_out_dev, stream ? (hipStream_t)stream : h->stream);
+}
+
+int sdempc_noise_from_keys(sdempc_handle* h, int32_t B, const uint32_t* keys, float* noise) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!keys || !noise) return fail(h, SDEMPC_EINVAL, "NULL pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    const size_t nf = (size_t)h->P * h->H * SDEMPC_NNOISE;
+    if (!h->d_noise_canon.p && (rc = dev_alloc(h, h->d_noise_canon, sizeof(float) * (size_t)h->max_batch * nf))) return rc;
+    if ((rc = noise_from_keys(h, B, keys, (float*)h->d_noise.p, h->stream))) return rc;
+    HIPCHK(h, launch_relayout(false, (const float*)h->d_noise.p, (float*)h->d_noise_canon.p, B, h->P, h->G, h->H * SDEMPC_NNOISE, h->stream));
+    HIPCHK(h, hipMemcpyAsync(noise, h->d_noise_canon.p, sizeof(float) * B * nf, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SDEMPC_OK;
+}
+
 float sdempc_last_kernel_ms(const sdempc_handle* h) {
     if (!h || !h->timed) return -1.0f;
     if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0f;
@@ -433,6 +464,27 @@ int sdempc_solve_batch(sdempc_handle* h, int32_t B, const float* x0, const float
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(uopt, h->d_uopt.p, sizeof(float) * B * h->H * h->m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(xevol, h->d_xmean.p, sizeof(float) * B * (h->H + 1) * SDEMPC_NX, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof(float) * B * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SDEMPC_OK;
+}
+
+int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const float* xref, const uint32_t* keys, const float* u_init,
+                            const float* stepsize_in, float* uopt, float* xevol, sdempc_info* info) {
+    int rc = check_batch(h, B);
+    if (rc) return rc;
+    if (!x0 || !xref || !keys || !u_init || !stepsize_in || !uopt || !xevol || !info) return fail(h, SDEMPC_EINVAL, "NULL host pointer%s");
+    if ((rc = ensure_device(h))) return rc;
+    const int H = h->H, m = h->m;
+    HIPCHK(h, hipMemcpyAsync(h->d_x0.p, x0, sizeof(float) * B * SDEMPC_NX, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_u.p, u_init, sizeof(float) * B * H * m, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_xref.p, xref, sizeof(float) * B * (H + 1) * SDEMPC_NX, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_step.p, stepsize_in, sizeof(float) * B, hipMemcpyHostToDevice, h->stream));
+    if ((rc = noise_from_keys(h, B, keys, (float*)h->d_noise.p, h->stream))) return rc;
+    rc = sdempc_solve_batch_dev(h, B, h->d_x0.p, h->d_xref.p, h->d_noise.p, h->d_u.p, h->d_step.p, h->d_uopt.p, h->d_xmean.p, h->d_info.p, h->stream);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(uopt, h->d_uopt.p, sizeof(float) * B * H * m, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(xevol, h->d_xmean.p, sizeof(float) * B * (H + 1) * SDEMPC_NX, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof(float) * B * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return SDEMPC_OK;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdint.h>
 
 namespace sdempc {
 
@@ -59,5 +60,7 @@ hipError_t launch_grad(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st);
 // canonical [B][P][C] <-> device [B][G][C][32] (to_dev: zero-pads particles >= P)
 hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int P, int G, int C, hipStream_t st);
+// SPEC.md §7: noise of B instances from their threefry keys (device u32[B][2]) straight into the device layout [B][G][H][6][32]
+hipError_t launch_noise_from_keys(const uint32_t* keys_dev, float* out, int B, int P, int G, int H, hipStream_t st);
 
 }  // namespace sdempc

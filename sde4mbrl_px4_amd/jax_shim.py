@@ -6,10 +6,12 @@ run unmodified apart from its import lines:
     jax.random.split(key, n)                 sde_control.py:341           -> uint32[n,2]
 
 Nothing is traced or compiled here: the solver callables already dispatch to pre-built HIP kernels.
-Key splitting is NOT threefry-compatible."""
+Keys follow JAX's threefry2x32 conventions (prng.py; pinned by public known-answer values)."""
 import os
 
 import numpy as np
+
+from . import prng as _prng
 
 
 class _Compiled:
@@ -56,12 +58,11 @@ def jit(f, **_):
 class random:  # noqa: N801 - mirrors the module name jax.random
     @staticmethod
     def PRNGKey(seed):
-        return np.array([0, int(seed) & 0xFFFFFFFF], dtype=np.uint32)
+        return _prng.PRNGKey(seed)
 
     @staticmethod
     def split(key, num=2):
-        g = np.random.default_rng([int(v) for v in np.asarray(key).reshape(-1)])
-        return g.integers(0, 2 ** 32, size=(num, 2), dtype=np.uint32)
+        return _prng.split(key, num)
 
 
 numpy = np

@@ -20,7 +20,7 @@ from typing import Callable, NamedTuple, Optional
 
 import numpy as np
 
-from . import workload
+from . import prng, workload
 from .config import MPCConfig, load_mpc_config
 from .model import RotorSDEModel, synthetic_hexa, synthetic_iris
 from .utils import TrajectoryCSV
@@ -50,17 +50,11 @@ class OptState(NamedTuple):
     num_ls_trials: np.float32 = np.float32(0.0)
 
 
-def _key_to_seed(rng) -> int:
-    k = np.asarray(rng).astype(np.uint64).reshape(-1)
-    return int((int(k[0]) << 32 | int(k[-1])) & 0x7FFFFFFFFFFFFFFF)
-
-
 def _next_key(rng):
-    """Advance a (2,) uint32 key. NOT JAX's threefry split: the noise stream of
-    this build is numpy PCG64 seeded from the key, so identical seeds give identical results between
-    this build's GPU path and its oracle, not with the original JAX path."""
-    g = np.random.default_rng(_key_to_seed(rng))
-    return g.integers(0, 2 ** 32, size=2, dtype=np.uint32), g
+    """SPEC.md §7.3: `new_rng, sub = split(rng)` with JAX's threefry2x32 split; the solve draws its noise tensor as
+    normal(sub, (P, H, 6)) on the device. Returns (new_rng, sub), both uint32[2]."""
+    k = prng.split(np.asarray(rng, dtype=np.uint32).reshape(2), 2)
+    return k[0].copy(), k[1].copy()
 
 
 @dataclass
@@ -102,14 +96,12 @@ class MpcProblem:
         return _arr(np.asarray(opt_state.yk, np.float32)), opt_state, rng, _arr(np.tile(x, (self.cfg.horizon + 1, 1)))
 
     def m_mpc(self, x, rng, opt_state: OptState, curr_t=0.0, xdes=None):
-        H, P = self.cfg.horizon, self.cfg.num_particles
         x = np.asarray(x, np.float32).reshape(13)
         xdes = x if xdes is None else np.asarray(xdes, np.float32).reshape(13)
-        new_rng, gen = _next_key(rng)
-        noise = gen.standard_normal((1, P, H, 6), dtype=np.float32)
+        new_rng, sub = _next_key(rng)
         xref = self.xref(float(curr_t), xdes)[None]
         u0 = np.asarray(opt_state.yk, np.float32)[None]
-        uopt, xevol, info = self.solver().solve(x[None], xref, noise, u0, np.array([opt_state.stepsize], np.float32))
+        uopt, xevol, info = self.solver().solve_keys(x[None], xref, sub[None], u0, np.array([opt_state.stepsize], np.float32))
         uo = uopt[0]
         yk = np.concatenate([uo[1:], uo[-1:]], axis=0) if self.shift_warm_start else uo
         i = info[0]

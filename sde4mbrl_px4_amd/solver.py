@@ -109,6 +109,41 @@ class SdeMpcSolver:
         info_np = np.frombuffer(info, dtype=np.float32).reshape(B, 8).copy()
         return uopt, xevol, info_np
 
+    # ---- key-derived noise (SPEC.md §7): keys uint32[B][2], JAX threefry conventions ------------------
+    @staticmethod
+    def _keys(keys, B=None):
+        k = np.ascontiguousarray(keys, dtype=np.uint32)
+        if k.ndim != 2 or k.shape[1] != 2 or (B is not None and k.shape[0] != B):
+            raise ValueError(f"keys must be uint32[B][2], got {k.shape}")
+        return k
+
+    def solve_keys(self, x0, xref, keys, u_init, stepsize_in):
+        """m_mpc's mapping: the noise of instance b is normal(keys[b], (P, H, 6)), drawn on the device."""
+        x0 = _f32(x0)
+        B = x0.shape[0]
+        x0, u_init = _f32(x0, (B, 13)), _f32(u_init, (B, self.H, self.m))
+        xref, keys, stepsize_in = _f32(xref, (B, self.H + 1, 13)), self._keys(keys, B), _f32(stepsize_in, (B,))
+        uopt = np.zeros((B, self.H, self.m), np.float32)
+        xevol = np.zeros((B, self.H + 1, 13), np.float32)
+        info = (SdempcInfo * B)()
+        self._check(self.lib.sdempc_solve_batch_keys(self._h, B, _fp(x0), _fp(xref), keys.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                     _fp(u_init), _fp(stepsize_in), _fp(uopt), _fp(xevol), info))
+        return uopt, xevol, np.frombuffer(info, dtype=np.float32).reshape(B, 8).copy()
+
+    def noise_from_keys(self, keys):
+        """The canonical noise tensors f32[B][P][H][6] the device draws from keys (inspection / parity tests)."""
+        keys = self._keys(keys)
+        B = keys.shape[0]
+        out = np.zeros((B, self.P, self.H, 6), np.float32)
+        self._check(self.lib.sdempc_noise_from_keys(self._h, B, keys.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(out)))
+        return out
+
+    def noise_from_keys_dev(self, keys, noise_out, stream=0):
+        """keys: host uint32[B][2]; noise_out: device pointer to sdempc_noise_dev_floats(B) floats (device layout)."""
+        keys = self._keys(keys)
+        self._check(self.lib.sdempc_noise_from_keys_dev(self._h, keys.shape[0], keys.ctypes.data_as(C.POINTER(C.c_uint32)), noise_out,
+                                                        C.c_void_p(stream)))
+
     # ---- device-resident entry points (torch tensors or raw device pointers) ---------------------
     def noise_to_device_layout(self, noise):
         noise = _f32(noise)

@@ -32,7 +32,44 @@ def lib():
             for fn in ("rcp", "rsqrt", "tanh", "sigmoid"):
                 f = getattr(_LIB, pre + fn)
                 f.argtypes, f.restype = [ft], ft
+        _LIB.orc_log.argtypes, _LIB.orc_log.restype = [C.c_float], C.c_float
+        _LIB.orc_erfinv.argtypes, _LIB.orc_erfinv.restype = [C.c_float], C.c_float
+        _LIB.orc_bits_to_normal.argtypes, _LIB.orc_bits_to_normal.restype = [C.c_uint32], C.c_float
     return _LIB
+
+
+def _key(key):
+    k = np.asarray(key, dtype=np.uint32).reshape(2)
+    return (C.c_uint32 * 2)(int(k[0]), int(k[1]))
+
+
+def threefry2x32(key, x0, x1):
+    out = (C.c_uint32 * 2)()
+    lib().orc_threefry2x32(_key(key), C.c_uint32(int(x0)), C.c_uint32(int(x1)), out)
+    return int(out[0]), int(out[1])
+
+
+def split(key, num=2):
+    out = np.zeros((num, 2), np.uint32)
+    lib().orc_split(_key(key), C.c_int(num), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+def random_bits(key, n):
+    out = np.zeros(n, np.uint32)
+    lib().orc_random_bits(_key(key), C.c_size_t(n), out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+def normal(key, n):
+    out = np.zeros(n, np.float32)
+    lib().orc_normal(_key(key), C.c_size_t(n), _fp(out))
+    return out
+
+
+def noise_from_key(key, P, H):
+    """SPEC.md §7.3: canonical f32[P][H][6] noise tensor of one solve."""
+    return normal(key, P * H * 6).reshape(P, H, 6)
 
 
 def _fp(a):

@@ -25,8 +25,9 @@ def test_m_mpc_matches_oracle_on_identical_seed():
     uopt, st2, rng2, xevol = prob.m_mpc(x, rng, st, curr_t=0.0, xdes=xdes)
     uopt.block_until_ready()
     assert uopt.shape == (20, 4) and xevol.shape == (21, 13) and uopt.dtype == np.float32
-    _, gen = _next_key(rng)
-    noise = gen.standard_normal((1, 32, 20, 6), dtype=np.float32)[0]
+    new_rng, sub = _next_key(rng)
+    assert np.array_equal(np.stack([new_rng, sub]), orc.split(rng, 2)) and np.array_equal(rng2, new_rng)   # threefry split (SPEC.md §7.3)
+    noise = orc.noise_from_key(sub, 32, 20)
     O = orc.Oracle(prob.cfg, prob.model)
     uo, xe, info, _ = O.solve(x, W.constant_reference(xdes, 20), noise, np.asarray(st.yk), float(st.stepsize))
     np.testing.assert_allclose(uopt, uo, rtol=1e-4, atol=1e-6)

@@ -396,3 +396,43 @@ def test_c5_f16_mlp_path():
     np.testing.assert_allclose(gc[0], c2, rtol=1e-5)
     np.testing.assert_allclose(grad[0], g2, rtol=1e-3, atol=1e-4 * np.abs(g2).max())
     S.close()
+
+
+# ---- key-derived noise (SPEC.md §7): device threefry/normal stream vs the oracle, bit for bit ----------------------------
+@pytest.mark.parametrize("P,H", [(1, 20), (2, 3), (31, 7), (32, 20), (33, 5), (63, 4), (128, 50), (257, 9)])
+def test_device_noise_from_keys_bit_exact(P, H):
+    cfg = load_mpc_config(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml")).replace(horizon=H, num_short_dt=H, num_particles=P)
+    B = 5
+    keys = np.stack([orc.split([0, 10 + b], 2)[1] for b in range(B)]).astype(np.uint32)
+    keys[3] = [0xFFFFFFFF, 0xFFFFFFFF]
+    S = _solver(cfg, synthetic_iris(), B)
+    got = S.noise_from_keys(keys)
+    assert got.shape == (B, P, H, 6)
+    for b in range(B):
+        assert bits_differ(got[b], orc.noise_from_key(keys[b], P, H)) == 0, (P, H, b)
+    # the device layout written by the generator: padded particles of the last group are exactly zero
+    import torch
+    nd = torch.full((S.lib.sdempc_noise_dev_floats(S._h, B),), 7.0, dtype=torch.float32, device="cuda")
+    S.noise_from_keys_dev(keys, nd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    dev = nd.cpu().numpy().reshape(B, (P + 31) // 32, H, 6, 32)
+    assert np.array_equal(dev, S.noise_to_device_layout(got))
+    S.close()
+
+
+def test_solve_with_keys_equals_solve_with_oracle_noise():
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(horizon=14, num_short_dt=14, num_particles=72, max_iter=7, max_no_improvement_iter=7)
+    B = 3
+    x0, xref, _, u = _problem(cfg, B, 3)
+    keys = np.stack([orc.split([0, 10], 3)[b] for b in range(B)]).astype(np.uint32)
+    s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
+    S = _solver(cfg, synthetic_iris(), B)
+    uk, xk, ik = S.solve_keys(x0, xref, keys, u, s0)
+    noise = np.stack([orc.noise_from_key(keys[b], 72, 14) for b in range(B)])
+    un, xn, inn = S.solve(x0, xref, noise, u, s0)
+    assert bits_differ(uk, un) == 0 and bits_differ(xk, xn) == 0 and bits_differ(ik, inn) == 0
+    O = orc.Oracle(cfg, synthetic_iris())
+    uo, xo, io = O.solve_batch(x0, xref, noise, u, s0)
+    _close(uk, uo, "uopt")
+    assert bits_differ(uk, uo) == 0 and bits_differ(xk, xo) == 0 and bits_differ(ik, io) == 0
+    S.close()

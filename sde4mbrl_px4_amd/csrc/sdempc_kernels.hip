@@ -30,6 +30,7 @@
 //   * template <bool F16>: optional fp16-operand contractions on v_mfma_f32_32x32x16_f16 (SPEC.md §9).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "sdempc_kernels.h"
 
 namespace sdempc {
@@ -119,6 +120,64 @@ DI void tanh16(f32x16& v) {
         v[4 * q] = a; v[4 * q + 1] = b; v[4 * q + 2] = c; v[4 * q + 3] = d;
     }
 }
+// Packed form of the same arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two values per instruction, identical IEEE
+// operations per value, so results are bit-identical to tanh4). A v_pk instruction costs two issue slots of the vector
+// datapath, so it gains nothing once a SIMD is shared by 2+ waves (tools/tanh_probe.hip: 772 vs 710 cycles per tile at two
+// waves per SIMD) but a lone wave per SIMD is issue-bound and gets 1.5x (816 vs 1237 cycles): used by the small-batch
+// (latency) instantiation of the solve kernel only.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DI f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+DI f32x2 splat2(float x) { return f32x2{x, x}; }
+DI f32x2 exp2d_pk(f32x2 x) {   // 1 + 2^(x*c) of two clamped values
+    const f32x2 c = splat2(2.885390043258667f), mg = splat2(12582912.0f);
+    f32x2 t2 = pk_fma(x, c, mg);
+    f32x2 n = t2 - mg;
+    f32x2 f = pk_fma(x, c, -n);
+    f32x2 p = splat2(0.001327647129073739f);
+    p = pk_fma(p, f, splat2(0.009675540961325169f));
+    p = pk_fma(p, f, splat2(0.05550713092088699f));
+    p = pk_fma(p, f, splat2(0.24022120237350464f));
+    p = pk_fma(p, f, splat2(0.6931469440460205f));
+    p = pk_fma(p, f, splat2(1.0000001192092896f));
+    f32x2 e;
+    e[0] = __uint_as_float(__float_as_uint(p[0]) + (__float_as_uint(t2[0]) << 23));
+    e[1] = __uint_as_float(__float_as_uint(p[1]) + (__float_as_uint(t2[1]) << 23));
+    return e + splat2(1.0f);
+}
+// two tanh4 groups at once: group a in element 0 of every pair, group b in element 1 (the two reciprocals share the Newton steps)
+DI void tanh8_pk(float* a, float* b) {
+    f32x2 a01 = f32x2{clampf(a[0], -9.0f, 9.0f), clampf(a[1], -9.0f, 9.0f)}, a23 = f32x2{clampf(a[2], -9.0f, 9.0f), clampf(a[3], -9.0f, 9.0f)};
+    f32x2 b01 = f32x2{clampf(b[0], -9.0f, 9.0f), clampf(b[1], -9.0f, 9.0f)}, b23 = f32x2{clampf(b[2], -9.0f, 9.0f), clampf(b[3], -9.0f, 9.0f)};
+    f32x2 da01 = exp2d_pk(a01), da23 = exp2d_pk(a23), db01 = exp2d_pk(b01), db23 = exp2d_pk(b23);
+    f32x2 d0 = f32x2{da01[0], db01[0]}, d1 = f32x2{da01[1], db01[1]}, d2 = f32x2{da23[0], db23[0]}, d3 = f32x2{da23[1], db23[1]};
+    f32x2 p2 = d0 * d1, p3 = p2 * d2, p4 = p3 * d3;
+    f32x2 y;
+    y[0] = __uint_as_float(0x7EF311C7u - __float_as_uint(p4[0]));
+    y[1] = __uint_as_float(0x7EF311C7u - __float_as_uint(p4[1]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { f32x2 e = pk_fma(-p4, y, splat2(1.0f)); y = pk_fma(y, e, y); }
+    f32x2 r = y;
+    f32x2 r3 = r * p3; r = r * d3;
+    f32x2 r2 = r * p2; r = r * d2;
+    f32x2 r1 = r * d0;
+    f32x2 r0 = r * d1;
+    const f32x2 m2 = splat2(-2.0f), one = splat2(1.0f);
+    f32x2 t0 = pk_fma(m2, r0, one), t1 = pk_fma(m2, r1, one), t2 = pk_fma(m2, r2, one), t3 = pk_fma(m2, r3, one);
+    a[0] = t0[0]; a[1] = t1[0]; a[2] = t2[0]; a[3] = t3[0];
+    b[0] = t0[1]; b[1] = t1[1]; b[2] = t2[1]; b[3] = t3[1];
+}
+DI void tanh16_pk(f32x16& v) {
+#pragma unroll
+    for (int q = 0; q < 4; q += 2) {
+        float a[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        float b[4] = {v[4 * q + 4], v[4 * q + 5], v[4 * q + 6], v[4 * q + 7]};
+        tanh8_pk(a, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[4 * q + i] = a[i]; v[4 * q + 4 + i] = b[i]; }
+    }
+}
+template <bool PK>
+DI void tanh_tile(f32x16& v) { if constexpr (PK) tanh16_pk(v); else tanh16(v); }
 DI float sigmoid_spec(float x) {
     float E = exp2_spec(clampf(x, -30.0f, 30.0f), -1.4426950216293335f);
     return rcp_spec(1.0f + E);
@@ -364,7 +423,7 @@ struct StepAux {
 };
 
 
-template <bool F16>
+template <bool F16, bool PK = false>
 DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, float* xn, StepAux& A) {
     const float* ust = sm.ust + t * UST;
     const float dt = sm.dt[t];
@@ -411,10 +470,10 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     }
     SCHED_PHASE();
 
-    tanh16(accD);
+    tanh_tile<PK>(accD);
     SCHED_PHASE();
 
-    tanh16(accN);
+    tanh_tile<PK>(accN);
     A.h1d = accD; A.h1n = accN;
     SCHED_PHASE();
 
@@ -450,7 +509,7 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     }
     SCHED_PHASE();
 
-    tanh16(acc2);
+    tanh_tile<PK>(acc2);
     A.h2 = acc2;
     SCHED_PHASE();
 
@@ -722,7 +781,7 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
 // block-level rollout: expected cost of control sequence u (LDS). SPEC.md §5.3/§6/§7
 //   store_traj: stream x_t to a.traj; want_mean: particle mean trajectory -> xmean_out (global)
 // ------------------------------------------------------------------------------------------------
-template <class Team, bool F16>
+template <class Team, bool F16, bool PK = false>
 DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;
@@ -764,7 +823,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 #pragma unroll
                 for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
             }
-            step_fwd<F16>(a, sm, ww, t, h, lane, x, xi, xn, A);
+            step_fwd<F16, PK>(a, sm, ww, t, h, lane, x, xi, xn, A);
             float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
             l = FMA(a.C.res_mult * A.eta, A.eta, l);
             J = FMA(sm.disc[t], l, J);
@@ -807,7 +866,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 // block-level cost + gradient (forward sweep with trajectory store, adjoint sweep). SPEC.md §5.4/§6
 //   y: control sequence in LDS; gout: gradient [H*m] in LDS
 // ------------------------------------------------------------------------------------------------
-template <class Team, int M, bool F16>
+template <class Team, int M, bool F16, bool PK = false>
 DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const float* y, float* gout, int b, int tid) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P, m = a.m;
@@ -845,7 +904,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 #pragma unroll
                 for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
             }
-            step_fwd<F16>(a, sm, ww, t, h, lane, x, xi, xn, A);
+            step_fwd<F16, PK>(a, sm, ww, t, h, lane, x, xi, xn, A);
             {   // activation checkpoint: second hidden layer (4 x 16-byte stores per lane) + step scalars once per particle;
                 // the adjoint sweep recomputes only layer 1 from x_t (balance between HBM traffic and vector work)
                 float* ap = ac + (size_t)t * ACT_STRIDE;
@@ -916,7 +975,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
             float lamn[NX], gq[12];
             // recompute layer 1 only (R, v_body, 6 MFMAs, 32 tanh); everything downstream of it comes from the checkpoint
             // (the unused remainder of step_fwd is dead code and is removed by the compiler)
-            step_fwd<F16>(a, sm, ww, t, h, lane, xt, xi, xn, A);
+            step_fwd<F16, PK>(a, sm, ww, t, h, lane, xt, xi, xn, A);
             A.h2 = h2l; A.eta = eta_l; A.Fb[0] = fb0; A.Fb[1] = fb1; A.Fb[2] = fb2; A.rn = rn_l;
 #pragma unroll
             for (int i = 0; i < 3; ++i) A.Jom[i] = a.M.J[i] * xt[10 + i];
@@ -1019,7 +1078,8 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_grad_kernel(KArgs a) {
 }
 
 // SPEC.md §8: monotone accelerated proximal gradient with Armijo backtracking, one instance per block
-template <class Team, int M, bool F16>
+// PK: packed-f32 tanh, for launches that leave one wave per SIMD (see tanh8_pk); results are bit-identical either way
+template <class Team, int M, bool F16, bool PK = false>
 __global__ void __launch_bounds__(BNT, 2) sdempc_solve_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int m = a.m, N = a.H * m;
@@ -1029,11 +1089,11 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_solve_kernel(KArgs a) {
         float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
         xk[e] = v; yk[e] = v;
     }
-    const float c_init = block_rollout<Team, F16>(a, sm, ww, xk, b, tid, false, nullptr);
+    const float c_init = block_rollout<Team, F16, PK>(a, sm, ww, xk, b, tid, false, nullptr);
     float c_x = c_init, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f;
     int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1;
     for (int k = 0; k < a.A.max_iter; ++k) {
-        const float c_y = block_cost_grad<Team, M, F16>(a, sm, ww, yk, g, b, tid);
+        const float c_y = block_cost_grad<Team, M, F16, PK>(a, sm, ww, yk, g, b, tid);
         gsq = block_dot<Team>(sm, g, g, N, tid);
         if (!(gsq < __builtin_inff())) break;   // SPEC.md §8 non-finite guard (team-uniform): keep xk, report gsq
         float c_n = 0.0f;
@@ -1048,7 +1108,7 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_solve_kernel(KArgs a) {
                     float v = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
                     xn[e] = v; d1[e] = v - yk[e];
                 }
-                c_n = block_rollout<Team, F16>(a, sm, ww, xn, b, tid, false, nullptr);
+                c_n = block_rollout<Team, F16, PK>(a, sm, ww, xn, b, tid, false, nullptr);
                 float gd = block_dot<Team>(sm, g, d1, N, tid);
                 nls = jl + 1;
                 if (c_n <= FMA(a.A.coef, gd, c_y)) break;
@@ -1058,7 +1118,7 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_solve_kernel(KArgs a) {
             s = a.A.stepsize;
             Team::sync();
             for (int e = tid; e < N; e += Team::NT) { int jj = e % m; xn[e] = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]); }
-            c_n = block_rollout<Team, F16>(a, sm, ww, xn, b, tid, false, nullptr);
+            c_n = block_rollout<Team, F16, PK>(a, sm, ww, xn, b, tid, false, nullptr);
             nls = 1;
         }
         sum_ls = sum_ls + (float)nls; sum_s = sum_s + s; nit = k + 1; nls_tot += nls;
@@ -1087,7 +1147,7 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_solve_kernel(KArgs a) {
     }
     Team::sync();
     for (int e = tid; e < N; e += Team::NT) a.uopt[(size_t)b * N + e] = xk[e];
-    block_rollout<Team, F16>(a, sm, ww, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
+    block_rollout<Team, F16, PK>(a, sm, ww, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
     if (tid == 0) {
         float* inf = a.info + (size_t)b * 8;
         const float fn = (float)nit;
@@ -1126,8 +1186,29 @@ static hipError_t launch_grad_team(const KArgs& a, hipStream_t st) {
     if (a.m == 6) return launch_k(sdempc_grad_kernel<Team, 6, F16>, a, st, Team::IPB);
     return launch_k(sdempc_grad_kernel<Team, 8, F16>, a, st, Team::IPB);
 }
+// Number of compute units of the current device (cached): a grid of at most that many workgroups leaves one wave per SIMD.
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else return 256;
+    }
+    return cus;
+}
 template <class Team, bool F16>
 static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
+    if constexpr (!F16) {
+        // small-batch (latency) launches: one workgroup per CU at most -> a lone wave per SIMD is issue-bound -> packed tanh
+        const int wgs = (a.B + Team::IPB - 1) / Team::IPB;
+        static const char* force = getenv("SDEMPC_PK");     // "0" / "1": A/B switch for tools and tests; unset: by grid size
+        const bool pk = force ? force[0] == '1' : wgs <= device_cus();
+        if (pk) {
+            if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, false, true>, a, st, Team::IPB);
+            if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, false, true>, a, st, Team::IPB);
+            return launch_k(sdempc_solve_kernel<Team, 8, false, true>, a, st, Team::IPB);
+        }
+    }
     if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16>, a, st, Team::IPB);
     if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, F16>, a, st, Team::IPB);
     return launch_k(sdempc_solve_kernel<Team, 8, F16>, a, st, Team::IPB);

@@ -88,6 +88,11 @@ typedef struct sdempc_cfg {
      * 0 = f32 (v_mfma_f32_32x32x2_f32, bit-reproducible; default), 1 = fp16 operands rounded toward zero,
      * f32 accumulate (v_mfma_f32_32x32x16_f16; BASELINE config C5). SPEC.md §9. */
     int32_t mlp_dtype;
+    /* extension (not a reference YAML key): 0 = exact (default): tanh / sigmoid / reciprocal square root in the bit-reproducible
+     * software forms of SPEC.md §3, results identical to the CPU oracle bit for bit. 1 = fast: the same kernels with the
+     * hardware transcendentals (v_exp_f32, v_rcp_f32, v_rsq_f32); about 1e-7 relative per operation away from the exact path,
+     * deterministic on a given GPU, not reproducible on a CPU. SPEC.md §10. */
+    int32_t math_mode;
 } sdempc_cfg;
 
 /* Optimiser telemetry: the 7 scalars the reference reads from opt_state

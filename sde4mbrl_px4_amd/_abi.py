@@ -43,6 +43,7 @@ class SdempcCfg(C.Structure):
         ("ls_reset_option", C.c_int32),
         ("ls_maxls", C.c_int32),
         ("mlp_dtype", C.c_int32),
+        ("math_mode", C.c_int32),
     ]
 
 

@@ -69,6 +69,7 @@ class MPCConfig:
     ls_maxls: int = 4
     # extension key (not in the reference schema): "f32" (default, bit-reproducible) or "f16" (SPEC.md §9)
     mlp_dtype: str = "f32"
+    math_mode: str = "exact"
 
     @property
     def num_motors(self) -> int:
@@ -130,6 +131,9 @@ class MPCConfig:
         if self.mlp_dtype not in ("f32", "f16"):
             raise ValueError(f"mlp_dtype must be f32|f16, got {self.mlp_dtype!r}")
         c.mlp_dtype = 1 if self.mlp_dtype == "f16" else 0
+        if self.math_mode not in ("exact", "fast"):
+            raise ValueError(f"math_mode must be exact|fast, got {self.math_mode!r}")
+        c.math_mode = 1 if self.math_mode == "fast" else 0
         return c, ts
 
 
@@ -183,6 +187,7 @@ def mpc_config_from_dict(d: dict) -> MPCConfig:
     else:
         cfg.ls_maxls = 0
     cfg.mlp_dtype = str(d.get("mlp_dtype", "f32"))
+    cfg.math_mode = str(d.get("math_mode", "exact"))
     return cfg
 
 

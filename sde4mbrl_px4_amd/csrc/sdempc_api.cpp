@@ -236,6 +236,7 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     const float* f = (const float*)(hd + SDEMPC_BLOB_HEADER_INTS);
     h->blob_f.assign(f, f + SDEMPC_BLOB_FLOATS);
     if (cfg->mlp_dtype != 0 && cfg->mlp_dtype != 1) { delete h; return fail(nullptr, SDEMPC_EINVAL, "mlp_dtype must be 0 (f32) or 1 (f16)%s"); }
+    if (cfg->math_mode != 0 && cfg->math_mode != 1) { delete h; return fail(nullptr, SDEMPC_EINVAL, "math_mode must be 0 (exact) or 1 (fast)%s"); }
     if (cfg->mlp_dtype == 1) {   // layer-1 state-input weights and layer-2 weights live in fp16 (forward and adjoint alike)
         for (int i = 0; i < 64 * 6; ++i) h->blob_f[56 + i] = f16_rtz_host(h->blob_f[56 + i]);
         for (int i = 0; i < 32 * 32; ++i) h->blob_f[760 + i] = f16_rtz_host(h->blob_f[760 + i]);
@@ -262,6 +263,7 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     a.H = h->H; a.P = h->P; a.m = m; a.G = h->G;
     a.invP = 1.0f / (float)h->P;
     a.f16 = cfg->mlp_dtype == 1;
+    a.fast = cfg->math_mode == 1;
     a.M.inv_mass = f[0]; a.M.grav = f[1];
     for (int i = 0; i < 3; ++i) { a.M.J[i] = f[2 + i]; a.M.iJ[i] = f[5 + i]; }
     a.M.ct2 = f[8]; a.M.ct1 = f[9]; a.M.ct0 = f[10]; a.M.cm2 = f[11]; a.M.cm1 = f[12];
@@ -356,7 +358,7 @@ int sdempc_rollout_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, co
     a.x0 = (const float*)x0_dev; a.u = (const float*)u_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
     a.cost = (float*)cost_dev; a.xmean = (float*)xmean_dev; a.store_traj = store_traj;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    return timed_launch(h, st, [&] { return launch_rollout(a, B, st); });
+    return timed_launch(h, st, [&] { return a.fast ? launch_rollout_fast(a, B, st) : launch_rollout(a, B, st); });
 }
 
 int sdempc_grad_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* u_dev, const void* xref_dev, const void* noise_dev,
@@ -369,7 +371,7 @@ int sdempc_grad_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const
     a.x0 = (const float*)x0_dev; a.u = (const float*)u_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
     a.cost = (float*)cost_dev; a.grad = (float*)grad_dev;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    return timed_launch(h, st, [&] { return launch_grad(a, B, st); });
+    return timed_launch(h, st, [&] { return a.fast ? launch_grad_fast(a, B, st) : launch_grad(a, B, st); });
 }
 
 int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* xref_dev, const void* noise_dev, const void* u_init_dev,
@@ -383,7 +385,7 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
     a.x0 = (const float*)x0_dev; a.u = (const float*)u_init_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
     a.stepsize_in = (const float*)stepsize_dev; a.uopt = (float*)uopt_dev; a.xmean = (float*)xevol_dev; a.info = (float*)info_dev;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    return timed_launch(h, st, [&] { return launch_solve(a, B, st); });
+    return timed_launch(h, st, [&] { return a.fast ? launch_solve_fast(a, B, st) : launch_solve(a, B, st); });
 }
 
 int sdempc_noise_from_keys_dev(sdempc_handle* h, int32_t B, const uint32_t* keys, void* noise_out_dev, void* stream) {

@@ -50,6 +50,7 @@ struct KArgs {
     float* info;               // [B][8] raw: sum_ls, stepsize, nit, grad_sqr, sum_s, c_init, c_opt, nls_total
     int store_traj;
     int f16;                   // SPEC.md §9: fp16-operand MLP contractions in the forward step
+    int fast;                  // SPEC.md §10: hardware transcendentals (selects the fastm translation unit; host-side switch)
 };
 
 constexpr int ACT_STRIDE = 1280;  // floats per (instance, group, step): h2 tile 4 chunks x 64 lanes x 4 + step scalars 32 x 8
@@ -58,6 +59,10 @@ int team_ipb(int G, int H, int m);            // 4 when one wave owns an instanc
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st);
+// math_mode fast (SPEC.md §10): the same kernels built with hardware transcendentals (second translation unit)
+hipError_t launch_rollout_fast(const KArgs& a, int B, hipStream_t st);
+hipError_t launch_grad_fast(const KArgs& a, int B, hipStream_t st);
+hipError_t launch_solve_fast(const KArgs& a, int B, hipStream_t st);
 // canonical [B][P][C] <-> device [B][G][C][32] (to_dev: zero-pads particles >= P)
 hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int P, int G, int C, hipStream_t st);
 // SPEC.md §7: noise of B instances from their threefry keys (device u32[B][2]) straight into the device layout [B][G][H][6][32]

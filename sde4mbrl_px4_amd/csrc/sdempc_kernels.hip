@@ -33,7 +33,21 @@
 #include <stdlib.h>
 #include "sdempc_kernels.h"
 
+// This file is compiled twice (Makefile): SDEMPC_FAST=0 -> namespace sdempc::exact, the bit-reproducible arithmetic of SPEC.md
+// §3 (the default and the path every parity claim is about); SDEMPC_FAST=1 -> namespace sdempc::fastm, the same kernels with the
+// hardware transcendentals v_exp_f32 / v_rcp_f32 / v_rsq_f32 in tanh, sigmoid and the quaternion normalisation (SPEC.md §10,
+// `math_mode: fast`): not reproducible on a CPU, checked against the oracle within tolerances.
+#ifndef SDEMPC_FAST
+#define SDEMPC_FAST 0
+#endif
+
 namespace sdempc {
+#if SDEMPC_FAST
+namespace fastm {
+#else
+namespace exact {
+#endif
+constexpr bool FAST = SDEMPC_FAST != 0;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -176,9 +190,22 @@ DI void tanh16_pk(f32x16& v) {
         for (int i = 0; i < 4; ++i) { v[4 * q + i] = a[i]; v[4 * q + 4 + i] = b[i]; }
     }
 }
+// math_mode fast (SPEC.md §10): 1 - 2 / (1 + 2^(x * 2 log2 e)) on the transcendental unit; saturates through inf / 0 without a clamp
+DI void tanh16_hw(f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(v[r] * 2.885390043258667f);
+        v[r] = FMA(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+    }
+}
 template <bool PK>
-DI void tanh_tile(f32x16& v) { if constexpr (PK) tanh16_pk(v); else tanh16(v); }
+DI void tanh_tile(f32x16& v) {
+    if constexpr (FAST) tanh16_hw(v);
+    else if constexpr (PK) tanh16_pk(v);
+    else tanh16(v);
+}
 DI float sigmoid_spec(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950216293335f));
     float E = exp2_spec(clampf(x, -30.0f, 30.0f), -1.4426950216293335f);
     return rcp_spec(1.0f + E);
 }
@@ -579,7 +606,7 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) qt[i] = FMA(dq[i], dt, x[6 + i]);
     float n2 = FMA(qt[3], qt[3], FMA(qt[2], qt[2], FMA(qt[1], qt[1], qt[0] * qt[0])));
-    A.rn = rsqrt_spec(n2);
+    if constexpr (FAST) A.rn = __builtin_amdgcn_rsqf(n2); else A.rn = rsqrt_spec(n2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { A.qn[i] = qt[i] * A.rn; xn[6 + i] = A.qn[i]; }
 }
@@ -1198,7 +1225,7 @@ static int device_cus() {
 }
 template <class Team, bool F16>
 static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
-    if constexpr (!F16) {
+    if constexpr (!F16 && !FAST) {
         // small-batch (latency) launches: one workgroup per CU at most -> a lone wave per SIMD is issue-bound -> packed tanh
         const int wgs = (a.B + Team::IPB - 1) / Team::IPB;
         static const char* force = getenv("SDEMPC_PK");     // "0" / "1": A/B switch for tools and tests; unset: by grid size
@@ -1272,5 +1299,22 @@ hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int 
     }
     return hipGetLastError();
 }
+
+#if SDEMPC_FAST
+}  // namespace fastm
+hipError_t launch_rollout_fast(const KArgs& a, int B, hipStream_t st) { return fastm::launch_rollout(a, B, st); }
+hipError_t launch_grad_fast(const KArgs& a, int B, hipStream_t st) { return fastm::launch_grad(a, B, st); }
+hipError_t launch_solve_fast(const KArgs& a, int B, hipStream_t st) { return fastm::launch_solve(a, B, st); }
+#else
+}  // namespace exact
+size_t smem_bytes(int H, int m, int ipb) { return exact::smem_bytes(H, m, ipb); }
+int team_ipb(int G, int H, int m) { return exact::team_ipb(G, H, m); }
+hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) { return exact::launch_rollout(a, B, st); }
+hipError_t launch_grad(const KArgs& a, int B, hipStream_t st) { return exact::launch_grad(a, B, st); }
+hipError_t launch_solve(const KArgs& a, int B, hipStream_t st) { return exact::launch_solve(a, B, st); }
+hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int P, int G, int C, hipStream_t st) {
+    return exact::launch_relayout(to_dev, in, out, B, P, G, C, st);
+}
+#endif
 
 }  // namespace sdempc

@@ -436,3 +436,37 @@ def test_solve_with_keys_equals_solve_with_oracle_noise():
     _close(uk, uo, "uopt")
     assert bits_differ(uk, uo) == 0 and bits_differ(xk, xo) == 0 and bits_differ(ik, io) == 0
     S.close()
+
+
+# ---- math_mode: fast (SPEC.md §10): hardware transcendentals, tolerance parity against the exact oracle -------------------
+@pytest.mark.parametrize("mlp", ["f32", "f16"])
+def test_fast_math_mode_within_tolerance_of_exact_oracle(mlp):
+    cfg = MPCConfig(horizon=24, num_short_dt=24, num_particles=70, u_slew_coeff=1.0, max_iter=8, max_no_improvement_iter=8, mlp_dtype=mlp, math_mode="fast")
+    model = synthetic_iris()
+    B = 4
+    x0, xref, noise, u = _problem(cfg, B, 11)
+    S = _solver(cfg, model, B)
+    O = orc.Oracle(cfg.replace(math_mode="exact"), model)        # the oracle has no fast mode: it IS the exact arithmetic
+    cost, traj, xmean = S.rollout(x0, u, xref, noise, True, True)
+    gc, grad = S.grad(x0, u, xref, noise)
+    s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
+    uopt, xevol, info = S.solve(x0, xref, noise, u, s0)
+    tol = 2e-5 if mlp == "f32" else 2e-4          # f16: hardware MFMA accumulation order on top (SPEC.md §9)
+    for b in range(B):
+        co, tro, xmo = O.rollout(x0[b], u[b], xref[b], noise[b], True, True)
+        assert abs(cost[b] - co) <= tol * abs(co)
+        np.testing.assert_allclose(traj[b], tro, rtol=0, atol=50 * tol * max(1.0, np.abs(tro).max()))
+        gco, go = O.grad(x0[b], u[b], xref[b], noise[b])
+        assert abs(gc[b] - gco) <= tol * abs(gco)
+        assert np.linalg.norm(grad[b] - go) <= 20 * tol * np.linalg.norm(go)
+        uo, xe, io, _ = O.solve(x0[b], xref[b], noise[b], u[b], float(s0[b]))
+        np.testing.assert_allclose(uopt[b], uo, rtol=RTOL, atol=1e-4)        # north_star tolerance on the controls
+        assert info[b, 2] == io[2] and abs(info[b, 6] - io[6]) <= 1e-3 * abs(io[6])
+    # deterministic run to run
+    uopt2, _, _ = S.solve(x0, xref, noise, u, s0)
+    assert bits_differ(uopt, uopt2) == 0
+    # and genuinely a different arithmetic from the exact mode (otherwise this test tests nothing)
+    Sx = _solver(cfg.replace(math_mode="exact"), model, B)
+    cx, _, _ = Sx.rollout(x0, u, xref, noise)
+    assert bits_differ(cost, cx) > 0
+    S.close(); Sx.close()

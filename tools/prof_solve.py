@@ -12,8 +12,10 @@ ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--max-iter", type=int, default=0)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--mode", default="solve", choices=["solve", "rollout", "grad"])
+ap.add_argument("--math-mode", default="exact", choices=["exact", "fast"])
+ap.add_argument("--mlp-dtype", default="f32", choices=["f32", "f16"])
 a = ap.parse_args()
-cfg = load_mpc_config(a.config)
+cfg = load_mpc_config(a.config).replace(math_mode=a.math_mode, mlp_dtype=a.mlp_dtype)
 if a.max_iter: cfg = cfg.replace(max_iter=a.max_iter, max_no_improvement_iter=a.max_iter)
 H, P, m, B = cfg.horizon, cfg.num_particles, cfg.num_motors, a.batch
 dev = torch.device("cuda", 0)
@@ -41,5 +43,5 @@ for r in range(a.reps):
         ih = info.cpu().numpy(); extra = f" N_it {ih[:,2].mean():.1f} N_ls {ih[:,7].mean():.1f} -> {B/ms*1e3:.1f} solves/s"
     else:
         extra = f" -> {B*H*P/ms*1e3/1e9:.3f} G particle-steps/s"
-    print(f"{a.mode} B={B} H={H} P={P} rep {r}: {ms:.3f} ms{extra}")
+    print(f"{a.mode} {a.math_mode}/{a.mlp_dtype} B={B} H={H} P={P} rep {r}: {ms:.3f} ms{extra}")
 S.close()

@@ -119,8 +119,17 @@ def _pick_model(cfg: MPCConfig, model) -> RotorSDEModel:
         if m.num_motors != cfg.num_motors:
             raise ValueError(f"{lm}: model has {m.num_motors} motors, config has {cfg.num_motors}")
         return m
-    # learned_model_params names a pickle of the external sde4mbrl repo (iris_sitl_traj_mpc.yaml:3) whose
-    # format is not in the reference; this build ships synthetic vehicles.
+    if lm and lm.endswith(".pkl") and os.path.exists(lm):
+        # a pickle of the external sde4mbrl repo (iris_sitl_traj_mpc.yaml:3): its layout is not in the reference, so it is read
+        # only when the user states the layout in <name>.mapping.yaml beside it (importer.py)
+        mp = lm[:-4] + ".mapping.yaml"
+        if os.path.exists(mp):
+            from .importer import import_sde_pickle
+            mdl = import_sde_pickle(lm, mp)
+            if mdl.num_motors != cfg.num_motors:
+                raise ValueError(f"{lm}: model has {mdl.num_motors} motors, config has {cfg.num_motors}")
+            return mdl
+    # otherwise: this build's synthetic vehicles
     return synthetic_iris() if cfg.num_motors == 4 else synthetic_hexa()
 
 

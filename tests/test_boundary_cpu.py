@@ -106,3 +106,55 @@ def test_shared_block_layouts_and_command_selection():
     idx, _, _ = select_command(9_000_000.0, 1_000_000.0, 50000.0, u, w, 20)
     assert idx == 19                                                     # clamped to the last row (sde_control.py:294-298)
     assert CONTROL_STATE == {"none": 0, "reset": 1, "test": 2, "pos": 3, "idle": 4, "traj": 5}
+
+
+# ---- N3: importer for pickled parameter trees (layout supplied by the caller; nothing about the external format is guessed) ----
+def test_param_tree_importer_round_trip(tmp_path):
+    import pickle
+
+    import yaml
+
+    from sde4mbrl_px4_amd import synthetic_hexa
+    from sde4mbrl_px4_amd.importer import import_sde_pickle, load_param_tree
+
+    ref = synthetic_hexa()
+    m = ref.num_motors
+    W1 = np.concatenate([ref.W1z[:32], ref.W1u], axis=1)            # [32, 6+m]
+    tree = {   # Haiku-style: module -> {w [in, out], b}; arrays are plain numpy (jax.device_get before pickling)
+        "drift/~/linear_0": {"w": W1.T.copy(), "b": ref.b1[:32].copy()},
+        "drift/~/linear_1": {"w": ref.W2.T.copy(), "b": ref.b2.copy()},
+        "drift/~/linear_2": {"w": ref.W3.T.copy(), "b": ref.b3.copy()},
+        "density": {"linear_0": {"w": ref.W1z[32:].T.copy(), "b": ref.b1[32:].copy()}, "linear_1": {"w": ref.w3n[:, None].copy(), "b": np.array([ref.b3n], np.float32)}},
+        "prior": {"mass": np.float32(ref.mass), "inertia": ref.inertia},
+    }
+    pk = tmp_path / "hexa_sde.pkl"
+    pk.write_bytes(pickle.dumps(tree))
+    mapping = {
+        "drift_l1": {"w": "drift/~/linear_0/w", "b": "drift/~/linear_0/b"},
+        "drift_l2": {"w": "drift/~/linear_1/w", "b": "drift/~/linear_1/b"},
+        "drift_out": {"w": "drift/~/linear_2/w", "b": "drift/~/linear_2/b"},
+        "density_l1": {"w": "density/linear_0/w", "b": "density/linear_0/b"},
+        "density_out": {"w": "density/linear_1/w", "b": "density/linear_1/b"},
+        "physics": {"mass": "prior/mass", "inertia": "prior/inertia", "grav": ref.grav, "thrust_poly": ref.thrust_poly.tolist(),
+                    "moment_poly": ref.moment_poly.tolist(), "rotor_x": ref.rotor_x.tolist(), "rotor_y": ref.rotor_y.tolist(),
+                    "rotor_dir": ref.rotor_dir.tolist(), "res_force_scale": ref.res_force_scale.tolist(),
+                    "res_torque_scale": ref.res_torque_scale.tolist(), "sigma": ref.sigma.tolist()},
+    }
+    mp = tmp_path / "mapping.yaml"
+    mp.write_text(yaml.safe_dump(mapping))
+    got = import_sde_pickle(str(pk), str(mp))
+    assert got.num_motors == m and got.to_blob() == ref.to_blob()
+    # wrong orientation / architecture is reported with the shape
+    bad = dict(mapping, drift_l2={"w": "drift/~/linear_0/w", "b": "drift/~/linear_1/b"})
+    with pytest.raises(ValueError, match="drift_l2"):
+        import_sde_pickle(str(pk), bad)
+    with pytest.raises(KeyError, match="no leaf"):
+        import_sde_pickle(str(pk), dict(mapping, drift_out={"w": "nope/w", "b": "drift/~/linear_2/b"}))
+
+    # a pickle that names any other callable is refused before it can run
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned",))
+    with pytest.raises(pickle.UnpicklingError, match="refusing"):
+        load_param_tree(pickle.dumps({"w": Evil()}))

@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=2048, help="MPC problem instances per GPU per step")
+    ap.add_argument("--batch", type=int, default=3072, help="MPC problem instances per GPU per step (3 workgroups per CU x 256 CUs x 4 rounds)")
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "c2_iris_traj_h50_p128.yaml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

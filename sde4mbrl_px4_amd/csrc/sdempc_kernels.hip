@@ -893,7 +893,9 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 // block-level cost + gradient (forward sweep with trajectory store, adjoint sweep). SPEC.md §5.4/§6
 //   y: control sequence in LDS; gout: gradient [H*m] in LDS
 // ------------------------------------------------------------------------------------------------
-template <class Team, int M, bool F16, bool PK = false>
+// PREF: software-prefetch the adjoint sweep's loads one step ahead through a register double buffer (40 VGPRs). Needed when a
+// SIMD holds one or two waves; the throughput instantiation drops it to fit three waves per SIMD, which hide the latency instead.
+template <class Team, int M, bool F16, bool PK = false, bool PREF = true>
 DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const float* y, float* gout, int b, int tid) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P, m = a.m;
@@ -978,8 +980,9 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 #pragma unroll
             for (int i = 0; i < NN; ++i) nxi[i] = nz[(t * NN + i) * 32];
         };
-        issue_loads(H - 1);
+        if constexpr (PREF) issue_loads(H - 1);
         for (int t = H - 1; t >= 0; --t) {
+            if constexpr (!PREF) issue_loads(t);
             // take ownership of the prefetched step
             f32x16 h2l;
 #pragma unroll
@@ -989,7 +992,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
             for (int i = 0; i < NX; ++i) xt[i] = nxt[i];
 #pragma unroll
             for (int i = 0; i < NN; ++i) xi[i] = nxi[i];
-            if (t > 0) issue_loads(t - 1);
+            if constexpr (PREF) { if (t > 0) issue_loads(t - 1); }
             // x = x_{t+1}: fold the stage-cost gradient into the incoming adjoint
             const float dsc = sm.disc[t];
             {
@@ -1106,8 +1109,12 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_grad_kernel(KArgs a) {
 
 // SPEC.md §8: monotone accelerated proximal gradient with Armijo backtracking, one instance per block
 // PK: packed-f32 tanh, for launches that leave one wave per SIMD (see tanh8_pk); results are bit-identical either way
+// Occupancy: the throughput instantiation of the workgroup-wide team is built for three waves per SIMD (168 VGPRs: the hot loops
+// fit, the compiler spills only solver state around them; +6 % at C2 over two waves per SIMD with the prefetch buffer). The
+// latency instantiation (PK) and the one-wave teams (LDS allows two workgroups per CU anyway) keep two.
+template <class Team, bool PK> constexpr int solve_waves_per_simd() { return (Team::IPB == 1 && !PK) ? 3 : 2; }
 template <class Team, int M, bool F16, bool PK = false>
-__global__ void __launch_bounds__(BNT, 2) sdempc_solve_kernel(KArgs a) {
+__global__ void __launch_bounds__(BNT, (solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int m = a.m, N = a.H * m;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
@@ -1120,7 +1127,7 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_solve_kernel(KArgs a) {
     float c_x = c_init, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f;
     int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1;
     for (int k = 0; k < a.A.max_iter; ++k) {
-        const float c_y = block_cost_grad<Team, M, F16, PK>(a, sm, ww, yk, g, b, tid);
+        const float c_y = block_cost_grad<Team, M, F16, PK, solve_waves_per_simd<Team, PK>() == 2>(a, sm, ww, yk, g, b, tid);
         gsq = block_dot<Team>(sm, g, g, N, tid);
         if (!(gsq < __builtin_inff())) break;   // SPEC.md §8 non-finite guard (team-uniform): keep xk, report gsq
         float c_n = 0.0f;

@@ -30,12 +30,18 @@ for it in range(n):
     S = SdeMpcSolver(cfg, model, max_batch=B); O = orc.Oracle(cfg, model)
     cost, traj, xm = S.rollout(x0, u, xref, noise, True, True); gc, g = S.grad(x0, u, xref, noise)
     uopt, xe, info = S.solve(x0, xref, noise, u, np.full(B, cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize, np.float32))
+    keys = rng.integers(0, 2 ** 32, size=(B, 2), dtype=np.uint32)
+    nk = S.noise_from_keys(keys)
+    uk, xk, ik = S.solve_keys(x0, xref, keys, u, np.full(B, cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize, np.float32))
     nb = 0; nonfinite += int(not (np.isfinite(traj).all() and np.isfinite(g).all()))
     for b in range(B):
         c, t, mm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True); c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
         uo, xo, io, _ = O.solve(x0[b], xref[b], noise[b], u[b], float(cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize))
         nb += bits_differ(cost[b], c) + bits_differ(traj[b], t) + bits_differ(xm[b], mm) + bits_differ(gc[b], c2) + bits_differ(g[b], g2.astype(np.float32)) \
               + bits_differ(uopt[b], uo) + bits_differ(xe[b], xo) + bits_differ(info[b], io)
+        nzo = orc.noise_from_key(keys[b], P, H)
+        uo2, xo2, io2, _ = O.solve(x0[b], xref[b], nzo, u[b], float(cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize))
+        nb += bits_differ(nk[b], nzo) + bits_differ(uk[b], uo2) + bits_differ(xk[b], xo2) + bits_differ(ik[b], io2)
     if nb: print(f"MISMATCH case {seed0+it}: m={m} H={H} P={P} B={B} words={nb} cfg={kw}"); bad += 1
     S.close()
 print(f"soak: {n} configurations ({nonfinite} with non-finite trajectories), {bad} with mismatches, {time.time()-t0:.1f} s")

@@ -59,7 +59,7 @@ struct sdempc_handle {
     // device tables
     DevBuf d_dt, d_sdt, d_disc, d_beta, d_wts;
     // workspace + staging (sized for max_batch)
-    DevBuf d_act, d_traj, d_x0, d_u, d_xref, d_noise, d_step, d_cost, d_grad, d_xmean, d_uopt, d_info;
+    DevBuf d_part, d_act, d_traj, d_x0, d_u, d_xref, d_noise, d_step, d_cost, d_grad, d_xmean, d_uopt, d_info;
     // canonical-layout staging of the host-pointer entry points (allocated on their first use)
     DevBuf d_noise_canon, d_traj_canon, d_keys;
     hipStream_t stream = nullptr;
@@ -130,6 +130,7 @@ int ensure_device(sdempc_handle* h) {
     if ((rc = dev_alloc(h, h->d_traj, sizeof(float) * traj_floats(h, B)))) return rc;
     HIPCHK(h, hipMemset(h->d_traj.p, 0, h->d_traj.bytes));
     if ((rc = dev_alloc(h, h->d_act, sizeof(float) * (size_t)B * h->G * H * ACT_STRIDE))) return rc;
+    if ((rc = dev_alloc(h, h->d_part, sizeof(float) * (size_t)B * h->G * part_stride(H)))) return rc;
     if ((rc = dev_alloc(h, h->d_x0, sizeof(float) * B * SDEMPC_NX))) return rc;
     if ((rc = dev_alloc(h, h->d_u, sizeof(float) * B * H * m))) return rc;
     if ((rc = dev_alloc(h, h->d_xref, sizeof(float) * B * (H + 1) * SDEMPC_NX))) return rc;
@@ -147,6 +148,7 @@ int ensure_device(sdempc_handle* h) {
     h->base.wts = (const float*)h->d_wts.p;
     h->base.traj = (float*)h->d_traj.p;
     h->base.act = (float*)h->d_act.p;
+    h->base.part = (float*)h->d_part.p;
     h->dev_ready = true;
     return 0;
 }
@@ -291,7 +293,7 @@ void sdempc_destroy(sdempc_handle* h) {
     if (!h) return;
     if (h->dev_ready) {
         (void)hipSetDevice(h->device);
-        for (DevBuf* b : {&h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys,
+        for (DevBuf* b : {&h->d_part, &h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys,
                           &h->d_step, &h->d_cost, &h->d_grad, &h->d_xmean, &h->d_uopt, &h->d_info})
             dev_free(*b);
         if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -43,6 +43,7 @@ struct KArgs {
     const float* stepsize_in;  // [B] (solve)
     float* traj;               // [B][G][H+1][13][32] workspace
     float* act;                // [B][G][H][ACT_STRIDE] activation checkpoint of the gradient's forward sweep
+    float* part;               // [B][G][part_stride(H)] per-group particle sums (adjoint outputs per step / mean trajectory), SPEC.md §6.1
     float* cost;               // [B]
     float* grad;               // [B][H][m]
     float* xmean;              // [B][H+1][13] or null
@@ -53,6 +54,8 @@ struct KArgs {
     int fast;                  // SPEC.md §10: hardware transcendentals (selects the fastm translation unit; host-side switch)
 };
 
+// floats per (instance, group) row of KArgs::part: max(H*12 adjoint sums, (H+1)*13 state sums), multiple of 4
+__host__ __device__ inline int part_stride(int H) { const int a = H * 12, b = (H + 1) * 13; return ((a > b ? a : b) + 3) & ~3; }
 constexpr int ACT_STRIDE = 1280;  // floats per (instance, group, step): h2 tile 4 chunks x 64 lanes x 4 + step scalars 32 x 8
 size_t smem_bytes(int H, int m, int ipb);   // ipb: instances (teams) per workgroup
 int team_ipb(int G, int H, int m);            // 4 when one wave owns an instance (G == 1 and LDS permits), else 1

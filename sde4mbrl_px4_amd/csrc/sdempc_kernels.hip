@@ -219,7 +219,6 @@ struct Smem {
     float *A2h;                                        // f16 mode: A operands of W2, [half][lane][8 x fp16]
     float *ust;                                        // [H][36]: c[32], Tz, tau[3]
     float *xref;                                       // [H+1][13]
-    float *SX;                                         // max(4*H*12, 4*(H+1)*13): per-wave partials
     float *dt, *sdt, *disc;                            // [H], [H][6], [H+1]
     float *red;                                        // [16] block-reduction scratch
     float *v[6];                                       // N-vectors: 0 xk, 1 yk, 2 xn, 3 g, 4 d1, 5 ucur
@@ -245,18 +244,17 @@ DI Smem carve(float* base, int H, int m, int team) {
     s.disc = p; p += (H + 1 + 3) & ~3;
     // ---- per team ----
     const int nv = (H * m + 3) & ~3;
-    const int per_team = H * UST + (((H + 1) * NX + 3) & ~3) + 4 * (H + 1) * NX + 16 + 6 * nv;
+    const int per_team = H * UST + (((H + 1) * NX + 3) & ~3) + 16 + 6 * nv;
     p += team * per_team;
     s.ust = p; p += H * UST;
     s.xref = p; p += ((H + 1) * NX + 3) & ~3;
-    s.SX = p; p += 4 * (H + 1) * NX;
     s.red = p; p += 16;
     for (int i = 0; i < 6; ++i) { s.v[i] = p; p += nv; }
     return s;
 }
 size_t smem_bytes(int H, int m, int ipb) {
     size_t shared = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + 2 * HID * HID + 512 + ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3);
-    size_t per_team = (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 4 * (H + 1) * NX + 16 + 6 * (size_t)((H * m + 3) & ~3);
+    size_t per_team = (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
     return (shared + ipb * per_team) * sizeof(float);
 }
 
@@ -804,6 +802,21 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     for (int i = 0; i < 4; ++i) lam[6 + i] = qb[i];
 }
 
+// SPEC.md §6.1 over per-group totals kept in global memory (a.part, one row of part_stride(H) floats per particle group):
+// slot s = g mod 4 accumulates S_s <- S_s + T_g in ascending g starting from 0, total ((S0+S1)+S2)+S3. The per-group rows
+// live in HBM/L2 instead of four LDS slot arrays so that a workgroup's LDS footprint does not grow with 4*(H+1)*13 floats:
+// long horizons keep two or three workgroups per CU, and any wave may process any group (no slot ownership).
+DI float group_ordered_sum(const float* rows, int G, int PS, int i) {
+    float S0 = 0.0f, S1 = 0.0f, S2 = 0.0f, S3 = 0.0f;
+    for (int g = 0; g < G; g += 4) {
+        S0 = S0 + rows[(size_t)g * PS + i];
+        if (g + 1 < G) S1 = S1 + rows[(size_t)(g + 1) * PS + i];
+        if (g + 2 < G) S2 = S2 + rows[(size_t)(g + 2) * PS + i];
+        if (g + 3 < G) S3 = S3 + rows[(size_t)(g + 3) * PS + i];
+    }
+    return ((S0 + S1) + S2) + S3;
+}
+
 // ------------------------------------------------------------------------------------------------
 // block-level rollout: expected cost of control sequence u (LDS). SPEC.md §5.3/§6/§7
 //   store_traj: stream x_t to a.traj; want_mean: particle mean trajectory -> xmean_out (global)
@@ -816,8 +829,8 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
     const bool want_mean = xmean_out != nullptr;
     Team::sync();
     block_prepass<Team>(a, sm, u, tid);
-    if (want_mean)
-        for (int i = tid; i < 4 * (H + 1) * NX; i += Team::NT) sm.SX[i] = 0.0f;
+    const int PS = part_stride(H);
+    float* prows = a.part + (size_t)b * G * PS;
     float cu = block_ucost<Team>(a, sm, u, tid);  // contains barriers: prepass results visible afterwards
     float x0r[NX];
 #pragma unroll
@@ -828,7 +841,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         const bool valid = (g * 32 + j) < P;
         const float* nz = a.noise + ((size_t)(b * G + g) * H) * NN * 32 + j;
         float* tj = a.traj + ((size_t)(b * G + g) * (H + 1)) * NX * 32 + j;
-        float* xm = sm.SX + (g & 3) * (H + 1) * NX;   // reduction slot g % 4 (SPEC.md §6.1)
+        float* xm = prows + (size_t)g * PS;           // this group's row of per-step particle sums (SPEC.md §6.1/§6.3)
         float x[NX], xn[NX], xi[NN];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = x0r[i];
@@ -840,7 +853,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         }
         if (want_mean) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { float s = group_bfly32(valid ? x[i] : 0.0f); if (lane == 0) xm[i] = xm[i] + s; }
+            for (int i = 0; i < NX; ++i) { float s = group_bfly32(valid ? x[i] : 0.0f); if (lane == 0) xm[i] = s; }
         }
         float J = 0.0f;
         StepAux A;
@@ -867,7 +880,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             }
             if (want_mean) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) { float s = group_bfly32(valid ? x[i] : 0.0f); if (lane == 0) xm[(t + 1) * NX + i] = xm[(t + 1) * NX + i] + s; }
+                for (int i = 0; i < NX; ++i) { float s = group_bfly32(valid ? x[i] : 0.0f); if (lane == 0) xm[(t + 1) * NX + i] = s; }
             }
         }
         float T = group_bfly32(valid ? J : 0.0f);
@@ -880,11 +893,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
     Team::sync();
     float tot = ((sm.red[8] + sm.red[9]) + sm.red[10]) + sm.red[11];
     if (want_mean) {
-        for (int i = tid; i < (H + 1) * NX; i += Team::NT) {
-            const int st = (H + 1) * NX;
-            float s = ((sm.SX[i] + sm.SX[st + i]) + sm.SX[2 * st + i]) + sm.SX[3 * st + i];
-            xmean_out[i] = s * a.invP;
-        }
+        for (int i = tid; i < (H + 1) * NX; i += Team::NT) xmean_out[i] = group_ordered_sum(prows, G, PS, i) * a.invP;
     }
     return FMA(tot, a.invP, cu);
 }
@@ -903,7 +912,8 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;   // wave index inside the team
     Team::sync();
     block_prepass<Team>(a, sm, y, tid);
-    for (int i = tid; i < 4 * H * 12; i += Team::NT) sm.SX[i] = 0.0f;
+    const int PS = part_stride(H);
+    float* prows = a.part + (size_t)b * G * PS;
     float cu = block_ucost<Team>(a, sm, y, tid);
     float x0r[NX];
 #pragma unroll
@@ -915,8 +925,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         const float* nz = a.noise + ((size_t)(b * G + g) * H) * NN * 32 + j;
         float* tj = a.traj + ((size_t)(b * G + g) * (H + 1)) * NX * 32 + j;
         float* ac = a.act + ((size_t)(b * G + g) * H) * ACT_STRIDE;
-        const bool first_group = (g < 4);
-        float* Sq = sm.SX + (g & 3) * H * 12;        // reduction slot g % 4 (SPEC.md §6.1)
+        float* Sq = prows + (size_t)g * PS;          // this group's row of per-step adjoint sums (SPEC.md §6.1)
         float x[NX], xn[NX], xi[NN];
         StepAux A;
         // ---- forward sweep, x_t and the hidden activations streamed to HBM ----
@@ -1024,9 +1033,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
                     const float lo = gq[k], hi = (k + half < nq) ? gq[k + half] : 0.0f;
                     float s = group_bfly32(valid ? (h ? hi : lo) : 0.0f);
                     if (j == 0 && (h == 0 || k + half < nq)) {
-                        const int idx = t * 12 + k + h * half;
-                        // first group of this wave: the slot still holds 0 -> "0 + s" without the LDS read
-                        Sq[idx] = (first_group ? 0.0f : Sq[idx]) + s;
+                        Sq[t * 12 + k + h * half] = s;
                     }
                 }
             }
@@ -1039,15 +1046,14 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     Team::sync();
     float tot = ((sm.red[8] + sm.red[9]) + sm.red[10]) + sm.red[11];
     // gradient assembly (SPEC.md §6.3)
-    const int N = H * m, st = H * 12;
+    const int N = H * m;
     for (int e = tid; e < N; e += Team::NT) {
         int t = e / m, jj = e - t * m;
         float S[5];
         int idx[5] = {jj, M, M + 1, M + 2, M + 3};
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            int o = t * 12 + idx[k];
-            S[k] = ((sm.SX[o] + sm.SX[st + o]) + sm.SX[2 * st + o]) + sm.SX[3 * st + o];
+            S[k] = group_ordered_sum(prows, G, PS, t * 12 + idx[k]);
         }
         float uj = y[e];
         float dT = FMA(2.0f * a.M.ct2, uj, a.M.ct1);
@@ -1112,7 +1118,7 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_grad_kernel(KArgs a) {
 // Occupancy: the throughput instantiation of the workgroup-wide team is built for three waves per SIMD (168 VGPRs: the hot loops
 // fit, the compiler spills only solver state around them; +6 % at C2 over two waves per SIMD with the prefetch buffer). The
 // latency instantiation (PK) and the one-wave teams (LDS allows two workgroups per CU anyway) keep two.
-template <class Team, bool PK> constexpr int solve_waves_per_simd() { return (Team::IPB == 1 && !PK) ? 3 : 2; }
+template <class Team, bool PK> constexpr int solve_waves_per_simd() { return PK ? 2 : 3; }
 template <class Team, int M, bool F16, bool PK = false>
 __global__ void __launch_bounds__(BNT, (solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();

@@ -48,7 +48,7 @@ if "FETCH_SIZE" in solve and "WRITE_SIZE" in solve:
 if cal_r:
     res["calibration"] = {"rollout_kernel_FETCH_SIZE_KiB": cal_r.get("FETCH_SIZE"), "rollout_kernel_WRITE_SIZE_KiB": cal_r.get("WRITE_SIZE"),
                           "grad_kernel_FETCH_SIZE_KiB": cal_g.get("FETCH_SIZE"), "grad_kernel_WRITE_SIZE_KiB": cal_g.get("WRITE_SIZE"),
-                          "known_rollout_read_bytes": a.batch * 4 * 50 * 6 * 32 * 4, "known_grad_write_bytes": a.batch * 4 * 51 * 13 * 32 * 4}
+                          "known_rollout_read_bytes": a.batch * 4 * 50 * 6 * 32 * 4, "known_grad_write_bytes": a.batch * 4 * (51 * 13 * 32 + 50 * 1280) * 4}
 if "GRBM_GUI_ACTIVE" in solve and "SQ_INSTS_VALU" in solve:
     cyc = solve["GRBM_GUI_ACTIVE"] / 8.0
     res["derived"] = {"kernel_cycles": cyc, "valu_insts_per_simd": solve["SQ_INSTS_VALU"] / 1024, "mfma_busy_frac": solve.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / cyc,

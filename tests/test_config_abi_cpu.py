@@ -125,8 +125,8 @@ def test_handle_lifecycle_and_errors_without_gpu():
     assert b"max_batch" in lib.sdempc_last_error(h)
     assert lib.sdempc_rollout_batch(h, 0, dummy, dummy, dummy, dummy, dummy, None, None) == -1          # empty batch
     lib.sdempc_destroy(h)
-    # horizon limits: one workgroup's LDS (160 KiB) bounds H; 256 still fits for 4 motors, 400 does not
-    for H, ok in ((256, True), (400, False), (0, False)):
+    # horizon limits: one workgroup's LDS (160 KiB) bounds H; (3550 + 81 H) floats for 4 motors: 450 still fits, 480 does not
+    for H, ok in ((256, True), (450, True), (480, False), (0, False)):
         cl, k2 = cfg_py.replace(horizon=H, num_short_dt=H).to_cfg() if H > 0 else (None, None)
         if H == 0:
             cl = _abi.SdempcCfg.from_buffer_copy(cfg)

@@ -63,20 +63,28 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define SCHED_PHASE() ((void)0)
 #endif
 
-constexpr int NX = 13, NN = 6, HID = 32, BNT = 256;   // BNT: threads per workgroup (4 waves)
+constexpr int NX = 13, NN = 6, HID = 32;
 
 // A "team" is the set of waves that owns one MPC instance.
 //   TeamBlock: the whole workgroup (4 waves, up to 4 particle groups in flight)           -- P > 32
 //   TeamWave : one wave per instance, 4 instances per workgroup sharing the LDS weights  -- P <= 32
 // Reduction semantics (SPEC.md §6) are identical: dot256 walks its 256 virtual lanes in 256/NT passes.
 struct TeamBlock {
-    static constexpr int NT = 256, NWAVES = 4, IPB = 1;
+    static constexpr int NT = 256, NWAVES = 4, IPB = 1, BNT = 256;   // BNT: threads per workgroup
+    DI static int tid() { return threadIdx.x; }
+    DI static int team() { return 0; }
+    DI static void sync() { __syncthreads(); }
+};
+// Eight waves (two per SIMD) on one instance: single-instance latency when it has more than four particle groups
+// (any wave may take any group: the per-group rows of SPEC.md §6.1 live in global memory, see group_ordered_sum)
+struct TeamBlock8 {
+    static constexpr int NT = 512, NWAVES = 8, IPB = 1, BNT = 512;
     DI static int tid() { return threadIdx.x; }
     DI static int team() { return 0; }
     DI static void sync() { __syncthreads(); }
 };
 struct TeamWave {
-    static constexpr int NT = 64, NWAVES = 1, IPB = 4;
+    static constexpr int NT = 64, NWAVES = 1, IPB = 4, BNT = 256;
     DI static int tid() { return threadIdx.x & 63; }
     DI static int team() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }   // wave-uniform -> SGPR
     // LDS operations of one wave execute in order; the fence keeps the compiler from moving them and drains lgkmcnt
@@ -273,7 +281,7 @@ DI int opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
 DI int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // cooperative (all BNT threads of the workgroup); caller issues __syncthreads() afterwards
-DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid) {
+DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid, int BNT) {
     const float* w = a.wts;
     const int lane = tid & 63, j = lane & 31, h = lane >> 5;
     for (int i = tid; i < 6 * HID; i += BNT) sm.W3[i] = w[OFF_W3 + i];
@@ -352,12 +360,13 @@ DI float wave_bfly64(float v) { return group_bfly32(xor32_sum(v)); }
 // ((w0+w1)+w2)+w3. A team of NT threads walks the 256 virtual lanes in 256/NT passes.
 template <class Team, class F>
 DI float team_reduce256(const Smem& sm, int N, int tid, F&& elem) {
-    if constexpr (Team::NT == 256) {
+    if constexpr (Team::NT >= 256) {      // the first four waves are the 256 virtual lanes; further waves only take part in the barriers
         float acc = 0.0f;
-        for (int e = tid; e < N; e += 256) acc = elem(e, acc);
+        if (tid < 256)
+            for (int e = tid; e < N; e += 256) acc = elem(e, acc);
         acc = wave_bfly64(acc);
         Team::sync();
-        if ((tid & 63) == 0) sm.red[tid >> 6] = acc;
+        if ((tid & 63) == 0 && tid < 256) sm.red[tid >> 6] = acc;
         Team::sync();
         return ((sm.red[0] + sm.red[1]) + sm.red[2]) + sm.red[3];
     } else {
@@ -835,8 +844,6 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
     float x0r[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x0r[i] = a.x0[b * NX + i];
-    float Sw = 0.0f;
-    
     for (int g = wave; g < G; g += Team::NWAVES) {
         const bool valid = (g * 32 + j) < P;
         const float* nz = a.noise + ((size_t)(b * G + g) * H) * NN * 32 + j;
@@ -884,14 +891,10 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             }
         }
         float T = group_bfly32(valid ? J : 0.0f);
-        Sw = Sw + T;
+        if (lane == 0) xm[PS - 1] = T;                // group total of the particle costs (last element of the group's row)
     }
     Team::sync();
-    if (tid < 4) sm.red[8 + tid] = 0.0f;
-    Team::sync();
-    if (lane == 0 && wave < G) sm.red[8 + wave] = Sw;   // wave w owns slot w (TeamBlock) / slot 0 (TeamWave, G == 1)
-    Team::sync();
-    float tot = ((sm.red[8] + sm.red[9]) + sm.red[10]) + sm.red[11];
+    const float tot = group_ordered_sum(prows, G, PS, PS - 1);
     if (want_mean) {
         for (int i = tid; i < (H + 1) * NX; i += Team::NT) xmean_out[i] = group_ordered_sum(prows, G, PS, i) * a.invP;
     }
@@ -918,8 +921,6 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     float x0r[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x0r[i] = a.x0[b * NX + i];
-    float Sw = 0.0f;
-    
     for (int g = wave; g < G; g += Team::NWAVES) {
         const bool valid = (g * 32 + j) < P;
         const float* nz = a.noise + ((size_t)(b * G + g) * H) * NN * 32 + j;
@@ -967,7 +968,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 #pragma unroll
             for (int c = 0; c < 7; ++c) { if (c + 7 * h < NX) tp[(c + 7 * h) * 32] = h ? x[(c + 7) % NX] : x[c]; }
         }
-        Sw = Sw + group_bfly32(valid ? J : 0.0f);
+        { const float T = group_bfly32(valid ? J : 0.0f); if (lane == 0) Sq[PS - 1] = T; }
         // ---- adjoint sweep: x (registers) currently holds x_H ----
         float lam[NX], xt[NX];
 #pragma unroll
@@ -1040,11 +1041,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         }
     }
     Team::sync();
-    if (tid < 4) sm.red[8 + tid] = 0.0f;
-    Team::sync();
-    if (lane == 0 && wave < G) sm.red[8 + wave] = Sw;   // wave w owns slot w (TeamBlock) / slot 0 (TeamWave, G == 1)
-    Team::sync();
-    float tot = ((sm.red[8] + sm.red[9]) + sm.red[10]) + sm.red[11];
+    const float tot = group_ordered_sum(prows, G, PS, PS - 1);
     // gradient assembly (SPEC.md §6.3)
     const int N = H * m;
     for (int e = tid; e < N; e += Team::NT) {
@@ -1089,13 +1086,13 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     const int tid = Team::tid(), b = __builtin_amdgcn_readfirstlane(blockIdx.x * Team::IPB + Team::team()); \
     Smem sm = carve(smem, a.H, a.m, Team::team());                                   \
     WaveW ww;                                                                        \
-    load_weights(a, sm, ww, threadIdx.x);                                            \
+    load_weights(a, sm, ww, threadIdx.x, Team::BNT);                                 \
     __syncthreads();                                                                 \
     if (b >= a.B) return; /* no workgroup-wide barrier below this line in TeamWave */ \
     load_common<Team>(a, sm, b, tid);
 
 template <class Team, bool F16>
-__global__ void __launch_bounds__(BNT, 2) sdempc_rollout_kernel(KArgs a) {
+__global__ void __launch_bounds__(Team::BNT, 2) sdempc_rollout_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
@@ -1104,7 +1101,7 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_rollout_kernel(KArgs a) {
 }
 
 template <class Team, int M, bool F16>
-__global__ void __launch_bounds__(BNT, 2) sdempc_grad_kernel(KArgs a) {
+__global__ void __launch_bounds__(Team::BNT, 2) sdempc_grad_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
@@ -1120,7 +1117,7 @@ __global__ void __launch_bounds__(BNT, 2) sdempc_grad_kernel(KArgs a) {
 // latency instantiation (PK) and the one-wave teams (LDS allows two workgroups per CU anyway) keep two.
 template <class Team, bool PK> constexpr int solve_waves_per_simd() { return PK ? 2 : 3; }
 template <class Team, int M, bool F16, bool PK = false>
-__global__ void __launch_bounds__(BNT, (solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
+__global__ void __launch_bounds__(Team::BNT, (solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int m = a.m, N = a.H * m;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
@@ -1209,11 +1206,11 @@ static bool use_wave_team(int G, int H, int m) { return G == 1 && smem_bytes(H, 
 int team_ipb(int G, int H, int m) { return use_wave_team(G, H, m) ? TeamWave::IPB : TeamBlock::IPB; }
 
 template <class Kern>
-static hipError_t launch_k(Kern k, const KArgs& a, hipStream_t st, int ipb) {
+static hipError_t launch_k(Kern k, const KArgs& a, hipStream_t st, int ipb, int bnt = 256) {
     const size_t sb = smem_bytes(a.H, a.m, ipb);
     hipError_t e = set_smem_attr((const void*)k, sb);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3((a.B + ipb - 1) / ipb), dim3(BNT), sb, st, a);
+    hipLaunchKernelGGL(k, dim3((a.B + ipb - 1) / ipb), dim3(bnt), sb, st, a);
     return hipGetLastError();
 }
 template <class Team>
@@ -1244,6 +1241,13 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
         static const char* force = getenv("SDEMPC_PK");     // "0" / "1": A/B switch for tools and tests; unset: by grid size
         const bool pk = force ? force[0] == '1' : wgs <= device_cus();
         if (pk) {
+            if constexpr (Team::IPB == 1) {
+                if (a.G > 4) {   // more particle groups than the four waves of a workgroup: eight waves halve the sequential depth
+                    if (a.m == 4) return launch_k(sdempc_solve_kernel<TeamBlock8, 4, false, true>, a, st, 1, TeamBlock8::BNT);
+                    if (a.m == 6) return launch_k(sdempc_solve_kernel<TeamBlock8, 6, false, true>, a, st, 1, TeamBlock8::BNT);
+                    return launch_k(sdempc_solve_kernel<TeamBlock8, 8, false, true>, a, st, 1, TeamBlock8::BNT);
+                }
+            }
             if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, false, true>, a, st, Team::IPB);
             if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, false, true>, a, st, Team::IPB);
             return launch_k(sdempc_solve_kernel<Team, 8, false, true>, a, st, Team::IPB);

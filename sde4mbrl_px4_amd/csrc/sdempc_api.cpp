@@ -102,7 +102,7 @@ void dev_free(DevBuf& b) {
 size_t noise_floats(const sdempc_handle* h, int B) { return (size_t)B * h->G * h->H * SDEMPC_NNOISE * 32; }
 size_t traj_floats(const sdempc_handle* h, int B) { return (size_t)B * h->G * (h->H + 1) * SDEMPC_NX * 32; }
 
-int ensure_device(sdempc_handle* h) {
+int ensure_device_impl(sdempc_handle* h) {
     if (h->dev_ready) {
         HIPCHK(h, hipSetDevice(h->device));
         return 0;
@@ -151,6 +151,16 @@ int ensure_device(sdempc_handle* h) {
     h->base.part = (float*)h->d_part.p;
     h->dev_ready = true;
     return 0;
+}
+
+void release_device(sdempc_handle* h);
+
+// Lazy device initialisation; a failure half-way (e.g. out of HBM) releases what was allocated so that a later call starts clean.
+int ensure_device(sdempc_handle* h) {
+    const bool was_ready = h->dev_ready;
+    const int rc = ensure_device_impl(h);
+    if (rc != 0 && !was_ready) { const std::string keep = h->err; release_device(h); h->err = keep; }
+    return rc;
 }
 
 int check_batch(sdempc_handle* h, int B) {
@@ -291,7 +301,15 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
 
 void sdempc_destroy(sdempc_handle* h) {
     if (!h) return;
-    if (h->dev_ready) {
+    release_device(h);
+    delete h;
+}
+
+}  // extern "C"
+
+namespace {
+void release_device(sdempc_handle* h) {
+    if (h->dev_ready || h->stream || h->d_dt.p) {
         (void)hipSetDevice(h->device);
         for (DevBuf* b : {&h->d_part, &h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys,
                           &h->d_step, &h->d_cost, &h->d_grad, &h->d_xmean, &h->d_uopt, &h->d_info})
@@ -299,9 +317,13 @@ void sdempc_destroy(sdempc_handle* h) {
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
         if (h->stream) (void)hipStreamDestroy(h->stream);
+        h->ev0 = h->ev1 = nullptr; h->stream = nullptr;
     }
-    delete h;
+    h->dev_ready = false; h->timed = false;
 }
+}  // namespace
+
+extern "C" {
 
 int sdempc_set_device(sdempc_handle* h, int32_t device) {
     if (!h) return SDEMPC_EINVAL;

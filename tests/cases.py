@@ -45,7 +45,7 @@ def bits_differ(a, b):
 
 def diverging_single_rotor_case(P=32):
     """A single-rotor vehicle over a 55-step horizon: it tumbles and the explicit-Euler state overflows f32 around t = 53 — cost NaN
-    (instance 0) / +inf (instance 1) and a NaN gradient (found by tools/soak.py, case 5495); instance 2 repeats instance 0 at low
+    (instance 0) / +inf (instance 1) and a NaN gradient (found by tests/tools/soak.py, case 5495); instance 2 repeats instance 0 at low
     throttle, which stays finite. Exercises SPEC.md §3.7 and the §8 non-finite guard in a mixed batch."""
     B = 2
     m, H, it = 1, 55, 495

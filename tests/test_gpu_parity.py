@@ -168,7 +168,7 @@ def test_generic_motor_count_bit_exact(m):
 def test_diverging_rollout_non_finite_parity(P):
     """A rollout that overflows f32 (single-rotor vehicle, H=55): infinities and NaN positions agree with the oracle word for word,
     the solve takes no step on a NaN gradient (SPEC.md §8 guard) and the finite instance beside it is unaffected. P=32 runs the
-    one-wave team, P=100 the four-wave team. Found by tools/soak.py."""
+    one-wave team, P=100 the four-wave team. Found by tests/tools/soak.py."""
     from cases import diverging_single_rotor_case
     cfg, model, x0, xref, noise, u = diverging_single_rotor_case(P=P)
     B = len(x0)

@@ -1,7 +1,7 @@
 """How far do full 200-iteration solves drift under ~1e-7 arithmetic perturbations?
 GPU f16-MLP mode vs the oracle's emulation of it (identical except for the MFMA summation order)."""
 import os, sys, threading, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from sde4mbrl_px4_amd import load_mpc_config, synthetic_iris, workload as W

@@ -1,6 +1,6 @@
 """Oracle (CPU baseline) thread scaling on the current host."""
 import os, sys, time, threading
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, orc
 from sde4mbrl_px4_amd import load_mpc_config, synthetic_iris, workload as W

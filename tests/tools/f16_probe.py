@@ -1,6 +1,6 @@
 """f16-MLP mode: GPU vs oracle(f16 emulation) closeness; f32 mode must be unaffected."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from sde4mbrl_px4_amd import MPCConfig, synthetic_iris, workload as W

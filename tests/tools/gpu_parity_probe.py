@@ -1,6 +1,6 @@
 """Quick GPU-vs-oracle parity probe (development aid; the real tests live in tests/)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from sde4mbrl_px4_amd import MPCConfig, synthetic_iris, synthetic_hexa

@@ -1,6 +1,6 @@
 """Prints both sides of the one soak configuration whose solve hits a non-finite gradient (m=1, H=55)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from sde4mbrl_px4_amd import MPCConfig, synthetic_multirotor, workload as W

@@ -176,3 +176,21 @@ def test_entry_scripts_are_valid_python():
     assert nflops == 3520 * 128 * 50 * (2 * 200 + 375 + 2)
     assert bench.checkpoint_bytes(cfg, 200) == 200 * 2 * 4 * 50 * 1280 * 4
     assert bench.effective_cores() >= 1
+
+
+def test_product_and_tools_never_touch_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"liborc|import orc\b|from orc\b|oracle/|orc_[a-z]+\(")
+    offenders = []
+    for f in glob.glob(os.path.join(root, "sde4mbrl_px4_amd", "**", "*"), recursive=True) + glob.glob(os.path.join(root, "tools", "*")):
+        if os.path.isfile(f) and f.endswith((".py", ".cpp", ".hip", ".h", ".sh", "Makefile")):
+            for i, line in enumerate(open(f, errors="ignore")):
+                if pat.search(line) and not line.lstrip().startswith(("#", "//", "*", '"')) and "oracle/prng_oracle.c" not in line:
+                    offenders.append(f"{os.path.relpath(f, root)}:{i + 1}: {line.strip()[:100]}")
+    assert not offenders, "\n".join(offenders)
+    # bench.py may use it in exactly one function
+    src = open(os.path.join(root, "bench.py")).read()
+    assert src.count("import orc") == 1 and "def cpu_baseline" in src.split("import orc")[0].rsplit("\ndef ", 1)[-1] or "cpu_baseline" in src.split("import orc")[0][-600:]

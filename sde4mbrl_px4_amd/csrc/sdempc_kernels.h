@@ -57,7 +57,12 @@ struct KArgs {
 // floats per (instance, group) row of KArgs::part: max(H*12 adjoint sums, (H+1)*13 state sums) + the group's cost total in the
 // last element; multiple of 4
 __host__ __device__ inline int part_stride(int H) { const int a = H * 12, b = (H + 1) * 13; return ((a > b ? a : b) + 1 + 3) & ~3; }
-constexpr int ACT_STRIDE = 1280;  // floats per (instance, group, step): h2 tile 4 chunks x 64 lanes x 4 + step scalars 32 x 8
+// Activation checkpoint of the gradient's forward sweep, floats per (instance, group, step): h2 tile (4 chunks x 64 lanes x 4) + step
+// scalars (32 x 8) [+ SDEMPC_CKPT1 further layer-1 tiles of 1024 floats: 1 = drift h1, 2 = drift and density h1 (build-time experiment)]
+#ifndef SDEMPC_CKPT1
+#define SDEMPC_CKPT1 0
+#endif
+constexpr int ACT_STRIDE = 1280 + 1024 * SDEMPC_CKPT1;
 size_t smem_bytes(int H, int m, int ipb);   // ipb: instances (teams) per workgroup
 int team_ipb(int G, int H, int m);            // 4 when one wave owns an instance (G == 1 and LDS permits), else 1
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st);

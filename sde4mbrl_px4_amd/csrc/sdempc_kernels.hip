@@ -954,6 +954,16 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
                     *reinterpret_cast<float4*>(ap + 1024 + j * 8) = make_float4(A.eta, A.Fb[0], A.Fb[1], A.Fb[2]);
                     ap[1024 + j * 8 + 4] = A.rn;
                 }
+#if SDEMPC_CKPT1 >= 1
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(ap + 1280 + (q * 64 + lane) * 4) = make_float4(A.h1d[4 * q], A.h1d[4 * q + 1], A.h1d[4 * q + 2], A.h1d[4 * q + 3]);
+#endif
+#if SDEMPC_CKPT1 >= 2
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(ap + 2304 + (q * 64 + lane) * 4) = make_float4(A.h1n[4 * q], A.h1n[4 * q + 1], A.h1n[4 * q + 2], A.h1n[4 * q + 3]);
+#endif
             }
             float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
             l = FMA(a.C.res_mult * A.eta, A.eta, l);
@@ -977,11 +987,25 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         // software pipeline: the loads of step t-1 are issued while step t is being processed
         float4 nh[4], ns4;
+#if SDEMPC_CKPT1 >= 1
+        float4 nh1[4];
+#endif
+#if SDEMPC_CKPT1 >= 2
+        float4 nh1n[4];
+#endif
         float nrn, nxt[NX], nxi[NN];
         auto issue_loads = [&](int t) {
             const float* ap = ac + (size_t)t * ACT_STRIDE;
 #pragma unroll
             for (int q = 0; q < 4; ++q) nh[q] = *reinterpret_cast<const float4*>(ap + (q * 64 + lane) * 4);
+#if SDEMPC_CKPT1 >= 1
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nh1[q] = *reinterpret_cast<const float4*>(ap + 1280 + (q * 64 + lane) * 4);
+#endif
+#if SDEMPC_CKPT1 >= 2
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nh1n[q] = *reinterpret_cast<const float4*>(ap + 2304 + (q * 64 + lane) * 4);
+#endif
             ns4 = *reinterpret_cast<const float4*>(ap + 1024 + j * 8);
             nrn = ap[1024 + j * 8 + 4];
             const float* tp = tj + (size_t)t * NX * 32;
@@ -997,6 +1021,16 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
             f32x16 h2l;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { h2l[4 * q] = nh[q].x; h2l[4 * q + 1] = nh[q].y; h2l[4 * q + 2] = nh[q].z; h2l[4 * q + 3] = nh[q].w; }
+#if SDEMPC_CKPT1 >= 1
+            f32x16 h1dl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { h1dl[4 * q] = nh1[q].x; h1dl[4 * q + 1] = nh1[q].y; h1dl[4 * q + 2] = nh1[q].z; h1dl[4 * q + 3] = nh1[q].w; }
+#endif
+#if SDEMPC_CKPT1 >= 2
+            f32x16 h1nl;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { h1nl[4 * q] = nh1n[q].x; h1nl[4 * q + 1] = nh1n[q].y; h1nl[4 * q + 2] = nh1n[q].z; h1nl[4 * q + 3] = nh1n[q].w; }
+#endif
             const float eta_l = ns4.x, fb0 = ns4.y, fb1 = ns4.z, fb2 = ns4.w, rn_l = nrn;
 #pragma unroll
             for (int i = 0; i < NX; ++i) xt[i] = nxt[i];
@@ -1016,6 +1050,12 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
             // recompute layer 1 only (R, v_body, 6 MFMAs, 32 tanh); everything downstream of it comes from the checkpoint
             // (the unused remainder of step_fwd is dead code and is removed by the compiler)
             step_fwd<F16, PK>(a, sm, ww, t, h, lane, xt, xi, xn, A);
+#if SDEMPC_CKPT1 >= 1
+            A.h1d = h1dl;      // checkpointed: the drift tile's MFMAs and tanh in step_fwd above become dead code
+#endif
+#if SDEMPC_CKPT1 >= 2
+            A.h1n = h1nl;
+#endif
             A.h2 = h2l; A.eta = eta_l; A.Fb[0] = fb0; A.Fb[1] = fb1; A.Fb[2] = fb2; A.rn = rn_l;
 #pragma unroll
             for (int i = 0; i < 3; ++i) A.Jom[i] = a.M.J[i] * xt[10 + i];

@@ -1132,7 +1132,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     load_common<Team>(a, sm, b, tid);
 
 template <class Team, bool F16>
-__global__ void __launch_bounds__(Team::BNT, 2) sdempc_rollout_kernel(KArgs a) {
+__global__ void __launch_bounds__(Team::BNT, 3) sdempc_rollout_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
@@ -1141,11 +1141,11 @@ __global__ void __launch_bounds__(Team::BNT, 2) sdempc_rollout_kernel(KArgs a) {
 }
 
 template <class Team, int M, bool F16>
-__global__ void __launch_bounds__(Team::BNT, 2) sdempc_grad_kernel(KArgs a) {
+__global__ void __launch_bounds__(Team::BNT, 3) sdempc_grad_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
-    float c = block_cost_grad<Team, M, F16>(a, sm, ww, sm.v[5], sm.v[3], b, tid);
+    float c = block_cost_grad<Team, M, F16, false, false>(a, sm, ww, sm.v[5], sm.v[3], b, tid);   // three waves per SIMD, no prefetch buffer
     if (tid == 0) a.cost[b] = c;
     for (int e = tid; e < N; e += Team::NT) a.grad[(size_t)b * N + e] = sm.v[3][e];
 }

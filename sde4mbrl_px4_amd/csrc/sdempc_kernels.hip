@@ -457,23 +457,22 @@ struct StepAux {
 };
 
 
-template <bool F16, bool PK = false>
-DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, float* xn, StepAux& A) {
-    const float* ust = sm.ust + t * UST;
-    const float dt = sm.dt[t];
+// ---- uniform head of a step: rotation matrix and the MLP inputs z = (R^T v, omega) ----
+DI void fwd_head(const float* x, float* Rm, float* z) {
     const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
     const float xx = qx * qx, yy = qy * qy, zz = qz * qz;
     const float xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
-    float* Rm = A.Rm;
     Rm[0] = FMA(-2.0f, yy + zz, 1.0f); Rm[1] = 2.0f * (xy - wz);          Rm[2] = 2.0f * (xz + wy);
     Rm[3] = 2.0f * (xy + wz);          Rm[4] = FMA(-2.0f, xx + zz, 1.0f); Rm[5] = 2.0f * (yz - wx);
     Rm[6] = 2.0f * (xz - wy);          Rm[7] = 2.0f * (yz + wx);          Rm[8] = FMA(-2.0f, xx + yy, 1.0f);
-    float z[NN];
 #pragma unroll
     for (int j = 0; j < 3; ++j) z[j] = FMA(Rm[6 + j], x[5], FMA(Rm[3 + j], x[4], Rm[j] * x[3]));
     z[3] = x[10]; z[4] = x[11]; z[5] = x[12];
-    SCHED_PHASE();
+}
 
+// ---- MLPs of a step in the MFMA tile layout (32 particles per wave): outputs o[6] and eta per particle ----
+template <bool F16, bool PK>
+DI void fwd_mlp_tiles(const KArgs& a, const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, StepAux& A, float* o, float& eta_out) {
     // layer 1: C operand = per-step offsets (drift) / bias (density); K = 6 -> 3 MFMAs per tile
     f32x16 accD, accN;
 #pragma unroll
@@ -548,7 +547,6 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     SCHED_PHASE();
 
     // output layers on the VALU: per-half partial chains, then (P0 + P1) + bias
-    float o[6];
     {
         float Po[6];
 #pragma unroll
@@ -575,9 +573,15 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
         }
         eta = sigmoid_spec(xor32_sum(P) + a.M.b3n);
     }
-    A.eta = eta;
+    eta_out = eta;
     SCHED_PHASE();
+}
 
+// ---- uniform tail of a step: rigid body, Euler-Maruyama update, quaternion renormalisation ----
+DI void fwd_tail(const KArgs& a, const Smem& sm, const float* ust, int t, const float* x, const float* xi, const float* Rm, const float* o, float eta, float* xn, StepAux& A) {
+    const float dt = sm.dt[t];
+    const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    A.eta = eta;
     // rigid body
     A.Fb[0] = a.M.sF[0] * o[0]; A.Fb[1] = a.M.sF[1] * o[1]; A.Fb[2] = FMA(a.M.sF[2], o[2], ust[32]);
     float acc[3];
@@ -616,6 +620,17 @@ DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     if constexpr (FAST) A.rn = __builtin_amdgcn_rsqf(n2); else A.rn = rsqrt_spec(n2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { A.qn[i] = qt[i] * A.rn; xn[6 + i] = A.qn[i]; }
+}
+
+template <bool F16, bool PK = false>
+DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, float* xn, StepAux& A) {
+    const float* ust = sm.ust + t * UST;
+    float z[NN];
+    fwd_head(x, A.Rm, z);
+    SCHED_PHASE();
+    float o[6], eta;
+    fwd_mlp_tiles<F16, PK>(a, sm, ww, ust, h, lane, z, A, o, eta);
+    fwd_tail(a, sm, ust, t, x, xi, A.Rm, o, eta, xn, A);
 }
 
 // rotation matrix of q (same expressions as in step_fwd)
@@ -658,29 +673,32 @@ DI float stage_cost(const KArgs& a, const float* x, const float* xr, float* gx) 
 // vector-Jacobian product of one step (SPEC.md §5.4). gq[0..m-1] = W1u^T abar1, gq[m] = Tz adjoint,
 // gq[m+1..m+3] = rotor-torque adjoint
 // ------------------------------------------------------------------------------------------------
+// Uniform (per particle) quantities that the three parts of the step's vector-Jacobian product share
+struct VjpTmp {
+    float ebraw, qtb[4], dqb[4], omb[3], Fwb[3], ob[6];
+};
+
+// ---- head: everything upstream of the MLPs (per particle); gq[M..M+3] = thrust / rotor-torque adjoints ----
 template <int M>
-DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, const StepAux& A,
-                 const float* L, float etabar_cost, float* lam, float* gq) {
+DI void vjp_head(const KArgs& a, const Smem& sm, int t, const float* x, const float* xi, const StepAux& A, const float* L, float etabar_cost, VjpTmp& T, float* gq) {
     const float dt = sm.dt[t];
     const float* sdt = sm.sdt + t * NN;
     const float* Rm = A.Rm;
-    const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
-    const float* v = x + 3;
     const float* om = x + 10;
     float eb = etabar_cost;
 #pragma unroll
     for (int i = 0; i < 3; ++i) eb = FMA(L[3 + i] * sdt[i], xi[i], eb);
 #pragma unroll
     for (int i = 0; i < 3; ++i) eb = FMA(L[10 + i] * sdt[3 + i], xi[3 + i], eb);
-    float ebraw = eb * (A.eta * (1.0f - A.eta));
+    T.ebraw = eb * (A.eta * (1.0f - A.eta));
     float dotq = FMA(A.qn[3], L[9], FMA(A.qn[2], L[8], FMA(A.qn[1], L[7], A.qn[0] * L[6])));
-    float qtb[4], dqb[4];
+    float* qtb = T.qtb; float* dqb = T.dqb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { qtb[i] = A.rn * FMA(-A.qn[i], dotq, L[6 + i]); dqb[i] = qtb[i] * dt; }
     float taub_b[3], crb[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { taub_b[i] = (L[10 + i] * dt) * a.M.iJ[i]; crb[i] = -taub_b[i]; }
-    float omb[3], Jb[3];
+    float* omb = T.omb; float Jb[3];
     omb[0] = L[10] + FMA(A.Jom[1], crb[2], -(A.Jom[2] * crb[1]));
     omb[1] = L[11] + FMA(A.Jom[2], crb[0], -(A.Jom[0] * crb[2]));
     omb[2] = L[12] + FMA(A.Jom[0], crb[1], -(A.Jom[1] * crb[0]));
@@ -689,21 +707,25 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     Jb[2] = FMA(crb[0], om[1], -(crb[1] * om[0]));
 #pragma unroll
     for (int i = 0; i < 3; ++i) omb[i] = FMA(a.M.J[i], Jb[i], omb[i]);
-    float Fwb[3], Fbb[3];
+    float* Fwb = T.Fwb; float Fbb[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) Fwb[i] = (L[3 + i] * dt) * a.M.inv_mass;
 #pragma unroll
     for (int j = 0; j < 3; ++j) Fbb[j] = FMA(Rm[6 + j], Fwb[2], FMA(Rm[3 + j], Fwb[1], Rm[j] * Fwb[0]));
-    float ob[6];
+    float* ob = T.ob;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { ob[i] = a.M.sF[i] * Fbb[i]; ob[3 + i] = a.M.sT[i] * taub_b[i]; }
     gq[M] = Fbb[2];
     gq[M + 1] = taub_b[0]; gq[M + 2] = taub_b[1]; gq[M + 3] = taub_b[2];
-    SCHED_PHASE();
+}
 
+// ---- MLP part in the MFMA tile layout: zb[6] = adjoint of z, gq[0..M-1] = W1u^T abar1 (per particle) ----
+template <int M>
+DI void vjp_mlp_tiles(const Smem& sm, int h, int lane, const StepAux& A, const VjpTmp& T, float* zb, float* gq) {
+    const float ebraw = T.ebraw;
+    const float* ob = T.ob;
     // MLP VJP. Order chosen to keep few tiles live: density tile first (frees h1n), then the drift
     // tile: abar2 on the VALU, W2^T abar2 by MFMA in the accumulator layout.
-    float zb[NN];
     {
         float Pz[NN], Pu[M];
 #pragma unroll
@@ -777,6 +799,17 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
         for (int jj = 0; jj < M; ++jj) gq[jj] = xor32_sum(Pu[jj]);
     }
     SCHED_PHASE();
+}
+
+// ---- tail: adjoint of the state (per particle) ----
+DI void vjp_tail(const Smem& sm, int t, const float* x, const StepAux& A, const float* L, const VjpTmp& T, const float* zb, float* lam) {
+    const float dt = sm.dt[t];
+    const float* Rm = A.Rm;
+    const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const float* v = x + 3;
+    const float* om = x + 10;
+    const float* qtb = T.qtb; const float* dqb = T.dqb; const float* Fwb = T.Fwb;
+    float omb[3] = {T.omb[0], T.omb[1], T.omb[2]};
 #pragma unroll
     for (int i = 0; i < 3; ++i) omb[i] = omb[i] + zb[3 + i];
     float vbar[3];
@@ -809,6 +842,17 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     for (int i = 0; i < 3; ++i) { lam[i] = L[i]; lam[3 + i] = vbar[i]; lam[10 + i] = omb[i]; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) lam[6 + i] = qb[i];
+}
+
+template <int M>
+DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, const StepAux& A,
+                 const float* L, float etabar_cost, float* lam, float* gq) {
+    VjpTmp T;
+    vjp_head<M>(a, sm, t, x, xi, A, L, etabar_cost, T, gq);
+    SCHED_PHASE();
+    float zb[NN];
+    vjp_mlp_tiles<M>(sm, h, lane, A, T, zb, gq);
+    vjp_tail(sm, t, x, A, L, T, zb, lam);
 }
 
 // SPEC.md §6.1 over per-group totals kept in global memory (a.part, one row of part_stride(H) floats per particle group):

@@ -870,6 +870,357 @@ DI float group_ordered_sum(const float* rows, int G, int PS, int i) {
     return ((S0 + S1) + S2) + S3;
 }
 
+// ================================================================================================
+// Single-particle path (P == 1 — every MPC YAML the reference ships: launch/*_mpc.yaml `num_particles: 1`).
+// With one particle the 32-column MFMA tiles would carry 31 idle columns, so the MLPs are laid out "one hidden unit per
+// lane" instead: lanes 0..31 hold drift-net unit k = lane, lanes 32..63 density-net unit k = lane - 32; weights live in VGPRs.
+//   layer 1      : 6 fma per lane (chain k = 0..5 from the C operand, as the MFMA does)
+//   tanh         : SPEC.md §3.4 groups units 4g..4g+3 = one DPP quad: the four (1 + exp) values are exchanged with quad_perm
+//                  broadcasts, every lane forms the shared reciprocal and keeps its own quotient (36 instructions per layer
+//                  instead of 272 per tile)
+//   layer 2      : 32 x (v_readlane of unit k, fma with this lane's W2 row), visiting k in the SPEC.md §4 order
+//   output layers: the 14 half-chains (6 outputs + density, halves h = 0/1) run on 14 lanes at once; ds_bpermute gathers the
+//                  unit each chain needs at step r, `row_ror:8` adds the two halves
+//   adjoint      : the same three patterns transposed (readlane chain for W2^T, 12 + 2m half-chains for z-bar / gu-bar)
+// Every value is produced by the same operation sequence as in the tile layout, so results are bit-identical to it and to
+// the oracle. State, rigid body and cost are wave-uniform and reuse fwd_head / fwd_tail / vjp_head / vjp_tail.
+// ================================================================================================
+DI int koff(int r) { return (r & 3) + 8 * (r >> 2); }   // rowmap(r, 0)
+DI float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+DI float bperm_f(int src_lane, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v))); }
+
+struct LaneW {
+    float w1[NN];        // W1z[32*hh + k][0..5]
+    float c1n;           // b1[32 + k] (C operand of the density rows; drift rows take c_t[k] from LDS)
+    float b2k;           // b2[k]
+    float w2row[HID];    // W2[k][0..31]   (layer 2, output unit k)
+    float w2col[HID];    // W2[0..31][k]   (adjoint, input unit k)
+    float w3col[6];      // W3[0..5][k]
+    float w3nk;          // w3n[k]
+    float wo[16];        // this lane's output half-chain: W3[c][koff(r) + 4 hs] (lanes c + 8 hs, c < 6), w3n[..] (c == 6), else 0
+    float wz[32];        // this lane's adjoint half-chain: positions 0..15 density units, 16..31 drift units
+    int obase, zbase;    // first source lane of the chains (4 hs, +32 for the density output chain)
+    bool is_u;           // gu-bar chain (lanes 16..31): skips the density positions
+};
+
+DI void load_lane_weights(const KArgs& a, LaneW& W, int lane) {
+    const float* w = a.wts;
+    const int k = lane & 31, hh = lane >> 5, row = 32 * hh + k;
+#pragma unroll
+    for (int j = 0; j < NN; ++j) W.w1[j] = w[OFF_W1Z + row * NN + j];
+    W.c1n = w[OFF_B1 + HID + k];
+    W.b2k = w[OFF_B2 + k];
+#pragma unroll
+    for (int i = 0; i < HID; ++i) { W.w2row[i] = w[OFF_W2 + k * HID + i]; W.w2col[i] = w[OFF_W2 + i * HID + k]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) W.w3col[i] = w[OFF_W3 + i * HID + k];
+    W.w3nk = w[OFF_W3N + k];
+    const int c = lane & 7, hs = (lane >> 3) & 1;
+    const bool row0 = lane < 16, row1 = lane >= 16 && lane < 32;
+    W.obase = (row0 && c == 6) ? 32 + 4 * hs : 4 * hs;
+    W.zbase = 4 * hs;
+    W.is_u = row1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int unit = koff(r) + 4 * hs;
+        float v = 0.0f;
+        if (row0 && c < 6) v = w[OFF_W3 + c * HID + unit];
+        if (row0 && c == 6) v = w[OFF_W3N + unit];
+        W.wo[r] = v;
+        float zd = 0.0f, zf = 0.0f;
+        if (row0 && c < 6) { zd = w[OFF_W1Z + (HID + unit) * NN + c]; zf = w[OFF_W1Z + unit * NN + c]; }
+        if (row1 && c < a.m) zf = w[OFF_W1U + unit * 8 + c];
+        W.wz[r] = zd; W.wz[16 + r] = zf;
+    }
+}
+
+// SPEC.md §3.4 tanh4 with the four values of a group in the four lanes of a DPP quad
+DI float lane_tanh(float av, int lane) {
+    const float d = 1.0f + exp2_spec(clampf(av, -9.0f, 9.0f), 2.885390043258667f);
+    const float d0 = dpp_f<0x00>(d), d1 = dpp_f<0x55>(d), d2 = dpp_f<0xAA>(d), d3 = dpp_f<0xFF>(d);
+    const float p2 = d0 * d1, p3 = p2 * d2, p4 = p3 * d3;
+    float r = rcp_spec(p4);
+    const float r3 = r * p3; r = r * d3;
+    const float r2 = r * p2; r = r * d2;
+    const float r1 = r * d0;
+    const float r0 = r * d1;
+    const int q = lane & 3;
+    const float rq = (q & 2) ? ((q & 1) ? r3 : r2) : ((q & 1) ? r1 : r0);
+    return FMA(-2.0f, rq, 1.0f);
+}
+
+// forward MLPs of one step; h1: drift (lanes 0..31) / density (32..63) hidden unit, h2: layer-2 unit (both halves)
+DI void lane_fwd_mlp(const KArgs& a, const LaneW& W, const float* ust, int lane, const float* z, float& h1, float& h2, float* o, float& eta) {
+    const int k = lane & 31, hh = lane >> 5;
+    float a1 = hh ? W.c1n : ust[k];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) a1 = FMA(W.w1[j], z[j], a1);
+    h1 = lane_tanh(a1, lane);
+    float a2 = W.b2k;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int kk = rowmap(r, h); a2 = FMA(W.w2row[kk], readlane_f(h1, kk), a2); }
+    }
+    h2 = lane_tanh(a2, lane);
+    const float Mreg = hh ? h1 : h2;     // lanes 0..31: layer-2 activations, lanes 32..63: density hidden units
+    float P = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) P = FMA(W.wo[r], bperm_f(W.obase + koff(r), Mreg), P);
+    const float Pc = P + dpp_f<0x128>(P);   // row_ror:8 -> lane c: P_0 + P_1
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = readlane_f(Pc, i) + a.M.b3[i];
+    eta = sigmoid_spec(readlane_f(Pc, 6) + a.M.b3n);
+}
+
+// adjoint of the MLPs: zb[6], gq[0..M-1]
+template <int M>
+DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp& T, float* zb, float* gq) {
+    const int hh = lane >> 5;
+    float hb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) hb = FMA(W.w3col[i], T.ob[i], hb);
+    const float a2b = hb * FMA(-h2, h2, 1.0f);
+    float accB = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { const int i = rowmap(r, h); accB = FMA(W.w2col[i], readlane_f(a2b, i), accB); }
+    }
+    const float g1 = FMA(-h1, h1, 1.0f);
+    const float ad = accB * g1;
+    const float an = (W.w3nk * T.ebraw) * g1;
+    const float Abar = hh ? an : ad;
+    float Pz = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {       // density units first (z-bar chains only)
+        const float src = bperm_f(32 + W.zbase + koff(p), Abar);
+        const float nv = FMA(W.wz[p], src, Pz);
+        Pz = W.is_u ? Pz : nv;
+    }
+#pragma unroll
+    for (int p = 0; p < 16; ++p) Pz = FMA(W.wz[16 + p], bperm_f(W.zbase + koff(p), Abar), Pz);
+    const float Pc = Pz + dpp_f<0x128>(Pz);
+#pragma unroll
+    for (int kk = 0; kk < NN; ++kk) zb[kk] = readlane_f(Pc, kk);
+#pragma unroll
+    for (int jj = 0; jj < M; ++jj) gq[jj] = readlane_f(Pc, 16 + jj);
+}
+
+constexpr int LANE_ACT_H1 = 0, LANE_ACT_H2 = 64, LANE_ACT_SC = 128;   // offsets inside one ACT_STRIDE row of the checkpoint
+
+template <class Team>
+DI float lane_rollout(const KArgs& a, const Smem& sm, const LaneW& W, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
+    b = opaque_s(b); tid = opaque_v(tid);
+    const int H = a.H, lane = tid & 63;
+    const bool want_mean = xmean_out != nullptr;
+    Team::sync();
+    block_prepass<Team>(a, sm, u, tid);
+    const int PS = part_stride(H);
+    float* prow = a.part + (size_t)b * PS;                      // G == 1
+    float cu = block_ucost<Team>(a, sm, u, tid);
+    const float* nz = a.noise + ((size_t)b * H) * NN * 32;      // particle 0 sits in column 0 of the 32-wide rows
+    float* tj = a.traj + ((size_t)b * (H + 1)) * NX * 32;
+    float x[NX], xn[NX], xi[NN];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = a.x0[b * NX + i];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) xi[i] = nz[i * 32];
+    if (lane == 0) {
+        if (store_traj) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) tj[i * 32] = x[i];
+        }
+        if (want_mean) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) prow[i] = x[i] + 0.0f;     // the 32-lane butterfly with 31 zero lanes: v + 0
+        }
+    }
+    float J = 0.0f;
+    StepAux A;
+    for (int t = 0; t < H; ++t) {
+        float xin[NN];
+        if (t + 1 < H) {
+#pragma unroll
+            for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
+        }
+        const float* ust = sm.ust + t * UST;
+        float z[NN], h1, h2, o[6], eta;
+        fwd_head(x, A.Rm, z);
+        lane_fwd_mlp(a, W, ust, lane, z, h1, h2, o, eta);
+        fwd_tail(a, sm, ust, t, x, xi, A.Rm, o, eta, xn, A);
+        float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
+        l = FMA(a.C.res_mult * A.eta, A.eta, l);
+        J = FMA(sm.disc[t], l, J);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        if (t + 1 < H) {
+#pragma unroll
+            for (int i = 0; i < NN; ++i) xi[i] = xin[i];
+        }
+        if (lane == 0) {
+            if (store_traj) {
+                float* tp = tj + (size_t)(t + 1) * NX * 32;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) tp[i * 32] = x[i];
+            }
+            if (want_mean) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) prow[(t + 1) * NX + i] = x[i] + 0.0f;
+            }
+        }
+    }
+    if (lane == 0) prow[PS - 1] = J + 0.0f;
+    Team::sync();
+    const float tot = group_ordered_sum(prow, 1, PS, PS - 1);
+    if (want_mean)
+        for (int i = tid; i < (H + 1) * NX; i += Team::NT) xmean_out[i] = group_ordered_sum(prow, 1, PS, i) * a.invP;
+    return FMA(tot, a.invP, cu);
+}
+
+template <class Team, int M>
+DI float lane_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, const float* y, float* gout, int b, int tid) {
+    b = opaque_s(b); tid = opaque_v(tid);
+    const int H = a.H, m = a.m, lane = tid & 63;
+    constexpr int nq = M + 4;
+    Team::sync();
+    block_prepass<Team>(a, sm, y, tid);
+    const int PS = part_stride(H);
+    float* prow = a.part + (size_t)b * PS;
+    float cu = block_ucost<Team>(a, sm, y, tid);
+    const float* nz = a.noise + ((size_t)b * H) * NN * 32;
+    float* tj = a.traj + ((size_t)b * (H + 1)) * NX * 32;
+    float* ac = a.act + ((size_t)b * H) * ACT_STRIDE;
+    float x[NX], xn[NX], xi[NN];
+    StepAux A;
+    // ---- forward sweep: x_t, the two hidden activations per lane and five step scalars are checkpointed ----
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = a.x0[b * NX + i];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) xi[i] = nz[i * 32];
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) tj[i * 32] = x[i];
+    }
+    float J = 0.0f;
+    for (int t = 0; t < H; ++t) {
+        float xin[NN];
+        if (t + 1 < H) {
+#pragma unroll
+            for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
+        }
+        const float* ust = sm.ust + t * UST;
+        float z[NN], h1, h2, o[6], eta;
+        fwd_head(x, A.Rm, z);
+        lane_fwd_mlp(a, W, ust, lane, z, h1, h2, o, eta);
+        fwd_tail(a, sm, ust, t, x, xi, A.Rm, o, eta, xn, A);
+        {
+            float* ap = ac + (size_t)t * ACT_STRIDE;
+            ap[LANE_ACT_H1 + lane] = h1;
+            ap[LANE_ACT_H2 + lane] = h2;
+            if (lane == 0) {
+                *reinterpret_cast<float4*>(ap + LANE_ACT_SC) = make_float4(A.eta, A.Fb[0], A.Fb[1], A.Fb[2]);
+                ap[LANE_ACT_SC + 4] = A.rn;
+            }
+        }
+        float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
+        l = FMA(a.C.res_mult * A.eta, A.eta, l);
+        J = FMA(sm.disc[t], l, J);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        if (t + 1 < H) {
+#pragma unroll
+            for (int i = 0; i < NN; ++i) xi[i] = xin[i];
+        }
+        if (lane == 0) {
+            float* tp = tj + (size_t)(t + 1) * NX * 32;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) tp[i * 32] = x[i];
+        }
+    }
+    if (lane == 0) prow[PS - 1] = J + 0.0f;
+    // ---- adjoint sweep (x holds x_H); loads of step t-1 are in flight while step t is processed ----
+    float lam[NX], xt[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) lam[i] = 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    float nh1, nh2, nrn, nxt[NX], nxi[NN];
+    float4 ns4;
+    auto issue_loads = [&](int t) {
+        const float* ap = ac + (size_t)t * ACT_STRIDE;
+        nh1 = ap[LANE_ACT_H1 + lane];
+        nh2 = ap[LANE_ACT_H2 + lane];
+        ns4 = *reinterpret_cast<const float4*>(ap + LANE_ACT_SC);
+        nrn = ap[LANE_ACT_SC + 4];
+        const float* tp = tj + (size_t)t * NX * 32;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) nxt[i] = tp[i * 32];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) nxi[i] = nz[(t * NN + i) * 32];
+    };
+    issue_loads(H - 1);
+    for (int t = H - 1; t >= 0; --t) {
+        const float h1 = nh1, h2 = nh2;
+        A.eta = ns4.x; A.Fb[0] = ns4.y; A.Fb[1] = ns4.z; A.Fb[2] = ns4.w; A.rn = nrn;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xt[i] = nxt[i];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) xi[i] = nxi[i];
+        if (t > 0) issue_loads(t - 1);
+        const float dsc = sm.disc[t];
+        {
+            float gx[NX];
+            stage_cost<true>(a, x, sm.xref + (t + 1) * NX, gx);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lam[i] = FMA(dsc, gx[i], lam[i]);
+        }
+        float zdummy[NN];
+        fwd_head(xt, A.Rm, zdummy);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) A.Jom[i] = a.M.J[i] * xt[10 + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) A.qn[i] = x[6 + i];
+        const float ebc = dsc * ((2.0f * a.C.res_mult) * A.eta);
+        float lamn[NX], gq[12], zb[NN];
+        VjpTmp T;
+        vjp_head<M>(a, sm, t, xt, xi, A, lam, ebc, T, gq);
+        lane_vjp_mlp<M>(W, lane, h1, h2, T, zb, gq);
+        vjp_tail(sm, t, xt, A, lam, T, zb, lamn);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { lam[i] = lamn[i]; x[i] = xt[i]; }
+        if (lane == 0) {
+#pragma unroll
+            for (int kq = 0; kq < nq; ++kq) prow[t * 12 + kq] = gq[kq] + 0.0f;
+        }
+    }
+    Team::sync();
+    const float tot = group_ordered_sum(prow, 1, PS, PS - 1);
+    const int N = H * m;
+    for (int e = tid; e < N; e += Team::NT) {
+        int t = e / m, jj = e - t * m;
+        float S[5];
+        int idx[5] = {jj, M, M + 1, M + 2, M + 3};
+#pragma unroll
+        for (int kq = 0; kq < 5; ++kq) S[kq] = group_ordered_sum(prow, 1, PS, t * 12 + idx[kq]);
+        float uj = y[e];
+        float dT = FMA(2.0f * a.M.ct2, uj, a.M.ct1);
+        float dM = a.M.dir[jj] * FMA(2.0f * a.M.cm2, uj, a.M.cm1);
+        float acc = S[0];
+        acc = FMA(S[1], dT, acc);
+        acc = FMA(S[2], a.M.ry[jj] * dT, acc);
+        acc = FMA(S[3], -(a.M.rx[jj] * dT), acc);
+        acc = FMA(S[4], dM, acc);
+        float du = uj - a.C.uref[jj];
+        float dw = 0.0f, ctmp;
+        if (t >= 1) dw = slew_dw(a, y, t, jj, m, ctmp);
+        float gcu = sm.disc[t] * FMA(2.0f * a.C.uerr, du, dw);
+        if (t + 1 < H) { float dwn = slew_dw(a, y, t + 1, jj, m, ctmp); gcu = FMA(-sm.disc[t + 1], dwn, gcu); }
+        gout[e] = FMA(acc, a.invP, gcu);
+    }
+    Team::sync();
+    return FMA(tot, a.invP, cu);
+}
+
 // ------------------------------------------------------------------------------------------------
 // block-level rollout: expected cost of control sequence u (LDS). SPEC.md §5.3/§6/§7
 //   store_traj: stream x_t to a.traj; want_mean: particle mean trajectory -> xmean_out (global)
@@ -1156,6 +1507,18 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     return FMA(tot, a.invP, cu);
 }
 
+// tile layout (32 particles per wave) or the single-particle lane layout
+template <class Team, bool F16, bool PK, bool LANE>
+DI float team_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
+    if constexpr (LANE) return lane_rollout<Team>(a, sm, LW, u, b, tid, store_traj, xmean_out);
+    else return block_rollout<Team, F16, PK>(a, sm, ww, u, b, tid, store_traj, xmean_out);
+}
+template <class Team, int M, bool F16, bool PK, bool PREF, bool LANE>
+DI float team_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, const float* y, float* gout, int b, int tid) {
+    if constexpr (LANE) return lane_cost_grad<Team, M>(a, sm, LW, y, gout, b, tid);
+    else return block_cost_grad<Team, M, F16, PK, PREF>(a, sm, ww, y, gout, b, tid);
+}
+
 template <class Team>
 DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     for (int i = tid; i < (a.H + 1) * NX; i += Team::NT) sm.xref[i] = a.xref[(size_t)b * (a.H + 1) * NX + i];
@@ -1166,6 +1529,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
 // ------------------------------------------------------------------------------------------------
 // Common kernel prologue: carve LDS, stage weights (whole workgroup), then each team takes its instance.
 #define SDEMPC_KERNEL_PROLOGUE()                                                     \
+    LaneW LW;                                                                        \
     extern __shared__ __attribute__((aligned(16))) float smem[];                     \
     const int tid = Team::tid(), b = __builtin_amdgcn_readfirstlane(blockIdx.x * Team::IPB + Team::team()); \
     Smem sm = carve(smem, a.H, a.m, Team::team());                                   \
@@ -1173,23 +1537,24 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     load_weights(a, sm, ww, threadIdx.x, Team::BNT);                                 \
     __syncthreads();                                                                 \
     if (b >= a.B) return; /* no workgroup-wide barrier below this line in TeamWave */ \
+    if constexpr (LANE) load_lane_weights(a, LW, threadIdx.x & 63);                  \
     load_common<Team>(a, sm, b, tid);
 
-template <class Team, bool F16>
-__global__ void __launch_bounds__(Team::BNT, 3) sdempc_rollout_kernel(KArgs a) {
+template <class Team, bool F16, bool LANE = false>
+__global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : 3)) sdempc_rollout_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
-    float c = block_rollout<Team, F16>(a, sm, ww, sm.v[5], b, tid, a.store_traj != 0, a.xmean ? a.xmean + (size_t)b * (a.H + 1) * NX : nullptr);
+    float c = team_rollout<Team, F16, false, LANE>(a, sm, ww, LW, sm.v[5], b, tid, a.store_traj != 0, a.xmean ? a.xmean + (size_t)b * (a.H + 1) * NX : nullptr);
     if (tid == 0) a.cost[b] = c;
 }
 
-template <class Team, int M, bool F16>
-__global__ void __launch_bounds__(Team::BNT, 3) sdempc_grad_kernel(KArgs a) {
+template <class Team, int M, bool F16, bool LANE = false>
+__global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : 3)) sdempc_grad_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
-    float c = block_cost_grad<Team, M, F16, false, false>(a, sm, ww, sm.v[5], sm.v[3], b, tid);   // three waves per SIMD, no prefetch buffer
+    float c = team_cost_grad<Team, M, F16, false, false, LANE>(a, sm, ww, LW, sm.v[5], sm.v[3], b, tid);   // tiles: three waves per SIMD, no prefetch buffer
     if (tid == 0) a.cost[b] = c;
     for (int e = tid; e < N; e += Team::NT) a.grad[(size_t)b * N + e] = sm.v[3][e];
 }
@@ -1200,8 +1565,9 @@ __global__ void __launch_bounds__(Team::BNT, 3) sdempc_grad_kernel(KArgs a) {
 // fit, the compiler spills only solver state around them; +6 % at C2 over two waves per SIMD with the prefetch buffer). The
 // latency instantiation (PK) and the one-wave teams (LDS allows two workgroups per CU anyway) keep two.
 template <class Team, bool PK> constexpr int solve_waves_per_simd() { return PK ? 2 : 3; }
-template <class Team, int M, bool F16, bool PK = false>
-__global__ void __launch_bounds__(Team::BNT, (solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
+// LANE: single-particle layout (P == 1): weights in VGPRs, two waves per SIMD
+template <class Team, int M, bool F16, bool PK = false, bool LANE = false>
+__global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int m = a.m, N = a.H * m;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
@@ -1210,11 +1576,11 @@ __global__ void __launch_bounds__(Team::BNT, (solve_waves_per_simd<Team, PK>()))
         float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
         xk[e] = v; yk[e] = v;
     }
-    const float c_init = block_rollout<Team, F16, PK>(a, sm, ww, xk, b, tid, false, nullptr);
+    const float c_init = team_rollout<Team, F16, PK, LANE>(a, sm, ww, LW, xk, b, tid, false, nullptr);
     float c_x = c_init, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f;
     int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1;
     for (int k = 0; k < a.A.max_iter; ++k) {
-        const float c_y = block_cost_grad<Team, M, F16, PK, solve_waves_per_simd<Team, PK>() == 2>(a, sm, ww, yk, g, b, tid);
+        const float c_y = team_cost_grad<Team, M, F16, PK, solve_waves_per_simd<Team, PK>() == 2, LANE>(a, sm, ww, LW, yk, g, b, tid);
         gsq = block_dot<Team>(sm, g, g, N, tid);
         if (!(gsq < __builtin_inff())) break;   // SPEC.md §8 non-finite guard (team-uniform): keep xk, report gsq
         float c_n = 0.0f;
@@ -1229,7 +1595,7 @@ __global__ void __launch_bounds__(Team::BNT, (solve_waves_per_simd<Team, PK>()))
                     float v = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
                     xn[e] = v; d1[e] = v - yk[e];
                 }
-                c_n = block_rollout<Team, F16, PK>(a, sm, ww, xn, b, tid, false, nullptr);
+                c_n = team_rollout<Team, F16, PK, LANE>(a, sm, ww, LW, xn, b, tid, false, nullptr);
                 float gd = block_dot<Team>(sm, g, d1, N, tid);
                 nls = jl + 1;
                 if (c_n <= FMA(a.A.coef, gd, c_y)) break;
@@ -1239,7 +1605,7 @@ __global__ void __launch_bounds__(Team::BNT, (solve_waves_per_simd<Team, PK>()))
             s = a.A.stepsize;
             Team::sync();
             for (int e = tid; e < N; e += Team::NT) { int jj = e % m; xn[e] = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]); }
-            c_n = block_rollout<Team, F16, PK>(a, sm, ww, xn, b, tid, false, nullptr);
+            c_n = team_rollout<Team, F16, PK, LANE>(a, sm, ww, LW, xn, b, tid, false, nullptr);
             nls = 1;
         }
         sum_ls = sum_ls + (float)nls; sum_s = sum_s + s; nit = k + 1; nls_tot += nls;
@@ -1268,7 +1634,7 @@ __global__ void __launch_bounds__(Team::BNT, (solve_waves_per_simd<Team, PK>()))
     }
     Team::sync();
     for (int e = tid; e < N; e += Team::NT) a.uopt[(size_t)b * N + e] = xk[e];
-    block_rollout<Team, F16, PK>(a, sm, ww, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
+    team_rollout<Team, F16, PK, LANE>(a, sm, ww, LW, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
     if (tid == 0) {
         float* inf = a.info + (size_t)b * 8;
         const float fn = (float)nit;
@@ -1341,17 +1707,37 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
     if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, F16>, a, st, Team::IPB);
     return launch_k(sdempc_solve_kernel<Team, 8, F16>, a, st, Team::IPB);
 }
+// Single-particle lane layout: exact f32 arithmetic only, one wave per instance (SDEMPC_LANE=0 forces the tile layout: A/B, tests)
+static bool use_lane(const KArgs& k) {
+    if (FAST || k.f16 || k.P != 1 || !use_wave_team(k.G, k.H, k.m)) return false;
+    static const char* force = getenv("SDEMPC_LANE");
+    return !(force && force[0] == '0');
+}
+template <int M>
+static hipError_t launch_lane(int what, const KArgs& k, hipStream_t st) {
+    if (what == 0) return launch_k(sdempc_rollout_kernel<TeamWave, false, true>, k, st, TeamWave::IPB);
+    if (what == 1) return launch_k(sdempc_grad_kernel<TeamWave, M, false, true>, k, st, TeamWave::IPB);
+    return launch_k(sdempc_solve_kernel<TeamWave, M, false, false, true>, k, st, TeamWave::IPB);
+}
+static hipError_t launch_lane_m(int what, const KArgs& k, hipStream_t st) {
+    if (k.m == 4) return launch_lane<4>(what, k, st);
+    if (k.m == 6) return launch_lane<6>(what, k, st);
+    return launch_lane<8>(what, k, st);
+}
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B;
+    if (use_lane(k)) return launch_lane_m(0, k, st);
     return use_wave_team(k.G, k.H, k.m) ? launch_rollout_team<TeamWave>(k, st) : launch_rollout_team<TeamBlock>(k, st);
 }
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B;
+    if (use_lane(k)) return launch_lane_m(1, k, st);
     if (use_wave_team(k.G, k.H, k.m)) return k.f16 ? launch_grad_team<TeamWave, true>(k, st) : launch_grad_team<TeamWave, false>(k, st);
     return k.f16 ? launch_grad_team<TeamBlock, true>(k, st) : launch_grad_team<TeamBlock, false>(k, st);
 }
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B;
+    if (use_lane(k)) return launch_lane_m(2, k, st);
     if (use_wave_team(k.G, k.H, k.m)) return k.f16 ? launch_solve_team<TeamWave, true>(k, st) : launch_solve_team<TeamWave, false>(k, st);
     return k.f16 ? launch_solve_team<TeamBlock, true>(k, st) : launch_solve_team<TeamBlock, false>(k, st);
 }

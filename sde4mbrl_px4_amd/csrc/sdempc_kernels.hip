@@ -958,9 +958,14 @@ DI void lane_fwd_mlp(const KArgs& a, const LaneW& W, const float* ust, int lane,
     h1 = lane_tanh(a1, lane);
     float a2 = W.b2k;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; r += 4) {      // eight lanes are read ahead of their fma chain (a read right before its use costs a wait state)
+        float sv[8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { const int kk = rowmap(r, h); a2 = FMA(W.w2row[kk], readlane_f(h1, kk), a2); }
+        for (int e = 0; e < 8; ++e) sv[e] = readlane_f(h1, rowmap(r + (e >> 1), e & 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a2 = FMA(W.w2row[rowmap(r + (e >> 1), e & 1)], sv[e], a2);
+        __builtin_amdgcn_sched_barrier(0);
     }
     h2 = lane_tanh(a2, lane);
     const float Mreg = hh ? h1 : h2;     // lanes 0..31: layer-2 activations, lanes 32..63: density hidden units
@@ -983,9 +988,14 @@ DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp&
     const float a2b = hb * FMA(-h2, h2, 1.0f);
     float accB = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; r += 4) {
+        float sv[8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) { const int i = rowmap(r, h); accB = FMA(W.w2col[i], readlane_f(a2b, i), accB); }
+        for (int e = 0; e < 8; ++e) sv[e] = readlane_f(a2b, rowmap(r + (e >> 1), e & 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) accB = FMA(W.w2col[rowmap(r + (e >> 1), e & 1)], sv[e], accB);
+        __builtin_amdgcn_sched_barrier(0);
     }
     const float g1 = FMA(-h1, h1, 1.0f);
     const float ad = accB * g1;
@@ -1713,6 +1723,9 @@ static bool use_lane(const KArgs& k) {
     static const char* force = getenv("SDEMPC_LANE");
     return !(force && force[0] == '0');
 }
+#if SDEMPC_FAST
+static hipError_t launch_lane_m(int, const KArgs&, hipStream_t) { return hipErrorInvalidValue; }   // never selected (use_lane)
+#else
 template <int M>
 static hipError_t launch_lane(int what, const KArgs& k, hipStream_t st) {
     if (what == 0) return launch_k(sdempc_rollout_kernel<TeamWave, false, true>, k, st, TeamWave::IPB);
@@ -1724,6 +1737,7 @@ static hipError_t launch_lane_m(int what, const KArgs& k, hipStream_t st) {
     if (k.m == 6) return launch_lane<6>(what, k, st);
     return launch_lane<8>(what, k, st);
 }
+#endif
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B;
     if (use_lane(k)) return launch_lane_m(0, k, st);

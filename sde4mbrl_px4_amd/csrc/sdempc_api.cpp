@@ -62,6 +62,9 @@ struct sdempc_handle {
     DevBuf d_part, d_act, d_traj, d_x0, d_u, d_xref, d_noise, d_step, d_cost, d_grad, d_xmean, d_uopt, d_info;
     // canonical-layout staging of the host-pointer entry points (allocated on their first use)
     DevBuf d_noise_canon, d_traj_canon, d_keys;
+    // cooperative latency path of the solve (allocated on its first use, sized for coop_cap instances)
+    DevBuf d_coop_bar, d_coop_pp, d_coop_ck;
+    int coop_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -311,13 +314,13 @@ namespace {
 void release_device(sdempc_handle* h) {
     if (h->dev_ready || h->stream || h->d_dt.p) {
         (void)hipSetDevice(h->device);
-        for (DevBuf* b : {&h->d_part, &h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys,
+        for (DevBuf* b : {&h->d_part, &h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys, &h->d_coop_bar, &h->d_coop_pp, &h->d_coop_ck,
                           &h->d_step, &h->d_cost, &h->d_grad, &h->d_xmean, &h->d_uopt, &h->d_info})
             dev_free(*b);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
         if (h->stream) (void)hipStreamDestroy(h->stream);
-        h->ev0 = h->ev1 = nullptr; h->stream = nullptr;
+        h->ev0 = h->ev1 = nullptr; h->stream = nullptr; h->coop_cap = 0;
     }
     h->dev_ready = false; h->timed = false;
 }
@@ -409,6 +412,23 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
     a.x0 = (const float*)x0_dev; a.u = (const float*)u_init_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
     a.stepsize_in = (const float*)stepsize_dev; a.uopt = (float*)uopt_dev; a.xmean = (float*)xevol_dev; a.info = (float*)info_dev;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    // Small batches of multi-particle instances: one instance over ceil(P/4) workgroups, one particle per wave (latency path).
+    // Same results bit for bit; only taken when every workgroup of the grid is resident at once.
+    const int cmax = (!a.fast && !a.f16) ? coop_max_instances(h->P, h->H, h->m) : 0;
+    if (B <= cmax) {
+        if (!h->d_coop_bar.p) {
+            const int cap = cmax < h->max_batch ? cmax : h->max_batch;
+            if ((rc = dev_alloc(h, h->d_coop_bar, sizeof(unsigned) * 2 * (size_t)cap))) return rc;
+            if ((rc = dev_alloc(h, h->d_coop_pp, sizeof(float) * coop_pp_floats(h->H, h->G) * cap))) return rc;
+            if ((rc = dev_alloc(h, h->d_coop_ck, sizeof(float) * coop_ck_floats(h->H, h->P) * cap))) return rc;
+            h->coop_cap = cap;
+        }
+        if (B <= h->coop_cap) {
+            HIPCHK(h, hipMemsetAsync(h->d_coop_bar.p, 0, sizeof(unsigned) * 2 * (size_t)B, st));
+            a.coop_bar = (unsigned*)h->d_coop_bar.p; a.coop_pp = (float*)h->d_coop_pp.p; a.coop_ck = (float*)h->d_coop_ck.p;
+            return timed_launch(h, st, [&] { return launch_solve_coop(a, B, st); });
+        }
+    }
     return timed_launch(h, st, [&] { return a.fast ? launch_solve_fast(a, B, st) : launch_solve(a, B, st); });
 }
 

@@ -51,6 +51,11 @@ struct KArgs {
     float* info;               // [B][8] raw: sum_ls, stepsize, nit, grad_sqr, sum_s, c_init, c_opt, nls_total
     int store_traj;
     int f16;                   // SPEC.md §9: fp16-operand MLP contractions in the forward step
+    // cooperative latency path (one instance over coop_nwg workgroups; workspace owned by the handle, see sdempc_api.cpp)
+    int coop_nwg;
+    unsigned* coop_bar;        // [B][2]: arrival counter, error flag (zeroed before every launch)
+    float* coop_pp;            // [B][2][part_stride(H)][G*32]
+    float* coop_ck;            // [B][P][H+1][160]
     int fast;                  // SPEC.md §10: hardware transcendentals (selects the fastm translation unit; host-side switch)
 };
 
@@ -64,6 +69,13 @@ __host__ __device__ inline int part_stride(int H) { const int a = H * 12, b = (H
 #endif
 constexpr int ACT_STRIDE = 1280 + 1024 * SDEMPC_CKPT1;
 size_t smem_bytes(int H, int m, int ipb);   // ipb: instances (teams) per workgroup
+// Cooperative latency path of the solve (exact f32, P >= 2): workgroups per instance, workspace sizes, launcher.
+// coop_max_instances: how many instances fit one workgroup per CU on the current device (0 = path unavailable for this shape)
+int coop_nwg(int P);
+int coop_max_instances(int P, int H, int m);
+size_t coop_pp_floats(int H, int G);           // per instance
+size_t coop_ck_floats(int H, int P);           // per instance
+hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st);
 int team_ipb(int G, int H, int m);            // 4 when one wave owns an instance (G == 1 and LDS permits), else 1
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st);

@@ -229,11 +229,12 @@ struct Smem {
     float *xref;                                       // [H+1][13]
     float *dt, *sdt, *disc;                            // [H], [H][6], [H+1]
     float *red;                                        // [16] block-reduction scratch
+    float *tot;                                        // cooperative path only: [H*12] particle sums of the adjoint outputs
     float *v[6];                                       // N-vectors: 0 xk, 1 yk, 2 xn, 3 g, 4 d1, 5 ucur
 };
 constexpr int UST = 36;
 
-DI Smem carve(float* base, int H, int m, int team) {
+DI Smem carve(float* base, int H, int m, int team, bool coop = false) {
     Smem s;
     float* p = base;
     // ---- shared by every team of the workgroup ----
@@ -258,12 +259,14 @@ DI Smem carve(float* base, int H, int m, int team) {
     s.xref = p; p += ((H + 1) * NX + 3) & ~3;
     s.red = p; p += 16;
     for (int i = 0; i < 6; ++i) { s.v[i] = p; p += nv; }
+    s.tot = p;                       // only the cooperative kernel (one team per workgroup) reserves it: see smem_bytes
+    (void)coop;
     return s;
 }
-size_t smem_bytes(int H, int m, int ipb) {
+size_t smem_bytes(int H, int m, int ipb, bool coop = false) {
     size_t shared = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + 2 * HID * HID + 512 + ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3);
     size_t per_team = (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
-    return (shared + ipb * per_team) * sizeof(float);
+    return (shared + ipb * per_team + (coop ? (size_t)((H * 12 + 3) & ~3) : 0)) * sizeof(float);
 }
 
 // blob float payload offsets (SPEC.md §2)
@@ -1017,33 +1020,36 @@ DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp&
     for (int jj = 0; jj < M; ++jj) gq[jj] = readlane_f(Pc, 16 + jj);
 }
 
-constexpr int LANE_ACT_H1 = 0, LANE_ACT_H2 = 64, LANE_ACT_SC = 128;   // offsets inside one ACT_STRIDE row of the checkpoint
+constexpr int LANE_ACT_H1 = 0, LANE_ACT_H2 = 64, LANE_ACT_SC = 128, LANE_ACT_X = 136;   // offsets inside one checkpoint row
+constexpr int COOP_ROW = 160;      // floats per (particle, step) checkpoint row of the cooperative path: h1[64] h2[64] scalars[8] x_t[13] pad
 
-template <class Team>
-DI float lane_rollout(const KArgs& a, const Smem& sm, const LaneW& W, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
-    b = opaque_s(b); tid = opaque_v(tid);
-    const int H = a.H, lane = tid & 63;
-    const bool want_mean = xmean_out != nullptr;
-    Team::sync();
-    block_prepass<Team>(a, sm, u, tid);
-    const int PS = part_stride(H);
-    float* prow = a.part + (size_t)b * PS;                      // G == 1
-    float cu = block_ucost<Team>(a, sm, u, tid);
-    const float* nz = a.noise + ((size_t)b * H) * NN * 32;      // particle 0 sits in column 0 of the 32-wide rows
-    float* tj = a.traj + ((size_t)b * (H + 1)) * NX * 32;
+// Where one particle's streams live (the same device functions serve the P == 1 team and the cooperative multi-workgroup path)
+struct LaneIO {
+    const float* x0;          // [13]
+    const float* nz;          // noise: element (t, i) at nz[(t*6 + i) * 32]
+    float* xs; int xs_t, xs_i;   // x_t kept for the adjoint / traj output: element (t, i) at xs[t*xs_t + i*xs_i]
+    float* ck; int ck_t;      // checkpoint rows: row t at ck + t*ck_t
+    float* out; int os;       // per-particle outputs: quantity q at out[q*os]  (q: t*12+k adjoint sums, t*13+i states, PS-1 cost)
+    bool add0;                // P == 1: store v + 0.0f (what the SPEC.md §6.1 butterfly over 31 zero lanes leaves)
+};
+DI float out_val(const LaneIO& io, float v) { return io.add0 ? v + 0.0f : v; }
+
+// one particle: rollout and cost; store_x: stream x_t to io.xs, want_mean: x_t to io.out
+DI void lane_particle_rollout(const KArgs& a, const Smem& sm, const LaneW& W, const LaneIO& io, int lane, bool store_x, bool want_mean) {
+    const int H = a.H, PS = part_stride(H);
     float x[NX], xn[NX], xi[NN];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = a.x0[b * NX + i];
+    for (int i = 0; i < NX; ++i) x[i] = io.x0[i];
 #pragma unroll
-    for (int i = 0; i < NN; ++i) xi[i] = nz[i * 32];
+    for (int i = 0; i < NN; ++i) xi[i] = io.nz[i * 32];
     if (lane == 0) {
-        if (store_traj) {
+        if (store_x) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) tj[i * 32] = x[i];
+            for (int i = 0; i < NX; ++i) io.xs[i * io.xs_i] = x[i];
         }
         if (want_mean) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) prow[i] = x[i] + 0.0f;     // the 32-lane butterfly with 31 zero lanes: v + 0
+            for (int i = 0; i < NX; ++i) io.out[(size_t)i * io.os] = out_val(io, x[i]);
         }
     }
     float J = 0.0f;
@@ -1052,7 +1058,7 @@ DI float lane_rollout(const KArgs& a, const Smem& sm, const LaneW& W, const floa
         float xin[NN];
         if (t + 1 < H) {
 #pragma unroll
-            for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
+            for (int i = 0; i < NN; ++i) xin[i] = io.nz[((t + 1) * NN + i) * 32];
         }
         const float* ust = sm.ust + t * UST;
         float z[NN], h1, h2, o[6], eta;
@@ -1069,55 +1075,41 @@ DI float lane_rollout(const KArgs& a, const Smem& sm, const LaneW& W, const floa
             for (int i = 0; i < NN; ++i) xi[i] = xin[i];
         }
         if (lane == 0) {
-            if (store_traj) {
-                float* tp = tj + (size_t)(t + 1) * NX * 32;
+            if (store_x) {
+                float* tp = io.xs + (size_t)(t + 1) * io.xs_t;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) tp[i * 32] = x[i];
+                for (int i = 0; i < NX; ++i) tp[i * io.xs_i] = x[i];
             }
             if (want_mean) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) prow[(t + 1) * NX + i] = x[i] + 0.0f;
+                for (int i = 0; i < NX; ++i) io.out[(size_t)((t + 1) * NX + i) * io.os] = out_val(io, x[i]);
             }
         }
     }
-    if (lane == 0) prow[PS - 1] = J + 0.0f;
-    Team::sync();
-    const float tot = group_ordered_sum(prow, 1, PS, PS - 1);
-    if (want_mean)
-        for (int i = tid; i < (H + 1) * NX; i += Team::NT) xmean_out[i] = group_ordered_sum(prow, 1, PS, i) * a.invP;
-    return FMA(tot, a.invP, cu);
+    if (lane == 0) io.out[(size_t)(PS - 1) * io.os] = out_val(io, J);
 }
 
-template <class Team, int M>
-DI float lane_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, const float* y, float* gout, int b, int tid) {
-    b = opaque_s(b); tid = opaque_v(tid);
-    const int H = a.H, m = a.m, lane = tid & 63;
+// one particle: cost, forward sweep with checkpoint, adjoint sweep; per-step adjoint outputs gq[0..M+3] -> io.out
+template <int M>
+DI void lane_particle_grad(const KArgs& a, const Smem& sm, const LaneW& W, const LaneIO& io, int lane) {
+    const int H = a.H, PS = part_stride(H);
     constexpr int nq = M + 4;
-    Team::sync();
-    block_prepass<Team>(a, sm, y, tid);
-    const int PS = part_stride(H);
-    float* prow = a.part + (size_t)b * PS;
-    float cu = block_ucost<Team>(a, sm, y, tid);
-    const float* nz = a.noise + ((size_t)b * H) * NN * 32;
-    float* tj = a.traj + ((size_t)b * (H + 1)) * NX * 32;
-    float* ac = a.act + ((size_t)b * H) * ACT_STRIDE;
     float x[NX], xn[NX], xi[NN];
     StepAux A;
-    // ---- forward sweep: x_t, the two hidden activations per lane and five step scalars are checkpointed ----
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = a.x0[b * NX + i];
+    for (int i = 0; i < NX; ++i) x[i] = io.x0[i];
 #pragma unroll
-    for (int i = 0; i < NN; ++i) xi[i] = nz[i * 32];
+    for (int i = 0; i < NN; ++i) xi[i] = io.nz[i * 32];
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) tj[i * 32] = x[i];
+        for (int i = 0; i < NX; ++i) io.xs[i * io.xs_i] = x[i];
     }
     float J = 0.0f;
     for (int t = 0; t < H; ++t) {
         float xin[NN];
         if (t + 1 < H) {
 #pragma unroll
-            for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
+            for (int i = 0; i < NN; ++i) xin[i] = io.nz[((t + 1) * NN + i) * 32];
         }
         const float* ust = sm.ust + t * UST;
         float z[NN], h1, h2, o[6], eta;
@@ -1125,7 +1117,7 @@ DI float lane_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, const fl
         lane_fwd_mlp(a, W, ust, lane, z, h1, h2, o, eta);
         fwd_tail(a, sm, ust, t, x, xi, A.Rm, o, eta, xn, A);
         {
-            float* ap = ac + (size_t)t * ACT_STRIDE;
+            float* ap = io.ck + (size_t)t * io.ck_t;
             ap[LANE_ACT_H1 + lane] = h1;
             ap[LANE_ACT_H2 + lane] = h2;
             if (lane == 0) {
@@ -1143,12 +1135,12 @@ DI float lane_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, const fl
             for (int i = 0; i < NN; ++i) xi[i] = xin[i];
         }
         if (lane == 0) {
-            float* tp = tj + (size_t)(t + 1) * NX * 32;
+            float* tp = io.xs + (size_t)(t + 1) * io.xs_t;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) tp[i * 32] = x[i];
+            for (int i = 0; i < NX; ++i) tp[i * io.xs_i] = x[i];
         }
     }
-    if (lane == 0) prow[PS - 1] = J + 0.0f;
+    if (lane == 0) io.out[(size_t)(PS - 1) * io.os] = out_val(io, J);
     // ---- adjoint sweep (x holds x_H); loads of step t-1 are in flight while step t is processed ----
     float lam[NX], xt[NX];
 #pragma unroll
@@ -1157,16 +1149,16 @@ DI float lane_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, const fl
     float nh1, nh2, nrn, nxt[NX], nxi[NN];
     float4 ns4;
     auto issue_loads = [&](int t) {
-        const float* ap = ac + (size_t)t * ACT_STRIDE;
+        const float* ap = io.ck + (size_t)t * io.ck_t;
         nh1 = ap[LANE_ACT_H1 + lane];
         nh2 = ap[LANE_ACT_H2 + lane];
         ns4 = *reinterpret_cast<const float4*>(ap + LANE_ACT_SC);
         nrn = ap[LANE_ACT_SC + 4];
-        const float* tp = tj + (size_t)t * NX * 32;
+        const float* tp = io.xs + (size_t)t * io.xs_t;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) nxt[i] = tp[i * 32];
+        for (int i = 0; i < NX; ++i) nxt[i] = tp[i * io.xs_i];
 #pragma unroll
-        for (int i = 0; i < NN; ++i) nxi[i] = nz[(t * NN + i) * 32];
+        for (int i = 0; i < NN; ++i) nxi[i] = io.nz[(t * NN + i) * 32];
     };
     issue_loads(H - 1);
     for (int t = H - 1; t >= 0; --t) {
@@ -1200,18 +1192,21 @@ DI float lane_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, const fl
         for (int i = 0; i < NX; ++i) { lam[i] = lamn[i]; x[i] = xt[i]; }
         if (lane == 0) {
 #pragma unroll
-            for (int kq = 0; kq < nq; ++kq) prow[t * 12 + kq] = gq[kq] + 0.0f;
+            for (int kq = 0; kq < nq; ++kq) io.out[(size_t)(t * 12 + kq) * io.os] = out_val(io, gq[kq]);
         }
     }
-    Team::sync();
-    const float tot = group_ordered_sum(prow, 1, PS, PS - 1);
-    const int N = H * m;
+}
+
+// SPEC.md §5.5 gradient assembly from the particle sums S(t, k) (shared by the lane and cooperative teams)
+template <class Team, int M, class SumF>
+DI void assemble_gradient(const KArgs& a, const Smem& sm, const float* y, float* gout, int tid, SumF&& Ssum) {
+    const int H = a.H, m = a.m, N = H * m;
     for (int e = tid; e < N; e += Team::NT) {
         int t = e / m, jj = e - t * m;
         float S[5];
         int idx[5] = {jj, M, M + 1, M + 2, M + 3};
 #pragma unroll
-        for (int kq = 0; kq < 5; ++kq) S[kq] = group_ordered_sum(prow, 1, PS, t * 12 + idx[kq]);
+        for (int kq = 0; kq < 5; ++kq) S[kq] = Ssum(t * 12 + idx[kq]);
         float uj = y[e];
         float dT = FMA(2.0f * a.M.ct2, uj, a.M.ct1);
         float dM = a.M.dir[jj] * FMA(2.0f * a.M.cm2, uj, a.M.cm1);
@@ -1227,6 +1222,167 @@ DI float lane_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, const fl
         if (t + 1 < H) { float dwn = slew_dw(a, y, t + 1, jj, m, ctmp); gcu = FMA(-sm.disc[t + 1], dwn, gcu); }
         gout[e] = FMA(acc, a.invP, gcu);
     }
+}
+
+// ---- P == 1 team: one wave per instance ----
+DI LaneIO lane_io_p1(const KArgs& a, int b) {
+    const int H = a.H, PS = part_stride(H);
+    LaneIO io;
+    io.x0 = a.x0 + (size_t)b * NX;
+    io.nz = a.noise + ((size_t)b * H) * NN * 32;              // particle 0 sits in column 0 of the 32-wide rows
+    io.xs = a.traj + ((size_t)b * (H + 1)) * NX * 32; io.xs_t = NX * 32; io.xs_i = 32;
+    io.ck = a.act + ((size_t)b * H) * ACT_STRIDE; io.ck_t = ACT_STRIDE;
+    io.out = a.part + (size_t)b * PS; io.os = 1;
+    io.add0 = true;
+    return io;
+}
+template <class Team>
+DI float lane_rollout(const KArgs& a, const Smem& sm, const LaneW& W, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
+    b = opaque_s(b); tid = opaque_v(tid);
+    const int H = a.H, lane = tid & 63, PS = part_stride(H);
+    const bool want_mean = xmean_out != nullptr;
+    Team::sync();
+    block_prepass<Team>(a, sm, u, tid);
+    float cu = block_ucost<Team>(a, sm, u, tid);
+    const LaneIO io = lane_io_p1(a, b);
+    lane_particle_rollout(a, sm, W, io, lane, store_traj, want_mean);
+    Team::sync();
+    const float tot = group_ordered_sum(io.out, 1, PS, PS - 1);
+    if (want_mean)
+        for (int i = tid; i < (H + 1) * NX; i += Team::NT) xmean_out[i] = group_ordered_sum(io.out, 1, PS, i) * a.invP;
+    return FMA(tot, a.invP, cu);
+}
+template <class Team, int M>
+DI float lane_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, const float* y, float* gout, int b, int tid) {
+    b = opaque_s(b); tid = opaque_v(tid);
+    const int H = a.H, lane = tid & 63, PS = part_stride(H);
+    Team::sync();
+    block_prepass<Team>(a, sm, y, tid);
+    float cu = block_ucost<Team>(a, sm, y, tid);
+    const LaneIO io = lane_io_p1(a, b);
+    lane_particle_grad<M>(a, sm, W, io, lane);
+    Team::sync();
+    const float tot = group_ordered_sum(io.out, 1, PS, PS - 1);
+    assemble_gradient<Team, M>(a, sm, y, gout, tid, [&](int q) { return group_ordered_sum(io.out, 1, PS, q); });
+    Team::sync();
+    return FMA(tot, a.invP, cu);
+}
+
+// ================================================================================================
+// Cooperative latency path: ONE instance spread over ceil(P/4) workgroups, one particle per wave in the lane layout, so a
+// step costs ~560 instructions per wave instead of ~1,300 + 22 MFMAs for a 32-particle tile. Every workgroup runs the
+// optimiser redundantly on identical data (deterministic, so all copies agree and take the same branches); the only
+// exchange is the per-particle outputs of a rollout, written particle-minor to a global array, followed by one grid barrier
+// per rollout; each workgroup then applies the SPEC.md §6.1 butterflies and slot order itself (bit-identical to the tile path).
+// Launched only when all workgroups of the batch are co-resident (B * ceil(P/4) <= number of CUs); every spin is bounded.
+// ================================================================================================
+struct CoopCtx {
+    int nwg, wgi, Ppad;
+    unsigned* bar;          // this instance's arrival counter (zeroed by the host before the launch), bar[1] = error flag
+    unsigned epoch;
+    float* pp;              // [2][PS][Ppad] per-particle outputs, double-buffered by rollout parity
+    float* ck;              // [P][H+1][COOP_ROW] checkpoint rows
+};
+constexpr unsigned COOP_SPIN_LIMIT = 40u * 1000u * 1000u;
+
+DI void coop_barrier(CoopCtx& C, int tid) {
+    __syncthreads();                                   // every wave of this workgroup has issued its stores (and waited for them)
+    C.epoch += 1;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(C.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = C.epoch * (unsigned)C.nwg;
+        unsigned spins = 0;
+        while (__hip_atomic_load(C.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(C.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;      // another workgroup gave up
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > COOP_SPIN_LIMIT) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// total of quantity q over the particles: SPEC.md §6.1 (32-particle butterflies, slots g mod 4 in ascending g, ((S0+S1)+S2)+S3);
+// a wave reduces two groups per pass (lanes 0..31 group g, lanes 32..63 group g + 1). Result valid in every lane.
+DI float coop_total(const float* pq, int P, int G, int lane) {
+    const int hh = lane >> 5, j = lane & 31;
+    float Sa = 0.0f, Sb = 0.0f;                       // lower half: slots 0 / 2, upper half: slots 1 / 3
+    for (int g0 = 0; g0 < G; g0 += 2) {
+        const int p = 32 * (g0 + hh) + j;
+        const float v = (g0 + hh < G && p < P) ? pq[p] : 0.0f;
+        const float T = group_bfly32(v);
+        if ((g0 >> 1) & 1) Sb = Sb + T; else Sa = Sa + T;
+    }
+    const float S0 = readlane_f(Sa, 0), S1 = readlane_f(Sa, 32), S2 = readlane_f(Sb, 0), S3 = readlane_f(Sb, 32);
+    return ((S0 + S1) + S2) + S3;
+}
+
+DI LaneIO lane_io_coop(const KArgs& a, const CoopCtx& C, int b, int p) {
+    const int H = a.H;
+    LaneIO io;
+    io.x0 = a.x0 + (size_t)b * NX;
+    io.nz = a.noise + ((size_t)(b * a.G + (p >> 5)) * H) * NN * 32 + (p & 31);
+    io.ck = C.ck + (size_t)p * (H + 1) * COOP_ROW; io.ck_t = COOP_ROW;     // H + 1 rows: row t also carries x_t, t = 0..H
+    io.xs = io.ck + LANE_ACT_X; io.xs_t = COOP_ROW; io.xs_i = 1;
+    io.out = C.pp + (size_t)(C.epoch & 1u) * part_stride(H) * C.Ppad + p; io.os = C.Ppad;
+    io.add0 = false;
+    return io;
+}
+
+template <class Team>
+DI float coop_rollout(const KArgs& a, const Smem& sm, const LaneW& W, CoopCtx& C, const float* u, int b, int tid, float* xmean_out) {
+    b = opaque_s(b); tid = opaque_v(tid);
+    const int H = a.H, P = a.P, G = a.G, lane = tid & 63, wave = tid >> 6, PS = part_stride(H);
+    const bool want_mean = xmean_out != nullptr;
+    Team::sync();
+    block_prepass<Team>(a, sm, u, tid);
+    float cu = block_ucost<Team>(a, sm, u, tid);
+    const int p = C.wgi * 4 + wave;
+    const float* pbuf = C.pp + (size_t)(C.epoch & 1u) * PS * C.Ppad;
+    if (p < P) {
+        const LaneIO io = lane_io_coop(a, C, b, p);
+        lane_particle_rollout(a, sm, W, io, lane, false, want_mean);
+    }
+    coop_barrier(C, tid);
+    if (wave == 0) { const float t0 = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, P, G, lane); if (lane == 0) sm.red[12] = t0; }
+    if (want_mean && C.wgi == 0) {      // the mean trajectory is an output only: one workgroup writes it
+        for (int q = wave; q < (H + 1) * NX; q += 4) {
+            const float s = coop_total(pbuf + (size_t)q * C.Ppad, P, G, lane);
+            if (lane == 0) xmean_out[q] = s * a.invP;
+        }
+    }
+    Team::sync();
+    return FMA(sm.red[12], a.invP, cu);
+}
+
+template <class Team, int M>
+DI float coop_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, CoopCtx& C, const float* y, float* gout, int b, int tid) {
+    b = opaque_s(b); tid = opaque_v(tid);
+    const int H = a.H, P = a.P, G = a.G, lane = tid & 63, wave = tid >> 6, PS = part_stride(H);
+    constexpr int nq = M + 4;
+    Team::sync();
+    block_prepass<Team>(a, sm, y, tid);
+    float cu = block_ucost<Team>(a, sm, y, tid);
+    const int p = C.wgi * 4 + wave;
+    const float* pbuf = C.pp + (size_t)(C.epoch & 1u) * PS * C.Ppad;
+    if (p < P) {
+        const LaneIO io = lane_io_coop(a, C, b, p);
+        lane_particle_grad<M>(a, sm, W, io, lane);
+    }
+    coop_barrier(C, tid);
+    // particle sums of the nq adjoint outputs of every step -> LDS (wave w takes the steps t = w, w + 4, ...)
+    if (wave == 0) { const float t0 = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, P, G, lane); if (lane == 0) sm.red[12] = t0; }
+    for (int t = wave; t < H; t += 4) {
+#pragma unroll
+        for (int kq = 0; kq < nq; ++kq) {
+            const float s = coop_total(pbuf + (size_t)(t * 12 + kq) * C.Ppad, P, G, lane);
+            if (lane == 0) sm.tot[t * 12 + kq] = s;
+        }
+    }
+    Team::sync();
+    const float tot = sm.red[12];
+    assemble_gradient<Team, M>(a, sm, y, gout, tid, [&](int q) { return sm.tot[q]; });
     Team::sync();
     return FMA(tot, a.invP, cu);
 }
@@ -1517,15 +1673,18 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     return FMA(tot, a.invP, cu);
 }
 
-// tile layout (32 particles per wave) or the single-particle lane layout
-template <class Team, bool F16, bool PK, bool LANE>
-DI float team_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
-    if constexpr (LANE) return lane_rollout<Team>(a, sm, LW, u, b, tid, store_traj, xmean_out);
+// MODE 0: tile layout (32 particles per wave); 1: single-particle lane layout (P == 1); 2: cooperative lane layout (one particle per
+// wave, one instance over several workgroups)
+template <class Team, bool F16, bool PK, int MODE>
+DI float team_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, CoopCtx& CC, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
+    if constexpr (MODE == 2) return coop_rollout<Team>(a, sm, LW, CC, u, b, tid, xmean_out);
+    else if constexpr (MODE == 1) return lane_rollout<Team>(a, sm, LW, u, b, tid, store_traj, xmean_out);
     else return block_rollout<Team, F16, PK>(a, sm, ww, u, b, tid, store_traj, xmean_out);
 }
-template <class Team, int M, bool F16, bool PK, bool PREF, bool LANE>
-DI float team_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, const float* y, float* gout, int b, int tid) {
-    if constexpr (LANE) return lane_cost_grad<Team, M>(a, sm, LW, y, gout, b, tid);
+template <class Team, int M, bool F16, bool PK, bool PREF, int MODE>
+DI float team_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, CoopCtx& CC, const float* y, float* gout, int b, int tid) {
+    if constexpr (MODE == 2) return coop_cost_grad<Team, M>(a, sm, LW, CC, y, gout, b, tid);
+    else if constexpr (MODE == 1) return lane_cost_grad<Team, M>(a, sm, LW, y, gout, b, tid);
     else return block_cost_grad<Team, M, F16, PK, PREF>(a, sm, ww, y, gout, b, tid);
 }
 
@@ -1539,32 +1698,44 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
 // ------------------------------------------------------------------------------------------------
 // Common kernel prologue: carve LDS, stage weights (whole workgroup), then each team takes its instance.
 #define SDEMPC_KERNEL_PROLOGUE()                                                     \
-    LaneW LW;                                                                        \
     extern __shared__ __attribute__((aligned(16))) float smem[];                     \
-    const int tid = Team::tid(), b = __builtin_amdgcn_readfirstlane(blockIdx.x * Team::IPB + Team::team()); \
-    Smem sm = carve(smem, a.H, a.m, Team::team());                                   \
+    LaneW LW;                                                                        \
+    CoopCtx CC;                                                                      \
+    const int tid = Team::tid();                                                     \
+    int b_;                                                                          \
+    if constexpr (MODE == 2) {                                                       \
+        b_ = blockIdx.x / a.coop_nwg;                                                \
+        CC.nwg = a.coop_nwg; CC.wgi = blockIdx.x - b_ * a.coop_nwg; CC.Ppad = a.G * 32; CC.epoch = 0u;            \
+        CC.bar = a.coop_bar + 2 * b_;                                                \
+        CC.pp = a.coop_pp + (size_t)b_ * 2 * part_stride(a.H) * CC.Ppad;             \
+        CC.ck = a.coop_ck + (size_t)b_ * a.P * (a.H + 1) * COOP_ROW;                 \
+    } else {                                                                         \
+        b_ = blockIdx.x * Team::IPB + Team::team();                                  \
+    }                                                                                \
+    const int b = __builtin_amdgcn_readfirstlane(b_);                                \
+    Smem sm = carve(smem, a.H, a.m, Team::team(), MODE == 2);                        \
     WaveW ww;                                                                        \
     load_weights(a, sm, ww, threadIdx.x, Team::BNT);                                 \
     __syncthreads();                                                                 \
     if (b >= a.B) return; /* no workgroup-wide barrier below this line in TeamWave */ \
-    if constexpr (LANE) load_lane_weights(a, LW, threadIdx.x & 63);                  \
+    if constexpr (MODE != 0) load_lane_weights(a, LW, threadIdx.x & 63);             \
     load_common<Team>(a, sm, b, tid);
 
-template <class Team, bool F16, bool LANE = false>
-__global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : 3)) sdempc_rollout_kernel(KArgs a) {
+template <class Team, bool F16, int MODE = 0>
+__global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_rollout_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
-    float c = team_rollout<Team, F16, false, LANE>(a, sm, ww, LW, sm.v[5], b, tid, a.store_traj != 0, a.xmean ? a.xmean + (size_t)b * (a.H + 1) * NX : nullptr);
+    float c = team_rollout<Team, F16, false, MODE>(a, sm, ww, LW, CC, sm.v[5], b, tid, a.store_traj != 0, a.xmean ? a.xmean + (size_t)b * (a.H + 1) * NX : nullptr);
     if (tid == 0) a.cost[b] = c;
 }
 
-template <class Team, int M, bool F16, bool LANE = false>
-__global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : 3)) sdempc_grad_kernel(KArgs a) {
+template <class Team, int M, bool F16, int MODE = 0>
+__global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_grad_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
-    float c = team_cost_grad<Team, M, F16, false, false, LANE>(a, sm, ww, LW, sm.v[5], sm.v[3], b, tid);   // tiles: three waves per SIMD, no prefetch buffer
+    float c = team_cost_grad<Team, M, F16, false, false, MODE>(a, sm, ww, LW, CC, sm.v[5], sm.v[3], b, tid);   // tiles: three waves per SIMD, no prefetch buffer
     if (tid == 0) a.cost[b] = c;
     for (int e = tid; e < N; e += Team::NT) a.grad[(size_t)b * N + e] = sm.v[3][e];
 }
@@ -1575,9 +1746,9 @@ __global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : 3)) sdempc_grad_kernel(
 // fit, the compiler spills only solver state around them; +6 % at C2 over two waves per SIMD with the prefetch buffer). The
 // latency instantiation (PK) and the one-wave teams (LDS allows two workgroups per CU anyway) keep two.
 template <class Team, bool PK> constexpr int solve_waves_per_simd() { return PK ? 2 : 3; }
-// LANE: single-particle layout (P == 1): weights in VGPRs, two waves per SIMD
-template <class Team, int M, bool F16, bool PK = false, bool LANE = false>
-__global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
+// MODE 1 / 2: lane layouts (weights in VGPRs, two waves per SIMD)
+template <class Team, int M, bool F16, bool PK = false, int MODE = 0>
+__global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int m = a.m, N = a.H * m;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
@@ -1586,11 +1757,11 @@ __global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : solve_waves_per_simd<Te
         float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
         xk[e] = v; yk[e] = v;
     }
-    const float c_init = team_rollout<Team, F16, PK, LANE>(a, sm, ww, LW, xk, b, tid, false, nullptr);
+    const float c_init = team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xk, b, tid, false, nullptr);
     float c_x = c_init, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f;
     int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1;
     for (int k = 0; k < a.A.max_iter; ++k) {
-        const float c_y = team_cost_grad<Team, M, F16, PK, solve_waves_per_simd<Team, PK>() == 2, LANE>(a, sm, ww, LW, yk, g, b, tid);
+        const float c_y = team_cost_grad<Team, M, F16, PK, solve_waves_per_simd<Team, PK>() == 2, MODE>(a, sm, ww, LW, CC, yk, g, b, tid);
         gsq = block_dot<Team>(sm, g, g, N, tid);
         if (!(gsq < __builtin_inff())) break;   // SPEC.md §8 non-finite guard (team-uniform): keep xk, report gsq
         float c_n = 0.0f;
@@ -1605,7 +1776,7 @@ __global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : solve_waves_per_simd<Te
                     float v = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
                     xn[e] = v; d1[e] = v - yk[e];
                 }
-                c_n = team_rollout<Team, F16, PK, LANE>(a, sm, ww, LW, xn, b, tid, false, nullptr);
+                c_n = team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xn, b, tid, false, nullptr);
                 float gd = block_dot<Team>(sm, g, d1, N, tid);
                 nls = jl + 1;
                 if (c_n <= FMA(a.A.coef, gd, c_y)) break;
@@ -1615,7 +1786,7 @@ __global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : solve_waves_per_simd<Te
             s = a.A.stepsize;
             Team::sync();
             for (int e = tid; e < N; e += Team::NT) { int jj = e % m; xn[e] = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]); }
-            c_n = team_rollout<Team, F16, PK, LANE>(a, sm, ww, LW, xn, b, tid, false, nullptr);
+            c_n = team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xn, b, tid, false, nullptr);
             nls = 1;
         }
         sum_ls = sum_ls + (float)nls; sum_s = sum_s + s; nit = k + 1; nls_tot += nls;
@@ -1643,9 +1814,10 @@ __global__ void __launch_bounds__(Team::BNT, (LANE ? 2 : solve_waves_per_simd<Te
         if (stop) break;
     }
     Team::sync();
-    for (int e = tid; e < N; e += Team::NT) a.uopt[(size_t)b * N + e] = xk[e];
-    team_rollout<Team, F16, PK, LANE>(a, sm, ww, LW, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
-    if (tid == 0) {
+    if (MODE != 2 || CC.wgi == 0)
+        for (int e = tid; e < N; e += Team::NT) a.uopt[(size_t)b * N + e] = xk[e];
+    team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
+    if (tid == 0 && (MODE != 2 || CC.wgi == 0)) {
         float* inf = a.info + (size_t)b * 8;
         const float fn = (float)nit;
         inf[0] = nit ? sum_ls / fn : 0.0f; inf[1] = s; inf[2] = fn; inf[3] = gsq; inf[4] = nit ? sum_s / fn : 0.0f;
@@ -1728,9 +1900,9 @@ static hipError_t launch_lane_m(int, const KArgs&, hipStream_t) { return hipErro
 #else
 template <int M>
 static hipError_t launch_lane(int what, const KArgs& k, hipStream_t st) {
-    if (what == 0) return launch_k(sdempc_rollout_kernel<TeamWave, false, true>, k, st, TeamWave::IPB);
-    if (what == 1) return launch_k(sdempc_grad_kernel<TeamWave, M, false, true>, k, st, TeamWave::IPB);
-    return launch_k(sdempc_solve_kernel<TeamWave, M, false, false, true>, k, st, TeamWave::IPB);
+    if (what == 0) return launch_k(sdempc_rollout_kernel<TeamWave, false, 1>, k, st, TeamWave::IPB);
+    if (what == 1) return launch_k(sdempc_grad_kernel<TeamWave, M, false, 1>, k, st, TeamWave::IPB);
+    return launch_k(sdempc_solve_kernel<TeamWave, M, false, false, 1>, k, st, TeamWave::IPB);
 }
 static hipError_t launch_lane_m(int what, const KArgs& k, hipStream_t st) {
     if (k.m == 4) return launch_lane<4>(what, k, st);
@@ -1738,6 +1910,35 @@ static hipError_t launch_lane_m(int what, const KArgs& k, hipStream_t st) {
     return launch_lane<8>(what, k, st);
 }
 #endif
+#if !SDEMPC_FAST
+// ---- cooperative latency path (exact arithmetic only) ----
+int coop_nwg(int P) { return (P + 3) / 4; }
+int coop_max_instances(int P, int H, int m) {
+    static const char* force = getenv("SDEMPC_COOP");           // "0" disables the path (A/B, tests)
+    if ((force && force[0] == '0') || P < 2) return 0;
+    if (smem_bytes(H, m, 1, true) > 160 * 1024) return 0;
+    return device_cus() / coop_nwg(P);                          // one workgroup per CU: every workgroup of the grid is resident
+}
+size_t coop_pp_floats(int H, int G) { return (size_t)2 * part_stride(H) * G * 32; }
+size_t coop_ck_floats(int H, int P) { return (size_t)P * (H + 1) * COOP_ROW; }
+template <int M>
+static hipError_t launch_coop_m(const KArgs& k, hipStream_t st) {
+    auto kern = sdempc_solve_kernel<TeamBlock, M, false, false, 2>;
+    const size_t sb = smem_bytes(k.H, k.m, 1, true);
+    hipError_t e = set_smem_attr((const void*)kern, sb);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(k.B * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);
+    return hipGetLastError();
+}
+hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st) {
+    KArgs k = a; k.B = B; k.coop_nwg = coop_nwg(k.P);
+    if (B < 1 || B > coop_max_instances(k.P, k.H, k.m) || !k.coop_bar || !k.coop_pp || !k.coop_ck) return hipErrorInvalidValue;
+    if (k.m == 4) return launch_coop_m<4>(k, st);
+    if (k.m == 6) return launch_coop_m<6>(k, st);
+    return launch_coop_m<8>(k, st);
+}
+#endif
+
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B;
     if (use_lane(k)) return launch_lane_m(0, k, st);
@@ -1813,6 +2014,11 @@ int team_ipb(int G, int H, int m) { return exact::team_ipb(G, H, m); }
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) { return exact::launch_rollout(a, B, st); }
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st) { return exact::launch_grad(a, B, st); }
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st) { return exact::launch_solve(a, B, st); }
+int coop_nwg(int P) { return exact::coop_nwg(P); }
+int coop_max_instances(int P, int H, int m) { return exact::coop_max_instances(P, H, m); }
+size_t coop_pp_floats(int H, int G) { return exact::coop_pp_floats(H, G); }
+size_t coop_ck_floats(int H, int P) { return exact::coop_ck_floats(H, P); }
+hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st) { return exact::launch_solve_coop(a, B, st); }
 hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int P, int G, int C, hipStream_t st) {
     return exact::launch_relayout(to_dev, in, out, B, P, G, C, st);
 }

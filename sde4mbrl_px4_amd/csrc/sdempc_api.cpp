@@ -68,6 +68,7 @@ struct sdempc_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int last_coop_B = 0;      // > 0: the last solve launch took the cooperative path with this many instances (error flags to check)
 };
 
 namespace {
@@ -204,6 +205,16 @@ int noise_from_keys(sdempc_handle* h, int B, const uint32_t* keys, float* out_de
     if (!h->d_keys.p && (rc = dev_alloc(h, h->d_keys, sizeof(uint32_t) * 2 * (size_t)h->max_batch))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_keys.p, keys, sizeof(uint32_t) * 2 * (size_t)B, hipMemcpyHostToDevice, st));
     HIPCHK(h, launch_noise_from_keys((const uint32_t*)h->d_keys.p, out_dev, B, h->P, h->G, h->H, st));
+    return 0;
+}
+
+// after a synchronised cooperative solve: did any grid barrier give up? (telemetry is NaN in that case as well)
+int check_coop_flags(sdempc_handle* h) {
+    if (h->last_coop_B <= 0) return 0;
+    std::vector<unsigned> f(2 * (size_t)h->last_coop_B);
+    HIPCHK(h, hipMemcpy(f.data(), h->d_coop_bar.p, sizeof(unsigned) * f.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->last_coop_B; ++b)
+        if (f[2 * b + 1] != 0u) return fail(h, SDEMPC_EDEVICE, "cooperative solve: a grid barrier timed out (workgroups not co-resident?)%s");
     return 0;
 }
 
@@ -426,9 +437,11 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
         if (B <= h->coop_cap) {
             HIPCHK(h, hipMemsetAsync(h->d_coop_bar.p, 0, sizeof(unsigned) * 2 * (size_t)B, st));
             a.coop_bar = (unsigned*)h->d_coop_bar.p; a.coop_pp = (float*)h->d_coop_pp.p; a.coop_ck = (float*)h->d_coop_ck.p;
+            h->last_coop_B = B;
             return timed_launch(h, st, [&] { return launch_solve_coop(a, B, st); });
         }
     }
+    h->last_coop_B = 0;
     return timed_launch(h, st, [&] { return a.fast ? launch_solve_fast(a, B, st) : launch_solve(a, B, st); });
 }
 
@@ -512,7 +525,7 @@ int sdempc_solve_batch(sdempc_handle* h, int32_t B, const float* x0, const float
     HIPCHK(h, hipMemcpyAsync(xevol, h->d_xmean.p, sizeof(float) * B * (h->H + 1) * SDEMPC_NX, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof(float) * B * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return SDEMPC_OK;
+    return check_coop_flags(h);
 }
 
 int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const float* xref, const uint32_t* keys, const float* u_init,
@@ -533,7 +546,7 @@ int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const 
     HIPCHK(h, hipMemcpyAsync(xevol, h->d_xmean.p, sizeof(float) * B * (H + 1) * SDEMPC_NX, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof(float) * B * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    return SDEMPC_OK;
+    return check_coop_flags(h);
 }
 
 }  // extern "C"

@@ -1822,6 +1822,10 @@ __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : solve_waves_per_simd<Te
         const float fn = (float)nit;
         inf[0] = nit ? sum_ls / fn : 0.0f; inf[1] = s; inf[2] = fn; inf[3] = gsq; inf[4] = nit ? sum_s / fn : 0.0f;
         inf[5] = c_init; inf[6] = c_x; inf[7] = (float)nls_tot;
+        if constexpr (MODE == 2) {   // a grid barrier gave up (never seen in testing; bounded so that a fault cannot hang the GPU): poison the telemetry
+            if (__hip_atomic_load(CC.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                for (int i = 0; i < 8; ++i) inf[i] = __builtin_nanf("");
+        }
     }
 }
 

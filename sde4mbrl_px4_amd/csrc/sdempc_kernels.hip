@@ -1032,7 +1032,21 @@ struct LaneIO {
     float* out; int os;       // per-particle outputs: quantity q at out[q*os]  (q: t*12+k adjoint sums, t*13+i states, PS-1 cost)
     bool add0;                // P == 1: store v + 0.0f (what the SPEC.md §6.1 butterfly over 31 zero lanes leaves)
 };
-DI float out_val(const LaneIO& io, float v) { return io.add0 ? v + 0.0f : v; }
+// Cooperative path: the handed-off values are written and read with agent-scope (sc1) accesses, so the grid barrier needs no
+// L2 write-back / invalidate (the per-XCD L2s are not coherent with each other; a release fence would flush every dirty line of
+// the checkpoint stream as well). SDEMPC_COOP_FENCE=1 builds the fence-based variant instead (A/B).
+#ifndef SDEMPC_COOP_FENCE
+#define SDEMPC_COOP_FENCE 0
+#endif
+DI void out_store(const LaneIO& io, size_t q, float v) {
+    if (io.add0) io.out[q] = v + 0.0f;                 // P == 1 team (os == 1)
+    else if (SDEMPC_COOP_FENCE) io.out[q * io.os] = v;
+    else __hip_atomic_store(io.out + q * io.os, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DI float coop_load(const float* p) {
+    if (SDEMPC_COOP_FENCE) return *p;
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // one particle: rollout and cost; store_x: stream x_t to io.xs, want_mean: x_t to io.out
 DI void lane_particle_rollout(const KArgs& a, const Smem& sm, const LaneW& W, const LaneIO& io, int lane, bool store_x, bool want_mean) {
@@ -1049,7 +1063,7 @@ DI void lane_particle_rollout(const KArgs& a, const Smem& sm, const LaneW& W, co
         }
         if (want_mean) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) io.out[(size_t)i * io.os] = out_val(io, x[i]);
+            for (int i = 0; i < NX; ++i) out_store(io, i, x[i]);
         }
     }
     float J = 0.0f;
@@ -1082,11 +1096,11 @@ DI void lane_particle_rollout(const KArgs& a, const Smem& sm, const LaneW& W, co
             }
             if (want_mean) {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) io.out[(size_t)((t + 1) * NX + i) * io.os] = out_val(io, x[i]);
+                for (int i = 0; i < NX; ++i) out_store(io, (t + 1) * NX + i, x[i]);
             }
         }
     }
-    if (lane == 0) io.out[(size_t)(PS - 1) * io.os] = out_val(io, J);
+    if (lane == 0) out_store(io, PS - 1, J);
 }
 
 // one particle: cost, forward sweep with checkpoint, adjoint sweep; per-step adjoint outputs gq[0..M+3] -> io.out
@@ -1140,7 +1154,7 @@ DI void lane_particle_grad(const KArgs& a, const Smem& sm, const LaneW& W, const
             for (int i = 0; i < NX; ++i) tp[i * io.xs_i] = x[i];
         }
     }
-    if (lane == 0) io.out[(size_t)(PS - 1) * io.os] = out_val(io, J);
+    if (lane == 0) out_store(io, PS - 1, J);
     // ---- adjoint sweep (x holds x_H); loads of step t-1 are in flight while step t is processed ----
     float lam[NX], xt[NX];
 #pragma unroll
@@ -1192,7 +1206,7 @@ DI void lane_particle_grad(const KArgs& a, const Smem& sm, const LaneW& W, const
         for (int i = 0; i < NX; ++i) { lam[i] = lamn[i]; x[i] = xt[i]; }
         if (lane == 0) {
 #pragma unroll
-            for (int kq = 0; kq < nq; ++kq) io.out[(size_t)(t * 12 + kq) * io.os] = out_val(io, gq[kq]);
+            for (int kq = 0; kq < nq; ++kq) out_store(io, t * 12 + kq, gq[kq]);
         }
     }
 }
@@ -1286,10 +1300,11 @@ struct CoopCtx {
 constexpr unsigned COOP_SPIN_LIMIT = 40u * 1000u * 1000u;
 
 DI void coop_barrier(CoopCtx& C, int tid) {
-    __syncthreads();                                   // every wave of this workgroup has issued its stores (and waited for them)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's (sc1) stores of the handed-off values have completed
+    __syncthreads();
     C.epoch += 1;
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (SDEMPC_COOP_FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(C.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = C.epoch * (unsigned)C.nwg;
         unsigned spins = 0;
@@ -1298,7 +1313,7 @@ DI void coop_barrier(CoopCtx& C, int tid) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > COOP_SPIN_LIMIT) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (SDEMPC_COOP_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
@@ -1310,7 +1325,7 @@ DI float coop_total(const float* pq, int P, int G, int lane) {
     float Sa = 0.0f, Sb = 0.0f;                       // lower half: slots 0 / 2, upper half: slots 1 / 3
     for (int g0 = 0; g0 < G; g0 += 2) {
         const int p = 32 * (g0 + hh) + j;
-        const float v = (g0 + hh < G && p < P) ? pq[p] : 0.0f;
+        const float v = (g0 + hh < G && p < P) ? coop_load(pq + p) : 0.0f;
         const float T = group_bfly32(v);
         if ((g0 >> 1) & 1) Sb = Sb + T; else Sa = Sa + T;
     }
@@ -1373,11 +1388,35 @@ DI float coop_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, CoopCtx&
     coop_barrier(C, tid);
     // particle sums of the nq adjoint outputs of every step -> LDS (wave w takes the steps t = w, w + 4, ...)
     if (wave == 0) { const float t0 = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, P, G, lane); if (lane == 0) sm.red[12] = t0; }
-    for (int t = wave; t < H; t += 4) {
+    // all nq sums of a step are reduced together: the 2 x nq loads of a pass are independent and in flight at once (a load that
+    // crosses XCDs takes about a microsecond; one at a time they would dominate the gradient evaluation)
+    {
+        const int hh = lane >> 5, j = lane & 31;
+        for (int t = wave; t < H; t += 4) {
+            float Sa[nq], Sb[nq];
 #pragma unroll
-        for (int kq = 0; kq < nq; ++kq) {
-            const float s = coop_total(pbuf + (size_t)(t * 12 + kq) * C.Ppad, P, G, lane);
-            if (lane == 0) sm.tot[t * 12 + kq] = s;
+            for (int kq = 0; kq < nq; ++kq) { Sa[kq] = 0.0f; Sb[kq] = 0.0f; }
+            for (int g0 = 0; g0 < G; g0 += 4) {          // two passes (four groups) per chunk
+                float v0[nq], v1[nq];
+                const int pa = 32 * (g0 + hh) + j, pb = 32 * (g0 + 2 + hh) + j;
+                const bool oka = (g0 + hh < G) && pa < P, okb = (g0 + 2 + hh < G) && pb < P;
+#pragma unroll
+                for (int kq = 0; kq < nq; ++kq) {
+                    const float* pq = pbuf + (size_t)(t * 12 + kq) * C.Ppad;
+                    v0[kq] = oka ? coop_load(pq + pa) : 0.0f;
+                    v1[kq] = okb ? coop_load(pq + pb) : 0.0f;
+                }
+#pragma unroll
+                for (int kq = 0; kq < nq; ++kq) {
+                    Sa[kq] = Sa[kq] + group_bfly32(v0[kq]);                     // groups g0, g0+1 -> slots 0 / 1
+                    if (g0 + 2 < G) Sb[kq] = Sb[kq] + group_bfly32(v1[kq]);     // groups g0+2, g0+3 -> slots 2 / 3
+                }
+            }
+#pragma unroll
+            for (int kq = 0; kq < nq; ++kq) {
+                const float S0 = readlane_f(Sa[kq], 0), S1 = readlane_f(Sa[kq], 32), S2 = readlane_f(Sb[kq], 0), S3 = readlane_f(Sb[kq], 32);
+                if (lane == 0) sm.tot[t * 12 + kq] = ((S0 + S1) + S2) + S3;
+            }
         }
     }
     Team::sync();

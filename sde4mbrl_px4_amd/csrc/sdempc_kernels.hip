@@ -1913,7 +1913,7 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
     if constexpr (!F16 && !FAST) {
         // small-batch (latency) launches: one workgroup per CU at most -> a lone wave per SIMD is issue-bound -> packed tanh
         const int wgs = (a.B + Team::IPB - 1) / Team::IPB;
-        static const char* force = getenv("SDEMPC_PK");     // "0" / "1": A/B switch for tools and tests; unset: by grid size
+        const char* force = getenv("SDEMPC_PK");            // "0" / "1": A/B switch for tools and tests (read per launch); unset: by grid size
         const bool pk = force ? force[0] == '1' : wgs <= device_cus();
         if (pk) {
             if constexpr (Team::IPB == 1) {
@@ -1935,7 +1935,7 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
 // Single-particle lane layout: exact f32 arithmetic only, one wave per instance (SDEMPC_LANE=0 forces the tile layout: A/B, tests)
 static bool use_lane(const KArgs& k) {
     if (FAST || k.f16 || k.P != 1 || !use_wave_team(k.G, k.H, k.m)) return false;
-    static const char* force = getenv("SDEMPC_LANE");
+    const char* force = getenv("SDEMPC_LANE");
     return !(force && force[0] == '0');
 }
 #if SDEMPC_FAST
@@ -1957,7 +1957,7 @@ static hipError_t launch_lane_m(int what, const KArgs& k, hipStream_t st) {
 // ---- cooperative latency path (exact arithmetic only) ----
 int coop_nwg(int P) { return (P + 3) / 4; }
 int coop_max_instances(int P, int H, int m) {
-    static const char* force = getenv("SDEMPC_COOP");           // "0" disables the path (A/B, tests)
+    const char* force = getenv("SDEMPC_COOP");                  // "0" disables the path (A/B, tests; read per launch)
     if ((force && force[0] == '0') || P < 2) return 0;
     if (smem_bytes(H, m, 1, true) > 160 * 1024) return 0;
     return device_cus() / coop_nwg(P);                          // one workgroup per CU: every workgroup of the grid is resident

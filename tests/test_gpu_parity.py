@@ -17,6 +17,16 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4   # north_star tolerance (float32)
 
 
+@pytest.fixture(params=["auto", "tile"])
+def layout(request, monkeypatch):
+    """auto: the library picks the layout (single-particle lanes for P = 1, the cooperative one-particle-per-wave path for small batches,
+    32-particle tiles otherwise); tile: both alternatives switched off, so the same cases also pin the tile layout. All bit-identical."""
+    if request.param == "tile":
+        monkeypatch.setenv("SDEMPC_LANE", "0")
+        monkeypatch.setenv("SDEMPC_COOP", "0")
+    return request.param
+
+
 def _solver(cfg, model, B):
     from sde4mbrl_px4_amd.solver import SdeMpcSolver
     return SdeMpcSolver(cfg, model, max_batch=B)
@@ -27,7 +37,7 @@ def _close(a, b, what):
 
 
 @pytest.mark.parametrize("name", list(golden_cases().keys()))
-def test_golden_vectors(name):
+def test_golden_vectors(name, layout):
     cfg, model, seed, curr_t, pos = golden_cases()[name]
     g = load_golden(name)
     S = _solver(cfg, model, 1)
@@ -80,7 +90,7 @@ EDGE = {
 
 
 @pytest.mark.parametrize("name", list(EDGE.keys()))
-def test_edge_cases_bit_exact(name):
+def test_edge_cases_bit_exact(name, layout):
     kw = dict(u_slew_coeff=1.0, max_iter=8, max_no_improvement_iter=8)
     kw.update(EDGE[name])
     cfg = MPCConfig(**kw)
@@ -107,7 +117,7 @@ def test_edge_cases_bit_exact(name):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_random_configurations_bit_exact(seed):
+def test_random_configurations_bit_exact(seed, layout):
     """Randomised hyper-parameters (horizon, particles, motors, cost weights, time grid, optimiser knobs)."""
     rng = np.random.default_rng(1000 + seed)
     m = int(rng.choice([4, 6]))
@@ -145,7 +155,7 @@ def test_random_configurations_bit_exact(seed):
 
 
 @pytest.mark.parametrize("m", [1, 3, 5, 8])
-def test_generic_motor_count_bit_exact(m):
+def test_generic_motor_count_bit_exact(m, layout):
     """Motor counts other than 4 / 6 run the generic (8-slot, zero-padded) kernel instantiation."""
     cfg = MPCConfig(horizon=9, num_short_dt=9, num_particles=45, input_id=list(range(m)), input_bound=[[1e-4, 1.0]] * m, uref=[0.6] * m,
                     u_slew_coeff=0.5, max_iter=5, max_no_improvement_iter=5)
@@ -165,7 +175,7 @@ def test_generic_motor_count_bit_exact(m):
 
 
 @pytest.mark.parametrize("P", [32, 100])
-def test_diverging_rollout_non_finite_parity(P):
+def test_diverging_rollout_non_finite_parity(P, layout):
     """A rollout that overflows f32 (single-rotor vehicle, H=55): infinities and NaN positions agree with the oracle word for word,
     the solve takes no step on a NaN gradient (SPEC.md §8 guard) and the finite instance beside it is unaffected. P=32 runs the
     one-wave team, P=100 the four-wave team. Found by tests/tools/soak.py."""
@@ -219,7 +229,7 @@ def test_saturating_activations_and_violent_states_bit_exact():
     S.close()
 
 
-def test_hexa_six_motors_bit_exact():
+def test_hexa_six_motors_bit_exact(layout):
     cfg = load_mpc_config(os.path.join(CDIR, "c3_hexa_traj_h50_p256.yaml")).replace(horizon=14, num_short_dt=14, num_particles=96, max_iter=6, max_no_improvement_iter=6)
     model = synthetic_hexa()
     B = 2
@@ -236,7 +246,7 @@ def test_hexa_six_motors_bit_exact():
     S.close()
 
 
-def test_warm_start_chain_matches_oracle():
+def test_warm_start_chain_matches_oracle(layout):
     """Three consecutive ticks, each warm-started from the previous (uopt, stepsize) like mpc_process_fn
     (sde_control.py:412: opt_state is threaded through successive calls)."""
     cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(horizon=16, num_short_dt=16, num_particles=64, max_iter=10, max_no_improvement_iter=10)

@@ -1960,7 +1960,9 @@ int coop_max_instances(int P, int H, int m) {
     const char* force = getenv("SDEMPC_COOP");                  // "0" disables the path (A/B, tests; read per launch)
     if ((force && force[0] == '0') || P < 2) return 0;
     if (smem_bytes(H, m, 1, true) > 160 * 1024) return 0;
-    return device_cus() / coop_nwg(P);                          // one workgroup per CU: every workgroup of the grid is resident
+    // every workgroup of the grid must be resident at once: the kernel is built for two waves per SIMD, i.e. two workgroups per CU
+    // (its LDS footprint allows more); a margin of 16 workgroups is left
+    return (2 * device_cus() - 16) / coop_nwg(P);
 }
 size_t coop_pp_floats(int H, int G) { return (size_t)2 * part_stride(H) * G * 32; }
 size_t coop_ck_floats(int H, int P) { return (size_t)P * (H + 1) * COOP_ROW; }

@@ -438,6 +438,7 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
             HIPCHK(h, hipMemsetAsync(h->d_coop_bar.p, 0, sizeof(unsigned) * 2 * (size_t)B, st));
             a.coop_bar = (unsigned*)h->d_coop_bar.p; a.coop_pp = (float*)h->d_coop_pp.p; a.coop_ck = (float*)h->d_coop_ck.p;
             h->last_coop_B = B;
+            if (B <= spec_max_instances(h->P, h->H, h->m)) return timed_launch(h, st, [&] { return launch_solve_spec(a, B, st); });
             return timed_launch(h, st, [&] { return launch_solve_coop(a, B, st); });
         }
     }

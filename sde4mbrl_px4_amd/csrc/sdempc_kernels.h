@@ -76,6 +76,9 @@ int coop_max_instances(int P, int H, int m);
 size_t coop_pp_floats(int H, int G);           // per instance
 size_t coop_ck_floats(int H, int P);           // per instance
 hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st);
+// speculative variant for the smallest batches (4 groups of workgroups per instance: two trials and two candidate gradients at once)
+int spec_max_instances(int P, int H, int m);
+hipError_t launch_solve_spec(const KArgs& a, int B, hipStream_t st);
 int team_ipb(int G, int H, int m);            // 4 when one wave owns an instance (G == 1 and LDS permits), else 1
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st);

@@ -1785,9 +1785,9 @@ __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_grad_kernel(
 // fit, the compiler spills only solver state around them; +6 % at C2 over two waves per SIMD with the prefetch buffer). The
 // latency instantiation (PK) and the one-wave teams (LDS allows two workgroups per CU anyway) keep two.
 template <class Team, bool PK> constexpr int solve_waves_per_simd() { return PK ? 2 : 3; }
-// MODE 1 / 2: lane layouts (weights in VGPRs, two waves per SIMD)
+// MODE 1 / 2: lane layouts (weights in VGPRs, two waves per SIMD; MODE 2 with PK: one workgroup per CU, spills go to AGPRs)
 template <class Team, int M, bool F16, bool PK = false, int MODE = 0>
-__global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
+__global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : MODE ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE();
     const int m = a.m, N = a.H * m;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
@@ -2281,8 +2281,15 @@ hipError_t launch_solve_spec(const KArgs& a, int B, hipStream_t st) {
 }
 template <int M>
 static hipError_t launch_coop_m(const KArgs& k, hipStream_t st) {
-    auto kern = sdempc_solve_kernel<TeamBlock, M, false, false, 2>;
     const size_t sb = smem_bytes(k.H, k.m, 1, true);
+    if (k.B * k.coop_nwg <= device_cus()) {      // one workgroup per CU: the 512-register build (no scratch spills in the sweeps)
+        auto kern = sdempc_solve_kernel<TeamBlock, M, false, true, 2>;
+        hipError_t e = set_smem_attr((const void*)kern, sb);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(k.B * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);
+        return hipGetLastError();
+    }
+    auto kern = sdempc_solve_kernel<TeamBlock, M, false, false, 2>;
     hipError_t e = set_smem_attr((const void*)kern, sb);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(k.B * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);

@@ -53,6 +53,7 @@ struct KArgs {
     int f16;                   // SPEC.md §9: fp16-operand MLP contractions in the forward step
     // cooperative latency path (one instance over coop_nwg workgroups; workspace owned by the handle, see sdempc_api.cpp)
     int coop_nwg;
+    int coop_ngrp;             // speculative variant: groups of coop_nwg workgroups per instance (2..5)
     unsigned* coop_bar;        // [B][2]: arrival counter, error flag (zeroed before every launch)
     float* coop_pp;            // [B][2][part_stride(H)][G*32]
     float* coop_ck;            // [B][P][H+1][160]

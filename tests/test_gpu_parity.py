@@ -17,10 +17,13 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4   # north_star tolerance (float32)
 
 
-@pytest.fixture(params=["auto", "tile"])
+@pytest.fixture(params=["auto", "coop", "tile"])
 def layout(request, monkeypatch):
-    """auto: the library picks the layout (single-particle lanes for P = 1, the cooperative one-particle-per-wave path for small batches,
-    32-particle tiles otherwise); tile: both alternatives switched off, so the same cases also pin the tile layout. All bit-identical."""
+    """auto: the library picks (single-particle lanes for P = 1; for small batches the cooperative one-particle-per-wave path, in its
+    speculative form when two or more groups of workgroups fit; 32-particle tiles otherwise); coop: the speculative form switched off, which
+    pins the plain cooperative kernel; tile: every alternative off, which pins the tile layout on the same cases. All bit-identical."""
+    if request.param == "coop":
+        monkeypatch.setenv("SDEMPC_SPEC", "0")
     if request.param == "tile":
         monkeypatch.setenv("SDEMPC_LANE", "0")
         monkeypatch.setenv("SDEMPC_COOP", "0")

@@ -1323,11 +1323,12 @@ DI void coop_barrier(CoopCtx& C, int tid) {
 DI float coop_total(const float* pq, int P, int G, int lane) {
     const int hh = lane >> 5, j = lane & 31;
     float Sa = 0.0f, Sb = 0.0f;                       // lower half: slots 0 / 2, upper half: slots 1 / 3
-    for (int g0 = 0; g0 < G; g0 += 2) {
-        const int p = 32 * (g0 + hh) + j;
-        const float v = (g0 + hh < G && p < P) ? coop_load(pq + p) : 0.0f;
-        const float T = group_bfly32(v);
-        if ((g0 >> 1) & 1) Sb = Sb + T; else Sa = Sa + T;
+    for (int g0 = 0; g0 < G; g0 += 4) {               // four groups per chunk: both loads are in flight together
+        const int pa = 32 * (g0 + hh) + j, pb = 32 * (g0 + 2 + hh) + j;
+        const float va = ((g0 + hh < G) && pa < P) ? coop_load(pq + pa) : 0.0f;
+        const float vb = ((g0 + 2 + hh < G) && pb < P) ? coop_load(pq + pb) : 0.0f;
+        Sa = Sa + group_bfly32(va);
+        if (g0 + 2 < G) Sb = Sb + group_bfly32(vb);
     }
     const float S0 = readlane_f(Sa, 0), S1 = readlane_f(Sa, 32), S2 = readlane_f(Sb, 0), S3 = readlane_f(Sb, 32);
     return ((S0 + S1) + S2) + S3;
@@ -1959,7 +1960,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     CoopCtx C;
     C.nwg = per; C.wgi = r_ - grp * nwg; C.Ppad = a.G * 32; C.epoch = 0u;
     C.bar = a.coop_bar + 2 * b;
-    C.pp = a.coop_pp + (size_t)b * 2 * SPEC_SLOTS * PS * C.Ppad;
+    C.pp = a.coop_pp + (size_t)b * ((size_t)2 * SPEC_SLOTS * PS * C.Ppad + 2 * (size_t)PS);
     C.ck = a.coop_ck + ((size_t)b * 3 + (grp >= 2 ? grp - 2 : 0)) * a.P * (H + 1) * COOP_ROW;    // gradients run on groups 2..4 (or 0 when there are only two)
     Smem sm = carve(smem, H, m, 0, true);
     WaveW ww;
@@ -1978,7 +1979,12 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
         xk[e] = v; yk[e] = v;
     }
-    enum { PH_INIT, PH_GRAD, PH_PAR, PH_SEQ, PH_FINAL, PH_DONE };
+    // PH_RED: the particle sums of a gradient (H*nq totals + the cost total) are reduced ONCE, spread over all workgroups of the
+    // instance (one step each), published and read back after one more barrier — every workgroup reducing everything itself took
+    // ~45 us per iteration, a third of the time of an iteration
+    enum { PH_INIT, PH_GRAD, PH_PAR, PH_SEQ, PH_RED, PH_FINAL, PH_DONE };
+    float* gtot_base = C.pp + (size_t)2 * SPEC_SLOTS * PS * C.Ppad;       // [2][PS] published totals, after the per-particle slots
+    unsigned red_cnt = 0u, red_par = 0u; int red_slot = 0;
     int phase = PH_INIT;
     float c_init = 0.0f, c_x = 0.0f, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f, c_y = 0.0f, c_n = 0.0f;
     int k = 0, kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1, nls = 0, jsel = 0, jl = 0;
@@ -1989,7 +1995,22 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         // ---- this workgroup's work item of the phase ----
         const float* iu = xk; int islot = SLOT_SEQ; bool igrad = false, imean = false, iact = false;
         unsigned par = C.epoch & 1u;
-        if (phase == PH_INIT) { iact = grp == 0; }
+        if (phase == PH_RED) {
+            constexpr int nq = M + 4;
+            const float* pbuf = C.pp + (size_t)(red_par * SPEC_SLOTS + red_slot) * PS * C.Ppad;
+            float* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
+            for (int t = r_; t < H; t += per) {
+                for (int kq = wave; kq < nq; kq += 4) {
+                    const float sv = coop_total(pbuf + (size_t)(t * 12 + kq) * C.Ppad, a.P, a.G, lane);
+                    if (lane == 0) __hip_atomic_store(gt + t * 12 + kq, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (r_ == per - 1 && wave == 3) {      // the cost total: last workgroup (idle above unless per <= H)
+                const float sv = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, a.P, a.G, lane);
+                if (lane == 0) __hip_atomic_store(gt + PS - 1, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        else if (phase == PH_INIT) { iact = grp == 0; }
         else if (phase == PH_GRAD) { iact = grp == grad_grp; iu = yk; islot = SLOT_GRAD; igrad = true; }
         else if (phase == PH_SEQ) { iact = grp == 0; iu = xn; }
         else if (phase == PH_FINAL) { iact = grp == 0; imean = true; }
@@ -2021,8 +2042,19 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             c_x = c_init;
             phase = a.A.max_iter > 0 ? PH_GRAD : PH_FINAL;
         } else if (phase == PH_GRAD) {
-            c_y = spec_cost(a, sm, C, tid, par, yk, SLOT_GRAD);
-            spec_gradient<M>(a, sm, C, tid, par, yk, SLOT_GRAD, g);
+            red_slot = SLOT_GRAD; red_par = par; phase = PH_RED;
+        } else if (phase == PH_RED) {
+            constexpr int nq = M + 4;
+            const float* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
+            red_cnt += 1u;
+            for (int q = tid; q < H * 12; q += Team::NT)
+                if ((q % 12) < nq) sm.tot[q] = coop_load(gt + q);
+            if (tid == 0) sm.red[12] = coop_load(gt + PS - 1);
+            const float cu = block_ucost<Team>(a, sm, yk, tid);        // (contains the barriers that publish sm.tot / sm.red)
+            __syncthreads();
+            c_y = FMA(sm.red[12], a.invP, cu);
+            assemble_gradient<Team, M>(a, sm, yk, g, tid, [&](int q) { return sm.tot[q]; });
+            __syncthreads();
             head = true;
         } else if (phase == PH_PAR) {
             __syncthreads();
@@ -2121,12 +2153,8 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             if (noimp >= a.A.max_noimp) stop = 1;
             k += 1;
             if (stop || k >= a.A.max_iter) phase = PH_FINAL;
-            else if (hit_slot >= 0) {
-                __syncthreads();
-                c_y = spec_cost(a, sm, C, tid, par_spec, yk, hit_slot);
-                spec_gradient<M>(a, sm, C, tid, par_spec, yk, hit_slot, g);
-                head = true;
-            } else phase = PH_GRAD;
+            else if (hit_slot >= 0) { red_slot = hit_slot; red_par = par_spec; phase = PH_RED; }
+            else phase = PH_GRAD;
         }
         if (head) {      // start of iteration k with (c_y, g) in hand
             gsq = block_dot<Team>(sm, g, g, N, tid);
@@ -2260,7 +2288,7 @@ int coop_max_instances(int P, int H, int m) {
 }
 // per-instance workspace, sized for the speculative variant (7 output slots, 3 checkpoint regions); the plain cooperative kernel
 // uses a prefix of it
-size_t coop_pp_floats(int H, int G) { return (size_t)2 * SPEC_SLOTS * part_stride(H) * G * 32; }
+size_t coop_pp_floats(int H, int G) { return (size_t)2 * SPEC_SLOTS * part_stride(H) * G * 32 + 2 * (size_t)part_stride(H); }
 size_t coop_ck_floats(int H, int P) { return (size_t)3 * P * (H + 1) * COOP_ROW; }
 int spec_max_instances(int P, int H, int m) {
     const char* force = getenv("SDEMPC_SPEC");                  // "0" disables the speculative variant (A/B, tests; read per launch)

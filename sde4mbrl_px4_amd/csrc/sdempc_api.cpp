@@ -425,7 +425,9 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     // Small batches of multi-particle instances: one instance over ceil(P/4) workgroups, one particle per wave (latency path).
     // Same results bit for bit; only taken when every workgroup of the grid is resident at once.
-    const int cmax = (!a.fast && !a.f16) ? coop_max_instances(h->P, h->H, h->m) : 0;
+    const int smax = (!a.fast && !a.f16) ? spec_max_instances(h->P, h->H, h->m) : 0;
+    int cmax = (!a.fast && !a.f16) ? coop_max_instances(h->P, h->H, h->m) : 0;
+    if (smax > cmax) cmax = smax;
     if (B <= cmax) {
         if (!h->d_coop_bar.p) {
             const int cap = cmax < h->max_batch ? cmax : h->max_batch;
@@ -438,8 +440,9 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
             HIPCHK(h, hipMemsetAsync(h->d_coop_bar.p, 0, sizeof(unsigned) * 2 * (size_t)B, st));
             a.coop_bar = (unsigned*)h->d_coop_bar.p; a.coop_pp = (float*)h->d_coop_pp.p; a.coop_ck = (float*)h->d_coop_ck.p;
             h->last_coop_B = B;
-            if (B <= spec_max_instances(h->P, h->H, h->m)) return timed_launch(h, st, [&] { return launch_solve_spec(a, B, st); });
-            return timed_launch(h, st, [&] { return launch_solve_coop(a, B, st); });
+            if (B <= smax) return timed_launch(h, st, [&] { return launch_solve_spec(a, B, st); });
+            if (B <= coop_max_instances(h->P, h->H, h->m)) return timed_launch(h, st, [&] { return launch_solve_coop(a, B, st); });
+            h->last_coop_B = 0;
         }
     }
     h->last_coop_B = 0;

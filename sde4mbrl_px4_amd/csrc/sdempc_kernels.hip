@@ -2292,7 +2292,8 @@ size_t coop_pp_floats(int H, int G) { return (size_t)2 * SPEC_SLOTS * part_strid
 size_t coop_ck_floats(int H, int P) { return (size_t)3 * P * (H + 1) * COOP_ROW; }
 int spec_max_instances(int P, int H, int m) {
     const char* force = getenv("SDEMPC_SPEC");                  // "0" disables the speculative variant (A/B, tests; read per launch)
-    if ((force && force[0] == '0') || coop_max_instances(P, H, m) == 0) return 0;
+    const char* fc = getenv("SDEMPC_COOP");
+    if ((force && force[0] == '0') || (fc && fc[0] == '0')) return 0;      // P == 1 is welcome here (one wave per workgroup is active)
     const size_t nv = (size_t)((H * m + 3) & ~3);
     if (smem_bytes(H, m, 1, true) + 4 * nv * sizeof(float) > 160 * 1024) return 0;
     return device_cus() / (2 * coop_nwg(P));                    // built for one workgroup per CU; at least two groups per instance

@@ -1297,7 +1297,7 @@ struct CoopCtx {
     float* pp;              // [2][PS][Ppad] per-particle outputs, double-buffered by rollout parity
     float* ck;              // [P][H+1][COOP_ROW] checkpoint rows
 };
-constexpr unsigned COOP_SPIN_LIMIT = 40u * 1000u * 1000u;
+constexpr unsigned COOP_SPIN_LIMIT = 8u * 1000u * 1000u;     // polls of one barrier before giving up (several seconds)
 
 DI void coop_barrier(CoopCtx& C, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's (sc1) stores of the handed-off values have completed

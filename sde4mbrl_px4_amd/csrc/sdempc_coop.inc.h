@@ -1,0 +1,148 @@
+// sdempc_coop.inc.h — cooperative latency path: one instance over several workgroups, grid barrier, particle reductions
+// Fragment of sdempc_kernels.hip: included inside namespace sdempc::{exact|fastm} (it is compiled twice, see there); not a
+// stand-alone header.
+// ================================================================================================
+// Cooperative latency path: ONE instance spread over ceil(P/4) workgroups, one particle per wave in the lane layout, so a
+// step costs ~560 instructions per wave instead of ~1,300 + 22 MFMAs for a 32-particle tile. Every workgroup runs the
+// optimiser redundantly on identical data (deterministic, so all copies agree and take the same branches); the only
+// exchange is the per-particle outputs of a rollout, written particle-minor to a global array, followed by one grid barrier
+// per rollout; each workgroup then applies the SPEC.md §6.1 butterflies and slot order itself (bit-identical to the tile path).
+// Launched only when all workgroups of the batch are co-resident (B * ceil(P/4) <= number of CUs); every spin is bounded.
+// ================================================================================================
+struct CoopCtx {
+    int nwg, wgi, Ppad;
+    unsigned* bar;          // this instance's arrival counter (zeroed by the host before the launch), bar[1] = error flag
+    unsigned epoch;
+    float* pp;              // [2][PS][Ppad] per-particle outputs, double-buffered by rollout parity
+    float* ck;              // [P][H+1][COOP_ROW] checkpoint rows
+};
+constexpr unsigned COOP_SPIN_LIMIT = 8u * 1000u * 1000u;     // polls of one barrier before giving up (several seconds)
+
+DI void coop_barrier(CoopCtx& C, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's (sc1) stores of the handed-off values have completed
+    __syncthreads();
+    C.epoch += 1;
+    if (tid == 0) {
+        if (SDEMPC_COOP_FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(C.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = C.epoch * (unsigned)C.nwg;
+        unsigned spins = 0;
+        while (__hip_atomic_load(C.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(C.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;      // another workgroup gave up
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > COOP_SPIN_LIMIT) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        if (SDEMPC_COOP_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+// total of quantity q over the particles: SPEC.md §6.1 (32-particle butterflies, slots g mod 4 in ascending g, ((S0+S1)+S2)+S3);
+// a wave reduces two groups per pass (lanes 0..31 group g, lanes 32..63 group g + 1). Result valid in every lane.
+DI float coop_total(const float* pq, int P, int G, int lane) {
+    const int hh = lane >> 5, j = lane & 31;
+    float Sa = 0.0f, Sb = 0.0f;                       // lower half: slots 0 / 2, upper half: slots 1 / 3
+    for (int g0 = 0; g0 < G; g0 += 4) {               // four groups per chunk: both loads are in flight together
+        const int pa = 32 * (g0 + hh) + j, pb = 32 * (g0 + 2 + hh) + j;
+        const float va = ((g0 + hh < G) && pa < P) ? coop_load(pq + pa) : 0.0f;
+        const float vb = ((g0 + 2 + hh < G) && pb < P) ? coop_load(pq + pb) : 0.0f;
+        Sa = Sa + group_bfly32(va);
+        if (g0 + 2 < G) Sb = Sb + group_bfly32(vb);
+    }
+    const float S0 = readlane_f(Sa, 0), S1 = readlane_f(Sa, 32), S2 = readlane_f(Sb, 0), S3 = readlane_f(Sb, 32);
+    return ((S0 + S1) + S2) + S3;
+}
+
+DI LaneIO lane_io_coop(const KArgs& a, const CoopCtx& C, int b, int p) {
+    const int H = a.H;
+    LaneIO io;
+    io.x0 = a.x0 + (size_t)b * NX;
+    io.nz = a.noise + ((size_t)(b * a.G + (p >> 5)) * H) * NN * 32 + (p & 31);
+    io.ck = C.ck + (size_t)p * (H + 1) * COOP_ROW; io.ck_t = COOP_ROW;     // H + 1 rows: row t also carries x_t, t = 0..H
+    io.xs = io.ck + LANE_ACT_X; io.xs_t = COOP_ROW; io.xs_i = 1;
+    io.out = C.pp + (size_t)(C.epoch & 1u) * part_stride(H) * C.Ppad + p; io.os = C.Ppad;
+    io.add0 = false;
+    return io;
+}
+
+template <class Team>
+DI float coop_rollout(const KArgs& a, const Smem& sm, const LaneW& W, CoopCtx& C, const float* u, int b, int tid, float* xmean_out) {
+    b = opaque_s(b); tid = opaque_v(tid);
+    const int H = a.H, P = a.P, G = a.G, lane = tid & 63, wave = tid >> 6, PS = part_stride(H);
+    const bool want_mean = xmean_out != nullptr;
+    Team::sync();
+    block_prepass<Team>(a, sm, u, tid);
+    float cu = block_ucost<Team>(a, sm, u, tid);
+    const int p = C.wgi * 4 + wave;
+    const float* pbuf = C.pp + (size_t)(C.epoch & 1u) * PS * C.Ppad;
+    if (p < P) {
+        const LaneIO io = lane_io_coop(a, C, b, p);
+        lane_particle_rollout(a, sm, W, io, lane, false, want_mean);
+    }
+    coop_barrier(C, tid);
+    if (wave == 0) { const float t0 = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, P, G, lane); if (lane == 0) sm.red[12] = t0; }
+    if (want_mean && C.wgi == 0) {      // the mean trajectory is an output only: one workgroup writes it
+        for (int q = wave; q < (H + 1) * NX; q += 4) {
+            const float s = coop_total(pbuf + (size_t)q * C.Ppad, P, G, lane);
+            if (lane == 0) xmean_out[q] = s * a.invP;
+        }
+    }
+    Team::sync();
+    return FMA(sm.red[12], a.invP, cu);
+}
+
+template <class Team, int M>
+DI float coop_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, CoopCtx& C, const float* y, float* gout, int b, int tid) {
+    b = opaque_s(b); tid = opaque_v(tid);
+    const int H = a.H, P = a.P, G = a.G, lane = tid & 63, wave = tid >> 6, PS = part_stride(H);
+    constexpr int nq = M + 4;
+    Team::sync();
+    block_prepass<Team>(a, sm, y, tid);
+    float cu = block_ucost<Team>(a, sm, y, tid);
+    const int p = C.wgi * 4 + wave;
+    const float* pbuf = C.pp + (size_t)(C.epoch & 1u) * PS * C.Ppad;
+    if (p < P) {
+        const LaneIO io = lane_io_coop(a, C, b, p);
+        lane_particle_grad<M>(a, sm, W, io, lane);
+    }
+    coop_barrier(C, tid);
+    // particle sums of the nq adjoint outputs of every step -> LDS (wave w takes the steps t = w, w + 4, ...)
+    if (wave == 0) { const float t0 = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, P, G, lane); if (lane == 0) sm.red[12] = t0; }
+    // all nq sums of a step are reduced together: the 2 x nq loads of a pass are independent and in flight at once (a load that
+    // crosses XCDs takes about a microsecond; one at a time they would dominate the gradient evaluation)
+    {
+        const int hh = lane >> 5, j = lane & 31;
+        for (int t = wave; t < H; t += 4) {
+            float Sa[nq], Sb[nq];
+#pragma unroll
+            for (int kq = 0; kq < nq; ++kq) { Sa[kq] = 0.0f; Sb[kq] = 0.0f; }
+            for (int g0 = 0; g0 < G; g0 += 4) {          // two passes (four groups) per chunk
+                float v0[nq], v1[nq];
+                const int pa = 32 * (g0 + hh) + j, pb = 32 * (g0 + 2 + hh) + j;
+                const bool oka = (g0 + hh < G) && pa < P, okb = (g0 + 2 + hh < G) && pb < P;
+#pragma unroll
+                for (int kq = 0; kq < nq; ++kq) {
+                    const float* pq = pbuf + (size_t)(t * 12 + kq) * C.Ppad;
+                    v0[kq] = oka ? coop_load(pq + pa) : 0.0f;
+                    v1[kq] = okb ? coop_load(pq + pb) : 0.0f;
+                }
+#pragma unroll
+                for (int kq = 0; kq < nq; ++kq) {
+                    Sa[kq] = Sa[kq] + group_bfly32(v0[kq]);                     // groups g0, g0+1 -> slots 0 / 1
+                    if (g0 + 2 < G) Sb[kq] = Sb[kq] + group_bfly32(v1[kq]);     // groups g0+2, g0+3 -> slots 2 / 3
+                }
+            }
+#pragma unroll
+            for (int kq = 0; kq < nq; ++kq) {
+                const float S0 = readlane_f(Sa[kq], 0), S1 = readlane_f(Sa[kq], 32), S2 = readlane_f(Sb[kq], 0), S3 = readlane_f(Sb[kq], 32);
+                if (lane == 0) sm.tot[t * 12 + kq] = ((S0 + S1) + S2) + S3;
+            }
+        }
+    }
+    Team::sync();
+    const float tot = sm.red[12];
+    assemble_gradient<Team, M>(a, sm, y, gout, tid, [&](int q) { return sm.tot[q]; });
+    Team::sync();
+    return FMA(tot, a.invP, cu);
+}
+

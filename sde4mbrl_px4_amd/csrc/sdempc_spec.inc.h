@@ -1,0 +1,324 @@
+// sdempc_spec.inc.h — speculative cooperative solve kernel (state machine)
+// Fragment of sdempc_kernels.hip: included inside namespace sdempc::{exact|fastm} (it is compiled twice, see there); not a
+// stand-alone header.
+// ================================================================================================
+// Speculative cooperative solve (smallest batches): FIVE groups of ceil(P/4) workgroups per instance. While groups 0 and 1
+// evaluate the first two line-search trials of iteration k side by side, groups 2, 3 and 4 already evaluate the gradient of
+// iteration k+1 at the three points the optimiser can move to: where it goes if it ends on trial 1 resp. trial 2 with an
+// improvement, and xk (no improvement). The step sizes of the trials are known before any of them is evaluated (s, s*dec, ...),
+// so are the restart tests. One grid barrier per phase. The optimiser itself is unchanged and runs redundantly in every
+// workgroup: a gradient is a pure function of its point, so using the pre-computed one (when the speculation hits — the trial
+// costs decide that) gives the same bits as computing it afterwards; on a miss the iteration falls back to the sequential order.
+// Written as a state machine with ONE call site of the particle work, so that the rollout and the gradient sweep are each
+// instantiated once (the first version inlined them at seven sites: 140 KB of code, 2x slower sweeps).
+// ================================================================================================
+constexpr int SPEC_GROUPS = 5, SPEC_SLOTS = 7;
+constexpr int SLOT_SEQ = 6, SLOT_GRAD = 5;        // slots 0..4: the five items of a parallel phase
+
+DI LaneIO lane_io_slot(const KArgs& a, const CoopCtx& C, int b, int p, unsigned par, int slot) {
+    const int H = a.H;
+    LaneIO io;
+    io.x0 = a.x0 + (size_t)b * NX;
+    io.nz = a.noise + ((size_t)(b * a.G + (p >> 5)) * H) * NN * 32 + (p & 31);
+    io.ck = C.ck + (size_t)p * (H + 1) * COOP_ROW; io.ck_t = COOP_ROW;
+    io.xs = io.ck + LANE_ACT_X; io.xs_t = COOP_ROW; io.xs_i = 1;
+    io.out = C.pp + (size_t)(par * SPEC_SLOTS + slot) * part_stride(H) * C.Ppad + p; io.os = C.Ppad;
+    io.add0 = false;
+    return io;
+}
+// after a phase's barrier, in every workgroup: expected cost of control sequence u whose particle outputs sit in (par, slot)
+DI float spec_cost(const KArgs& a, const Smem& sm, const CoopCtx& C, int tid, unsigned par, const float* u, int slot) {
+    const int lane = tid & 63, wave = tid >> 6, PS = part_stride(a.H);
+    const float cu = block_ucost<TeamBlock>(a, sm, u, tid);
+    const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + slot) * PS * C.Ppad;
+    __syncthreads();
+    if (wave == 0) { const float t0 = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, a.P, a.G, lane); if (lane == 0) sm.red[12] = t0; }
+    __syncthreads();
+    return FMA(sm.red[12], a.invP, cu);
+}
+// gradient at y from the adjoint sums in (par, slot)
+template <int M>
+DI void spec_gradient(const KArgs& a, const Smem& sm, const CoopCtx& C, int tid, unsigned par, const float* y, int slot, float* gout) {
+    const int lane = tid & 63, wave = tid >> 6, PS = part_stride(a.H), H = a.H, P = a.P, G = a.G;
+    constexpr int nq = M + 4;
+    const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + slot) * PS * C.Ppad;
+    const int hh = lane >> 5, j = lane & 31;
+    __syncthreads();
+    for (int t = wave; t < H; t += 4) {
+        float Sa[nq], Sb[nq];
+#pragma unroll
+        for (int kq = 0; kq < nq; ++kq) { Sa[kq] = 0.0f; Sb[kq] = 0.0f; }
+        for (int g0 = 0; g0 < G; g0 += 4) {
+            float v0[nq], v1[nq];
+            const int pa = 32 * (g0 + hh) + j, pb = 32 * (g0 + 2 + hh) + j;
+            const bool oka = (g0 + hh < G) && pa < P, okb = (g0 + 2 + hh < G) && pb < P;
+#pragma unroll
+            for (int kq = 0; kq < nq; ++kq) {
+                const float* pq = pbuf + (size_t)(t * 12 + kq) * C.Ppad;
+                v0[kq] = oka ? coop_load(pq + pa) : 0.0f;
+                v1[kq] = okb ? coop_load(pq + pb) : 0.0f;
+            }
+#pragma unroll
+            for (int kq = 0; kq < nq; ++kq) {
+                Sa[kq] = Sa[kq] + group_bfly32(v0[kq]);
+                if (g0 + 2 < G) Sb[kq] = Sb[kq] + group_bfly32(v1[kq]);
+            }
+        }
+#pragma unroll
+        for (int kq = 0; kq < nq; ++kq) {
+            const float S0 = readlane_f(Sa[kq], 0), S1 = readlane_f(Sa[kq], 32), S2 = readlane_f(Sb[kq], 0), S3 = readlane_f(Sb[kq], 32);
+            if (lane == 0) sm.tot[t * 12 + kq] = ((S0 + S1) + S2) + S3;
+        }
+    }
+    __syncthreads();
+    assemble_gradient<TeamBlock, M>(a, sm, y, gout, tid, [&](int q) { return sm.tot[q]; });
+    __syncthreads();
+}
+
+// one workgroup per CU (512 registers per lane: what does not fit the 256 VGPRs spills to AGPRs, not to scratch memory — with two
+// workgroups per CU the adjoint loop carried 43 scratch accesses per step and ran 3x slower)
+template <int M>
+__global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
+    using Team = TeamBlock;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // a.coop_ngrp groups (2..5) per instance take the roles T1, T2, S(y2), S(xk), S(y1) in this order of usefulness
+    // (measured at C2: the line search ends on trial 2 in 60 %, there is no improvement in 31 %, it ends on trial 1 in 28 % of the iterations)
+    const int nwg = a.coop_nwg, ng = a.coop_ngrp, per = ng * nwg, H = a.H, m = a.m, N = H * m, PS = part_stride(H);
+    const int b_ = blockIdx.x / per, r_ = blockIdx.x - b_ * per, grp = r_ / nwg;
+    const bool have_y2 = ng >= 3, have_xk = ng >= 4, have_y1 = ng >= 5;
+    const int grad_grp = ng >= 3 ? 2 : 0;          // who evaluates a gradient outside the parallel phase
+    const int b = __builtin_amdgcn_readfirstlane(b_);
+    CoopCtx C;
+    C.nwg = per; C.wgi = r_ - grp * nwg; C.Ppad = a.G * 32; C.epoch = 0u;
+    C.bar = a.coop_bar + 2 * b;
+    C.pp = a.coop_pp + (size_t)b * ((size_t)2 * SPEC_SLOTS * PS * C.Ppad + 2 * (size_t)PS);
+    C.ck = a.coop_ck + ((size_t)b * 3 + (grp >= 2 ? grp - 2 : 0)) * a.P * (H + 1) * COOP_ROW;    // gradients run on groups 2..4 (or 0 when there are only two)
+    Smem sm = carve(smem, H, m, 0, true);
+    WaveW ww;
+    LaneW LW;
+    load_weights(a, sm, ww, tid, Team::BNT);
+    __syncthreads();
+    if (b >= a.B) return;
+    load_lane_weights(a, LW, lane);
+    load_common<Team>(a, sm, b, tid);
+    const int nv = (N + 3) & ~3;
+    float* ex = sm.tot + ((H * 12 + 3) & ~3);
+    float *xn1 = ex, *xn2 = ex + nv, *y1 = ex + 2 * nv, *y2 = ex + 3 * nv;
+    float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
+    for (int e = tid; e < N; e += Team::NT) {
+        int jj = e % m;
+        float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
+        xk[e] = v; yk[e] = v;
+    }
+    // PH_RED: the particle sums of a gradient (H*nq totals + the cost total) are reduced ONCE, spread over all workgroups of the
+    // instance (one step each), published and read back after one more barrier — every workgroup reducing everything itself took
+    // ~45 us per iteration, a third of the time of an iteration
+    enum { PH_INIT, PH_GRAD, PH_PAR, PH_SEQ, PH_RED, PH_FINAL, PH_DONE };
+    float* gtot_base = C.pp + (size_t)2 * SPEC_SLOTS * PS * C.Ppad;       // [2][PS] published totals, after the per-particle slots
+    unsigned red_cnt = 0u, red_par = 0u; int red_slot = 0;
+    int phase = PH_INIT;
+    float c_init = 0.0f, c_x = 0.0f, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f, c_y = 0.0f, c_n = 0.0f;
+    int k = 0, kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1, nls = 0, jsel = 0, jl = 0;
+    unsigned par_cnt = 0u, par_spec = 0u;
+    bool spec = false, two = false;
+    const bool has_ls = a.A.maxls > 0;
+    while (phase != PH_DONE) {
+        // ---- this workgroup's work item of the phase ----
+        const float* iu = xk; int islot = SLOT_SEQ; bool igrad = false, imean = false, iact = false;
+        unsigned par = C.epoch & 1u;
+        if (phase == PH_RED) {
+            constexpr int nq = M + 4;
+            const float* pbuf = C.pp + (size_t)(red_par * SPEC_SLOTS + red_slot) * PS * C.Ppad;
+            float* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
+            for (int t = r_; t < H; t += per) {
+                for (int kq = wave; kq < nq; kq += 4) {
+                    const float sv = coop_total(pbuf + (size_t)(t * 12 + kq) * C.Ppad, a.P, a.G, lane);
+                    if (lane == 0) __hip_atomic_store(gt + t * 12 + kq, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (r_ == per - 1 && wave == 3) {      // the cost total: last workgroup (idle above unless per <= H)
+                const float sv = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, a.P, a.G, lane);
+                if (lane == 0) __hip_atomic_store(gt + PS - 1, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        else if (phase == PH_INIT) { iact = grp == 0; }
+        else if (phase == PH_GRAD) { iact = grp == grad_grp; iu = yk; islot = SLOT_GRAD; igrad = true; }
+        else if (phase == PH_SEQ) { iact = grp == 0; iu = xn; }
+        else if (phase == PH_FINAL) { iact = grp == 0; imean = true; }
+        else {   // PH_PAR
+            par = par_cnt & 1u; par_spec = par; par_cnt += 1u;
+            if (grp == 0) { iact = true; iu = xn1; islot = 0; }
+            else if (grp == 1) { iact = two; iu = xn2; islot = 1; }
+            else if (grp == 2) { iact = spec && two; iu = y2; igrad = true; islot = 3; }     // when there is one trial only, y1 takes this group
+            else if (grp == 3) { iact = spec; iu = xk; igrad = true; islot = 4; }
+            else { iact = spec; iu = y1; igrad = true; islot = 2; }
+            if (grp == 2 && spec && !two) { iact = true; iu = y1; igrad = true; islot = 2; }
+        }
+        if (iact) {      // the only call site of the particle work
+            __syncthreads();
+            block_prepass<Team>(a, sm, iu, tid);
+            __syncthreads();
+            const int p = C.wgi * 4 + wave;
+            if (p < a.P) {
+                const LaneIO io = lane_io_slot(a, C, b, p, par, islot);
+                if (igrad) lane_particle_grad<M>(a, sm, LW, io, lane);
+                else lane_particle_rollout(a, sm, LW, io, lane, false, imean);
+            }
+        }
+        coop_barrier(C, tid);
+        // ---- the optimiser (SPEC.md §8), advanced as far as the data of this phase allows ----
+        bool head = false, tail = false;
+        if (phase == PH_INIT) {
+            c_init = spec_cost(a, sm, C, tid, par, xk, SLOT_SEQ);
+            c_x = c_init;
+            phase = a.A.max_iter > 0 ? PH_GRAD : PH_FINAL;
+        } else if (phase == PH_GRAD) {
+            red_slot = SLOT_GRAD; red_par = par; phase = PH_RED;
+        } else if (phase == PH_RED) {
+            constexpr int nq = M + 4;
+            const float* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
+            red_cnt += 1u;
+            for (int q = tid; q < H * 12; q += Team::NT)
+                if ((q % 12) < nq) sm.tot[q] = coop_load(gt + q);
+            if (tid == 0) sm.red[12] = coop_load(gt + PS - 1);
+            const float cu = block_ucost<Team>(a, sm, yk, tid);        // (contains the barriers that publish sm.tot / sm.red)
+            __syncthreads();
+            c_y = FMA(sm.red[12], a.invP, cu);
+            assemble_gradient<Team, M>(a, sm, yk, g, tid, [&](int q) { return sm.tot[q]; });
+            __syncthreads();
+            head = true;
+        } else if (phase == PH_PAR) {
+            __syncthreads();
+            for (int e = tid; e < N; e += Team::NT) { xn[e] = xn1[e]; d1[e] = xn1[e] - yk[e]; }
+            c_n = spec_cost(a, sm, C, tid, par, xn1, 0);
+            nls = 1; jsel = 1;
+            bool done = !has_ls;
+            if (has_ls) {
+                const float gd = block_dot<Team>(sm, g, d1, N, tid);
+                if (c_n <= FMA(a.A.coef, gd, c_y)) done = true;
+                else if (0 < a.A.maxls - 1) s = s * a.A.dec;
+            }
+            if (!done && two) {
+                __syncthreads();
+                for (int e = tid; e < N; e += Team::NT) { xn[e] = xn2[e]; d1[e] = xn2[e] - yk[e]; }
+                c_n = spec_cost(a, sm, C, tid, par, xn2, 1);
+                const float gd = block_dot<Team>(sm, g, d1, N, tid);
+                nls = 2; jsel = 2;
+                if (c_n <= FMA(a.A.coef, gd, c_y)) done = true;
+                else if (1 < a.A.maxls - 1) s = s * a.A.dec;
+            }
+            if (!done && 2 < a.A.maxls) {        // further trials one at a time
+                jl = 2;
+                __syncthreads();
+                for (int e = tid; e < N; e += Team::NT) {
+                    int jj = e % m;
+                    float v = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                    xn[e] = v; d1[e] = v - yk[e];
+                }
+                __syncthreads();
+                phase = PH_SEQ;
+            } else tail = true;
+        } else if (phase == PH_SEQ) {
+            c_n = spec_cost(a, sm, C, tid, par, xn, SLOT_SEQ);
+            const float gd = block_dot<Team>(sm, g, d1, N, tid);
+            nls = jl + 1; jsel = 0;
+            bool done = c_n <= FMA(a.A.coef, gd, c_y);
+            if (!done && jl < a.A.maxls - 1) s = s * a.A.dec;
+            if (!done && jl + 1 < a.A.maxls) {
+                jl += 1;
+                __syncthreads();
+                for (int e = tid; e < N; e += Team::NT) {
+                    int jj = e % m;
+                    float v = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                    xn[e] = v; d1[e] = v - yk[e];
+                }
+                __syncthreads();
+            } else tail = true;
+        } else {   // PH_FINAL
+            if (grp == 0 && C.wgi == 0) {
+                const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + SLOT_SEQ) * PS * C.Ppad;
+                float* xmean_out = a.xmean + (size_t)b * (H + 1) * NX;
+                for (int q = wave; q < (H + 1) * NX; q += 4) {
+                    const float sv = coop_total(pbuf + (size_t)q * C.Ppad, a.P, a.G, lane);
+                    if (lane == 0) xmean_out[q] = sv * a.invP;
+                }
+                for (int e = tid; e < N; e += Team::NT) a.uopt[(size_t)b * N + e] = xk[e];
+                if (tid == 0) {
+                    float* inf = a.info + (size_t)b * 8;
+                    const float fn = (float)nit;
+                    inf[0] = nit ? sum_ls / fn : 0.0f; inf[1] = s; inf[2] = fn; inf[3] = gsq; inf[4] = nit ? sum_s / fn : 0.0f;
+                    inf[5] = c_init; inf[6] = c_x; inf[7] = (float)nls_tot;
+                    if (__hip_atomic_load(C.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+                        for (int i = 0; i < 8; ++i) inf[i] = __builtin_nanf("");
+                }
+            }
+            phase = PH_DONE;
+        }
+        if (tail) {      // end of the line search of iteration k
+            sum_ls = sum_ls + (float)nls; sum_s = sum_s + s; nit = k + 1; nls_tot += nls;
+            int stop = (__builtin_fabsf(c_n - c_x) <= FMA(a.A.rtol, __builtin_fabsf(c_x), a.A.atol));
+            int hit_slot = -1;
+            __syncthreads();
+            if (c_n < c_x) {
+                for (int e = tid; e < N; e += Team::NT) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
+                float rs = block_dot<Team>(sm, d1, d2, N, tid);
+                if (rs > 0.0f) {
+                    kr = 0; plain = 1;
+                    for (int e = tid; e < N; e += Team::NT) { yk[e] = xn[e]; xk[e] = xn[e]; }
+                } else {
+                    float bt = a.beta[kr];
+                    for (int e = tid; e < N; e += Team::NT) { int jj = e % m; yk[e] = clampf(FMA(bt, d2[e], xn[e]), a.C.ulo[jj], a.C.uhi[jj]); xk[e] = xn[e]; }
+                    kr = kr + 1; plain = 0;
+                }
+                c_x = c_n; noimp = 0;
+                // the new yk is exactly y_jsel: was its gradient among the speculated ones?
+                if (spec && jsel == 2 && have_y2) hit_slot = 3;
+                if (spec && jsel == 1 && (have_y1 || (have_y2 && !two))) hit_slot = 2;
+            } else {
+                if (!plain) stop = 0;
+                kr = 0; plain = 1;
+                for (int e = tid; e < N; e += Team::NT) yk[e] = xk[e];
+                noimp = noimp + 1;
+                if (spec && have_xk) hit_slot = 4;               // the new yk is xk, unchanged since the parallel phase
+            }
+            if (noimp >= a.A.max_noimp) stop = 1;
+            k += 1;
+            if (stop || k >= a.A.max_iter) phase = PH_FINAL;
+            else if (hit_slot >= 0) { red_slot = hit_slot; red_par = par_spec; phase = PH_RED; }
+            else phase = PH_GRAD;
+        }
+        if (head) {      // start of iteration k with (c_y, g) in hand
+            gsq = block_dot<Team>(sm, g, g, N, tid);
+            if (!(gsq < __builtin_inff())) { phase = PH_FINAL; continue; }
+            if (has_ls) {
+                if (k > 0 && a.A.reset_inc) s = s * a.A.inc;
+                if (s > a.A.smax) s = a.A.smax;
+            } else {
+                s = a.A.stepsize;
+            }
+            two = (has_ls ? a.A.maxls : 1) > 1;
+            spec = (k + 1 < a.A.max_iter);
+            const float s1 = s, s2 = s * a.A.dec;
+            __syncthreads();
+            for (int e = tid; e < N; e += Team::NT) {
+                int jj = e % m;
+                xn1[e] = clampf(FMA(-s1, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                xn2[e] = clampf(FMA(-s2, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+            }
+            __syncthreads();
+            // where the optimiser moves if it ends on trial j with an improvement (the expressions of the tail above)
+            for (int jtr = 0; jtr < (two ? 2 : 1); ++jtr) {
+                const float* xj = jtr ? xn2 : xn1;
+                float* yj = jtr ? y2 : y1;
+                for (int e = tid; e < N; e += Team::NT) { d1[e] = yk[e] - xj[e]; d2[e] = xj[e] - xk[e]; }
+                const float rs = block_dot<Team>(sm, d1, d2, N, tid);
+                const float bt = a.beta[kr];
+                for (int e = tid; e < N; e += Team::NT) { int jj = e % m; yj[e] = (rs > 0.0f) ? xj[e] : clampf(FMA(bt, d2[e], xj[e]), a.C.ulo[jj], a.C.uhi[jj]); }
+                __syncthreads();
+            }
+            phase = PH_PAR;
+        }
+    }
+}
+

@@ -1,0 +1,411 @@
+// sdempc_step.inc.h — one Euler-Maruyama step and its vector-Jacobian product: uniform head / tail, MLPs in the MFMA tile layout, stage cost
+// Fragment of sdempc_kernels.hip: included inside namespace sdempc::{exact|fastm} (it is compiled twice, see there); not a
+// stand-alone header.
+// ------------------------------------------------------------------------------------------------
+// one Euler–Maruyama step for the wave's 32 particles (SPEC.md §5.2)
+// ------------------------------------------------------------------------------------------------
+struct StepAux {
+    float Rm[9];
+    f32x16 h1d, h1n, h2;
+    float eta, Fb[3], Jom[3], rn, qn[4];
+};
+
+
+// ---- uniform head of a step: rotation matrix and the MLP inputs z = (R^T v, omega) ----
+DI void fwd_head(const float* x, float* Rm, float* z) {
+    const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const float xx = qx * qx, yy = qy * qy, zz = qz * qz;
+    const float xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
+    Rm[0] = FMA(-2.0f, yy + zz, 1.0f); Rm[1] = 2.0f * (xy - wz);          Rm[2] = 2.0f * (xz + wy);
+    Rm[3] = 2.0f * (xy + wz);          Rm[4] = FMA(-2.0f, xx + zz, 1.0f); Rm[5] = 2.0f * (yz - wx);
+    Rm[6] = 2.0f * (xz - wy);          Rm[7] = 2.0f * (yz + wx);          Rm[8] = FMA(-2.0f, xx + yy, 1.0f);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) z[j] = FMA(Rm[6 + j], x[5], FMA(Rm[3 + j], x[4], Rm[j] * x[3]));
+    z[3] = x[10]; z[4] = x[11]; z[5] = x[12];
+}
+
+// ---- MLPs of a step in the MFMA tile layout (32 particles per wave): outputs o[6] and eta per particle ----
+template <bool F16, bool PK>
+DI void fwd_mlp_tiles(const KArgs& a, const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, StepAux& A, float* o, float& eta_out) {
+    // layer 1: C operand = per-step offsets (drift) / bias (density); K = 6 -> 3 MFMAs per tile
+    f32x16 accD, accN;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 c4 = *reinterpret_cast<const float4*>(ust + 8 * q + 4 * h);
+        float4 n4 = *reinterpret_cast<const float4*>(sm.b1n + 8 * q + 4 * h);
+        accD[4 * q] = c4.x; accD[4 * q + 1] = c4.y; accD[4 * q + 2] = c4.z; accD[4 * q + 3] = c4.w;
+        accN[4 * q] = n4.x; accN[4 * q + 1] = n4.y; accN[4 * q + 2] = n4.z; accN[4 * q + 3] = n4.w;
+    }
+    if constexpr (F16) {
+        // fp16 operands (round toward zero), f32 accumulate: one v_mfma_f32_32x32x16_f16 per tile, k slots 0..5 live in lanes 0..31
+        half8 bv;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            auto pk = __builtin_amdgcn_cvt_pkrtz(h ? 0.0f : z[2 * e], h ? 0.0f : z[2 * e + 1]);
+            bv[2 * e] = (_Float16)pk[0]; bv[2 * e + 1] = (_Float16)pk[1];
+        }
+        bv[6] = (_Float16)0.0f; bv[7] = (_Float16)0.0f;
+        accD = __builtin_amdgcn_mfma_f32_32x32x16_f16(ww.h1d, bv, accD, 0, 0, 0);
+        accN = __builtin_amdgcn_mfma_f32_32x32x16_f16(ww.h1n, bv, accN, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float b = h ? z[2 * s + 1] : z[2 * s];
+            accD = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1d[s], b, accD, 0, 0, 0);
+            accN = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1n[s], b, accN, 0, 0, 0);
+        }
+    }
+    SCHED_PHASE();
+
+    tanh_tile<PK>(accD);
+    SCHED_PHASE();
+
+    tanh_tile<PK>(accN);
+    A.h1d = accD; A.h1n = accN;
+    SCHED_PHASE();
+
+    // layer 2 (drift): B operand of k-step r is accumulator register r of layer 1
+    f32x16 acc2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 b4 = *reinterpret_cast<const float4*>(sm.b2 + 8 * q + 4 * h);
+        acc2[4 * q] = b4.x; acc2[4 * q + 1] = b4.y; acc2[4 * q + 2] = b4.z; acc2[4 * q + 3] = b4.w;
+    }
+    if constexpr (F16) {
+        // two K=16 MFMAs: k slot e of lane half h <-> accumulator register 8*hf + e, i.e. hidden unit rowmap(8*hf + e, h)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            half8 av = *reinterpret_cast<const half8*>(sm.A2h + (hf * 64 + lane) * 4);
+            half8 bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                auto pk = __builtin_amdgcn_cvt_pkrtz(accD[8 * hf + 2 * e], accD[8 * hf + 2 * e + 1]);
+                bv[2 * e] = (_Float16)pk[0]; bv[2 * e + 1] = (_Float16)pk[1];
+            }
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc2, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.A2 + (q * 64 + lane) * 4);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, accD[4 * q], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, accD[4 * q + 1], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, accD[4 * q + 2], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, accD[4 * q + 3], acc2, 0, 0, 0);
+        }
+    }
+    SCHED_PHASE();
+
+    tanh_tile<PK>(acc2);
+    A.h2 = acc2;
+    SCHED_PHASE();
+
+    // output layers on the VALU: per-half partial chains, then (P0 + P1) + bias
+    {
+        float Po[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Po[i] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
+                Po[i] = FMA(w4.x, acc2[4 * q], Po[i]); Po[i] = FMA(w4.y, acc2[4 * q + 1], Po[i]); Po[i] = FMA(w4.z, acc2[4 * q + 2], Po[i]); Po[i] = FMA(w4.w, acc2[4 * q + 3], Po[i]);
+            }
+            SCHED_PHASE();
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[i] = xor32_sum(Po[i]) + a.M.b3[i];
+    }
+    float eta;
+    {
+        float P = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
+            P = FMA(w4.x, accN[4 * q], P); P = FMA(w4.y, accN[4 * q + 1], P); P = FMA(w4.z, accN[4 * q + 2], P); P = FMA(w4.w, accN[4 * q + 3], P);
+        }
+        eta = sigmoid_spec(xor32_sum(P) + a.M.b3n);
+    }
+    eta_out = eta;
+    SCHED_PHASE();
+}
+
+// ---- uniform tail of a step: rigid body, Euler-Maruyama update, quaternion renormalisation ----
+DI void fwd_tail(const KArgs& a, const Smem& sm, const float* ust, int t, const float* x, const float* xi, const float* Rm, const float* o, float eta, float* xn, StepAux& A) {
+    const float dt = sm.dt[t];
+    const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    A.eta = eta;
+    // rigid body
+    A.Fb[0] = a.M.sF[0] * o[0]; A.Fb[1] = a.M.sF[1] * o[1]; A.Fb[2] = FMA(a.M.sF[2], o[2], ust[32]);
+    float acc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float Fw = FMA(Rm[3 * i + 2], A.Fb[2], FMA(Rm[3 * i + 1], A.Fb[1], Rm[3 * i] * A.Fb[0]));
+        acc[i] = Fw * a.M.inv_mass;
+    }
+    acc[2] = acc[2] - a.M.grav;
+    float taub[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { taub[i] = FMA(a.M.sT[i], o[3 + i], ust[33 + i]); A.Jom[i] = a.M.J[i] * x[10 + i]; }
+    float cr[3];
+    cr[0] = FMA(x[11], A.Jom[2], -(x[12] * A.Jom[1]));
+    cr[1] = FMA(x[12], A.Jom[0], -(x[10] * A.Jom[2]));
+    cr[2] = FMA(x[10], A.Jom[1], -(x[11] * A.Jom[0]));
+    float dom[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dom[i] = (taub[i] - cr[i]) * a.M.iJ[i];
+    float dq[4];
+    dq[0] = -0.5f * FMA(qz, x[12], FMA(qy, x[11], qx * x[10]));
+    dq[1] = 0.5f * FMA(-qz, x[11], FMA(qy, x[12], qw * x[10]));
+    dq[2] = 0.5f * FMA(-qx, x[12], FMA(qz, x[10], qw * x[11]));
+    dq[3] = 0.5f * FMA(-qy, x[10], FMA(qx, x[11], qw * x[12]));
+    const float* sdt = sm.sdt + t * NN;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        xn[i] = FMA(x[3 + i], dt, x[i]);
+        xn[3 + i] = FMA(sdt[i] * eta, xi[i], FMA(acc[i], dt, x[3 + i]));
+        xn[10 + i] = FMA(sdt[3 + i] * eta, xi[3 + i], FMA(dom[i], dt, x[10 + i]));
+    }
+    float qt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qt[i] = FMA(dq[i], dt, x[6 + i]);
+    float n2 = FMA(qt[3], qt[3], FMA(qt[2], qt[2], FMA(qt[1], qt[1], qt[0] * qt[0])));
+    if constexpr (FAST) A.rn = __builtin_amdgcn_rsqf(n2); else A.rn = rsqrt_spec(n2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { A.qn[i] = qt[i] * A.rn; xn[6 + i] = A.qn[i]; }
+}
+
+template <bool F16, bool PK = false>
+DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, float* xn, StepAux& A) {
+    const float* ust = sm.ust + t * UST;
+    float z[NN];
+    fwd_head(x, A.Rm, z);
+    SCHED_PHASE();
+    float o[6], eta;
+    fwd_mlp_tiles<F16, PK>(a, sm, ww, ust, h, lane, z, A, o, eta);
+    fwd_tail(a, sm, ust, t, x, xi, A.Rm, o, eta, xn, A);
+}
+
+// rotation matrix of q (same expressions as in step_fwd)
+DI void rot_from_q(const float* x, float* Rm) {
+    const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const float xx = qx * qx, yy = qy * qy, zz = qz * qz;
+    const float xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
+    Rm[0] = FMA(-2.0f, yy + zz, 1.0f); Rm[1] = 2.0f * (xy - wz);          Rm[2] = 2.0f * (xz + wy);
+    Rm[3] = 2.0f * (xy + wz);          Rm[4] = FMA(-2.0f, xx + zz, 1.0f); Rm[5] = 2.0f * (yz - wx);
+    Rm[6] = 2.0f * (xz - wy);          Rm[7] = 2.0f * (yz + wx);          Rm[8] = FMA(-2.0f, xx + yy, 1.0f);
+}
+
+// SPEC.md §5.3 stage cost at x_{t+1}; GX: also the gradient
+template <bool GX>
+DI float stage_cost(const KArgs& a, const float* x, const float* xr, float* gx) {
+    float l = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { float e = x[i] - xr[i]; float w = a.C.perr[i] * e; l = FMA(w, e, l); if (GX) gx[i] = 2.0f * w; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { float e = x[3 + i] - xr[3 + i]; float w = a.C.verr[i] * e; l = FMA(w, e, l); if (GX) gx[3 + i] = 2.0f * w; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { float e = x[10 + i] - xr[10 + i]; float w = a.C.werr[i] * e; l = FMA(w, e, l); if (GX) gx[10 + i] = 2.0f * w; }
+    float qw = x[6], qx = x[7], qy = x[8], qz = x[9], rw = xr[6], rx = xr[7], ry = xr[8], rz = xr[9];
+    float ex = FMA(rz, qy, FMA(-ry, qz, FMA(-rx, qw, rw * qx)));
+    float ey = FMA(-rz, qx, FMA(-ry, qw, FMA(rx, qz, rw * qy)));
+    float ez = FMA(-rz, qw, FMA(ry, qx, FMA(-rx, qy, rw * qz)));
+    float wxe = a.C.qerr[0] * ex, wye = a.C.qerr[1] * ey, wze = a.C.qerr[2] * ez;
+    l = FMA(wxe, ex, l); l = FMA(wye, ey, l); l = FMA(wze, ez, l);
+    if (GX) {
+        float ga = 2.0f * wxe, gb = 2.0f * wye, gc = 2.0f * wze;
+        gx[6] = FMA(-rz, gc, FMA(-ry, gb, -rx * ga));
+        gx[7] = FMA(ry, gc, FMA(-rz, gb, rw * ga));
+        gx[8] = FMA(-rx, gc, FMA(rw, gb, rz * ga));
+        gx[9] = FMA(rw, gc, FMA(rx, gb, -ry * ga));
+    }
+    return l;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vector-Jacobian product of one step (SPEC.md §5.4). gq[0..m-1] = W1u^T abar1, gq[m] = Tz adjoint,
+// gq[m+1..m+3] = rotor-torque adjoint
+// ------------------------------------------------------------------------------------------------
+// Uniform (per particle) quantities that the three parts of the step's vector-Jacobian product share
+struct VjpTmp {
+    float ebraw, qtb[4], dqb[4], omb[3], Fwb[3], ob[6];
+};
+
+// ---- head: everything upstream of the MLPs (per particle); gq[M..M+3] = thrust / rotor-torque adjoints ----
+template <int M>
+DI void vjp_head(const KArgs& a, const Smem& sm, int t, const float* x, const float* xi, const StepAux& A, const float* L, float etabar_cost, VjpTmp& T, float* gq) {
+    const float dt = sm.dt[t];
+    const float* sdt = sm.sdt + t * NN;
+    const float* Rm = A.Rm;
+    const float* om = x + 10;
+    float eb = etabar_cost;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) eb = FMA(L[3 + i] * sdt[i], xi[i], eb);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) eb = FMA(L[10 + i] * sdt[3 + i], xi[3 + i], eb);
+    T.ebraw = eb * (A.eta * (1.0f - A.eta));
+    float dotq = FMA(A.qn[3], L[9], FMA(A.qn[2], L[8], FMA(A.qn[1], L[7], A.qn[0] * L[6])));
+    float* qtb = T.qtb; float* dqb = T.dqb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qtb[i] = A.rn * FMA(-A.qn[i], dotq, L[6 + i]); dqb[i] = qtb[i] * dt; }
+    float taub_b[3], crb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { taub_b[i] = (L[10 + i] * dt) * a.M.iJ[i]; crb[i] = -taub_b[i]; }
+    float* omb = T.omb; float Jb[3];
+    omb[0] = L[10] + FMA(A.Jom[1], crb[2], -(A.Jom[2] * crb[1]));
+    omb[1] = L[11] + FMA(A.Jom[2], crb[0], -(A.Jom[0] * crb[2]));
+    omb[2] = L[12] + FMA(A.Jom[0], crb[1], -(A.Jom[1] * crb[0]));
+    Jb[0] = FMA(crb[1], om[2], -(crb[2] * om[1]));
+    Jb[1] = FMA(crb[2], om[0], -(crb[0] * om[2]));
+    Jb[2] = FMA(crb[0], om[1], -(crb[1] * om[0]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) omb[i] = FMA(a.M.J[i], Jb[i], omb[i]);
+    float* Fwb = T.Fwb; float Fbb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Fwb[i] = (L[3 + i] * dt) * a.M.inv_mass;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Fbb[j] = FMA(Rm[6 + j], Fwb[2], FMA(Rm[3 + j], Fwb[1], Rm[j] * Fwb[0]));
+    float* ob = T.ob;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ob[i] = a.M.sF[i] * Fbb[i]; ob[3 + i] = a.M.sT[i] * taub_b[i]; }
+    gq[M] = Fbb[2];
+    gq[M + 1] = taub_b[0]; gq[M + 2] = taub_b[1]; gq[M + 3] = taub_b[2];
+}
+
+// ---- MLP part in the MFMA tile layout: zb[6] = adjoint of z, gq[0..M-1] = W1u^T abar1 (per particle) ----
+template <int M>
+DI void vjp_mlp_tiles(const Smem& sm, int h, int lane, const StepAux& A, const VjpTmp& T, float* zb, float* gq) {
+    const float ebraw = T.ebraw;
+    const float* ob = T.ob;
+    // MLP VJP. Order chosen to keep few tiles live: density tile first (frees h1n), then the drift
+    // tile: abar2 on the VALU, W2^T abar2 by MFMA in the accumulator layout.
+    {
+        float Pz[NN], Pu[M];
+#pragma unroll
+        for (int k = 0; k < NN; ++k) Pz[k] = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < M; ++jj) Pu[jj] = 0.0f;
+        // density net: abar1n = (w3n * etaraw_bar) * (1 - h1n^2); zbar += W1z[32:64]^T abar1n
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
+            float an0 = (wn4.x * ebraw) * FMA(-A.h1n[4 * q], A.h1n[4 * q], 1.0f);
+            float an1 = (wn4.y * ebraw) * FMA(-A.h1n[4 * q + 1], A.h1n[4 * q + 1], 1.0f);
+            float an2 = (wn4.z * ebraw) * FMA(-A.h1n[4 * q + 2], A.h1n[4 * q + 2], 1.0f);
+            float an3 = (wn4.w * ebraw) * FMA(-A.h1n[4 * q + 3], A.h1n[4 * q + 3], 1.0f);
+#pragma unroll
+            for (int k = 0; k < NN; ++k) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + HID + 8 * q + 4 * h);
+                Pz[k] = FMA(w4.x, an0, Pz[k]); Pz[k] = FMA(w4.y, an1, Pz[k]); Pz[k] = FMA(w4.z, an2, Pz[k]); Pz[k] = FMA(w4.w, an3, Pz[k]);
+            }
+            SCHED_PHASE();
+        }
+        // drift net
+        f32x16 a2b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f, hb3 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
+                hb0 = FMA(w4.x, ob[i], hb0); hb1 = FMA(w4.y, ob[i], hb1); hb2 = FMA(w4.z, ob[i], hb2); hb3 = FMA(w4.w, ob[i], hb3);
+            }
+            a2b[4 * q] = hb0 * FMA(-A.h2[4 * q], A.h2[4 * q], 1.0f);
+            a2b[4 * q + 1] = hb1 * FMA(-A.h2[4 * q + 1], A.h2[4 * q + 1], 1.0f);
+            a2b[4 * q + 2] = hb2 * FMA(-A.h2[4 * q + 2], A.h2[4 * q + 2], 1.0f);
+            a2b[4 * q + 3] = hb3 * FMA(-A.h2[4 * q + 3], A.h2[4 * q + 3], 1.0f);
+            SCHED_PHASE();
+        }
+        f32x16 accB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.A2T + (q * 64 + lane) * 4);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, a2b[4 * q], accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, a2b[4 * q + 1], accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, a2b[4 * q + 2], accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, a2b[4 * q + 3], accB, 0, 0, 0);
+        }
+        SCHED_PHASE();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float ad0 = accB[4 * q] * FMA(-A.h1d[4 * q], A.h1d[4 * q], 1.0f);
+            float ad1 = accB[4 * q + 1] * FMA(-A.h1d[4 * q + 1], A.h1d[4 * q + 1], 1.0f);
+            float ad2 = accB[4 * q + 2] * FMA(-A.h1d[4 * q + 2], A.h1d[4 * q + 2], 1.0f);
+            float ad3 = accB[4 * q + 3] * FMA(-A.h1d[4 * q + 3], A.h1d[4 * q + 3], 1.0f);
+#pragma unroll
+            for (int k = 0; k < NN; ++k) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + 8 * q + 4 * h);
+                Pz[k] = FMA(w4.x, ad0, Pz[k]); Pz[k] = FMA(w4.y, ad1, Pz[k]); Pz[k] = FMA(w4.z, ad2, Pz[k]); Pz[k] = FMA(w4.w, ad3, Pz[k]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < M; ++jj) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W1uT + jj * HID + 8 * q + 4 * h);
+                Pu[jj] = FMA(w4.x, ad0, Pu[jj]); Pu[jj] = FMA(w4.y, ad1, Pu[jj]); Pu[jj] = FMA(w4.z, ad2, Pu[jj]); Pu[jj] = FMA(w4.w, ad3, Pu[jj]);
+            }
+            SCHED_PHASE();
+        }
+#pragma unroll
+        for (int k = 0; k < NN; ++k) zb[k] = xor32_sum(Pz[k]);
+#pragma unroll
+        for (int jj = 0; jj < M; ++jj) gq[jj] = xor32_sum(Pu[jj]);
+    }
+    SCHED_PHASE();
+}
+
+// ---- tail: adjoint of the state (per particle) ----
+DI void vjp_tail(const Smem& sm, int t, const float* x, const StepAux& A, const float* L, const VjpTmp& T, const float* zb, float* lam) {
+    const float dt = sm.dt[t];
+    const float* Rm = A.Rm;
+    const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const float* v = x + 3;
+    const float* om = x + 10;
+    const float* qtb = T.qtb; const float* dqb = T.dqb; const float* Fwb = T.Fwb;
+    float omb[3] = {T.omb[0], T.omb[1], T.omb[2]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) omb[i] = omb[i] + zb[3 + i];
+    float vbar[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float Rvb = FMA(Rm[3 * i + 2], zb[2], FMA(Rm[3 * i + 1], zb[1], Rm[3 * i] * zb[0]));
+        vbar[i] = FMA(L[i], dt, L[3 + i]) + Rvb;
+    }
+    float Rb[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Rb[3 * i + j] = FMA(v[i], zb[j], Fwb[i] * A.Fb[j]);
+    float qb[4];
+    qb[0] = FMA(0.5f, FMA(dqb[3], om[2], FMA(dqb[2], om[1], dqb[1] * om[0])), qtb[0]);
+    qb[1] = FMA(0.5f, FMA(dqb[3], om[1], FMA(-dqb[2], om[2], -(dqb[0] * om[0]))), qtb[1]);
+    qb[2] = FMA(0.5f, FMA(-dqb[3], om[0], FMA(dqb[1], om[2], -(dqb[0] * om[1]))), qtb[2]);
+    qb[3] = FMA(0.5f, FMA(dqb[2], om[0], FMA(-dqb[1], om[1], -(dqb[0] * om[2]))), qtb[3]);
+    omb[0] = FMA(0.5f, FMA(-dqb[3], qy, FMA(dqb[2], qz, FMA(dqb[1], qw, -(dqb[0] * qx)))), omb[0]);
+    omb[1] = FMA(0.5f, FMA(dqb[3], qx, FMA(dqb[2], qw, FMA(-dqb[1], qz, -(dqb[0] * qy)))), omb[1]);
+    omb[2] = FMA(0.5f, FMA(dqb[3], qw, FMA(-dqb[2], qx, FMA(dqb[1], qy, -(dqb[0] * qz)))), omb[2]);
+    float s01 = Rb[1] + Rb[3], d10 = Rb[3] - Rb[1];
+    float s02 = Rb[2] + Rb[6], d02 = Rb[2] - Rb[6];
+    float s12 = Rb[5] + Rb[7], d21 = Rb[7] - Rb[5];
+    qb[0] = FMA(2.0f, FMA(qx, d21, FMA(qy, d02, qz * d10)), qb[0]);
+    qb[1] = FMA(2.0f, FMA(qw, d21, FMA(qz, s02, qy * s01)), FMA(-4.0f * qx, Rb[4] + Rb[8], qb[1]));
+    qb[2] = FMA(2.0f, FMA(qz, s12, FMA(qw, d02, qx * s01)), FMA(-4.0f * qy, Rb[0] + Rb[8], qb[2]));
+    qb[3] = FMA(2.0f, FMA(qy, s12, FMA(qx, s02, qw * d10)), FMA(-4.0f * qz, Rb[0] + Rb[4], qb[3]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { lam[i] = L[i]; lam[3 + i] = vbar[i]; lam[10 + i] = omb[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lam[6 + i] = qb[i];
+}
+
+template <int M>
+DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, const StepAux& A,
+                 const float* L, float etabar_cost, float* lam, float* gq) {
+    VjpTmp T;
+    vjp_head<M>(a, sm, t, x, xi, A, L, etabar_cost, T, gq);
+    SCHED_PHASE();
+    float zb[NN];
+    vjp_mlp_tiles<M>(sm, h, lane, A, T, zb, gq);
+    vjp_tail(sm, t, x, A, L, T, zb, lam);
+}
+

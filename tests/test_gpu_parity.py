@@ -483,3 +483,22 @@ def test_fast_math_mode_within_tolerance_of_exact_oracle(mlp):
     cx, _, _ = Sx.rollout(x0, u, xref, noise)
     assert bits_differ(cost, cx) > 0
     S.close(); Sx.close()
+
+
+# ---- the latency layouts on full-length solves (hundreds of phases: hits, misses, third / fourth trials) ---------------------------
+@pytest.mark.parametrize("cfg_name,iters", [("c2_iris_traj_h50_p128.yaml", 200), ("c1_iris_posctrl_h20_p32.yaml", 100), ("iris_traj_shipped_h20_p1.yaml", 200)])
+def test_single_instance_full_length_solve_bit_exact(cfg_name, iters, layout):
+    cfg = load_mpc_config(os.path.join(CDIR, cfg_name))
+    assert cfg.max_iter == iters
+    model = synthetic_iris()
+    x0, xref, _, _ = _problem(cfg, 1, 21, pos="posctrl" in cfg_name)
+    key = orc.split([0, 10], 2)[1][None].astype(np.uint32)
+    S = _solver(cfg, model, 1)
+    yk, i0 = S.reset()
+    s0 = np.array([i0["stepsize"]], np.float32)
+    uopt, xevol, info = S.solve_keys(x0, xref, key, yk[None], s0)
+    noise = orc.noise_from_key(key[0], cfg.num_particles, cfg.horizon)
+    uo, xe, io, _ = orc.Oracle(cfg, model).solve(x0[0], xref[0], noise, yk, float(s0[0]))
+    _close(uopt[0], uo, "uopt")
+    assert io[2] > 50 and bits_differ(uopt[0], uo) == 0 and bits_differ(xevol[0], xe) == 0 and bits_differ(info[0], io) == 0
+    S.close()

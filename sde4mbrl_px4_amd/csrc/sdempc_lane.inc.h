@@ -18,7 +18,11 @@
 // ================================================================================================
 DI int koff(int r) { return (r & 3) + 8 * (r >> 2); }   // rowmap(r, 0)
 DI float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
-DI float bperm_f(int src_lane, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v))); }
+// base_bytes: byte address of the chain's first source lane, kept below 256 so that the compiler can fold the constant part into the
+// instruction's offset field (one VALU address add per gather otherwise)
+DI float bperm_f(int base_bytes, int lane_off, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((base_bytes & 252) + 4 * lane_off, __builtin_bit_cast(int, v)));
+}
 
 struct LaneW {
     float w1[NN];        // W1z[32*hh + k][0..5]
@@ -102,7 +106,7 @@ DI void lane_fwd_mlp(const KArgs& a, const LaneW& W, const float* ust, int lane,
     const float Mreg = hh ? h1 : h2;     // lanes 0..31: layer-2 activations, lanes 32..63: density hidden units
     float P = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) P = FMA(W.wo[r], bperm_f(W.obase + koff(r), Mreg), P);
+    for (int r = 0; r < 16; ++r) P = FMA(W.wo[r], bperm_f(W.obase << 2, koff(r), Mreg), P);
     const float Pc = P + dpp_f<0x128>(P);   // row_ror:8 -> lane c: P_0 + P_1
 #pragma unroll
     for (int i = 0; i < 6; ++i) o[i] = readlane_f(Pc, i) + a.M.b3[i];
@@ -135,12 +139,12 @@ DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp&
     float Pz = 0.0f;
 #pragma unroll
     for (int p = 0; p < 16; ++p) {       // density units first (z-bar chains only)
-        const float src = bperm_f(32 + W.zbase + koff(p), Abar);
+        const float src = bperm_f(W.zbase << 2, 32 + koff(p), Abar);
         const float nv = FMA(W.wz[p], src, Pz);
         Pz = W.is_u ? Pz : nv;
     }
 #pragma unroll
-    for (int p = 0; p < 16; ++p) Pz = FMA(W.wz[16 + p], bperm_f(W.zbase + koff(p), Abar), Pz);
+    for (int p = 0; p < 16; ++p) Pz = FMA(W.wz[16 + p], bperm_f(W.zbase << 2, koff(p), Abar), Pz);
     const float Pc = Pz + dpp_f<0x128>(Pz);
 #pragma unroll
     for (int kk = 0; kk < NN; ++kk) zb[kk] = readlane_f(Pc, kk);

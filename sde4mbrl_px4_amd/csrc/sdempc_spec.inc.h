@@ -36,45 +36,6 @@ DI float spec_cost(const KArgs& a, const Smem& sm, const CoopCtx& C, int tid, un
     __syncthreads();
     return FMA(sm.red[12], a.invP, cu);
 }
-// gradient at y from the adjoint sums in (par, slot)
-template <int M>
-DI void spec_gradient(const KArgs& a, const Smem& sm, const CoopCtx& C, int tid, unsigned par, const float* y, int slot, float* gout) {
-    const int lane = tid & 63, wave = tid >> 6, PS = part_stride(a.H), H = a.H, P = a.P, G = a.G;
-    constexpr int nq = M + 4;
-    const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + slot) * PS * C.Ppad;
-    const int hh = lane >> 5, j = lane & 31;
-    __syncthreads();
-    for (int t = wave; t < H; t += 4) {
-        float Sa[nq], Sb[nq];
-#pragma unroll
-        for (int kq = 0; kq < nq; ++kq) { Sa[kq] = 0.0f; Sb[kq] = 0.0f; }
-        for (int g0 = 0; g0 < G; g0 += 4) {
-            float v0[nq], v1[nq];
-            const int pa = 32 * (g0 + hh) + j, pb = 32 * (g0 + 2 + hh) + j;
-            const bool oka = (g0 + hh < G) && pa < P, okb = (g0 + 2 + hh < G) && pb < P;
-#pragma unroll
-            for (int kq = 0; kq < nq; ++kq) {
-                const float* pq = pbuf + (size_t)(t * 12 + kq) * C.Ppad;
-                v0[kq] = oka ? coop_load(pq + pa) : 0.0f;
-                v1[kq] = okb ? coop_load(pq + pb) : 0.0f;
-            }
-#pragma unroll
-            for (int kq = 0; kq < nq; ++kq) {
-                Sa[kq] = Sa[kq] + group_bfly32(v0[kq]);
-                if (g0 + 2 < G) Sb[kq] = Sb[kq] + group_bfly32(v1[kq]);
-            }
-        }
-#pragma unroll
-        for (int kq = 0; kq < nq; ++kq) {
-            const float S0 = readlane_f(Sa[kq], 0), S1 = readlane_f(Sa[kq], 32), S2 = readlane_f(Sb[kq], 0), S3 = readlane_f(Sb[kq], 32);
-            if (lane == 0) sm.tot[t * 12 + kq] = ((S0 + S1) + S2) + S3;
-        }
-    }
-    __syncthreads();
-    assemble_gradient<TeamBlock, M>(a, sm, y, gout, tid, [&](int q) { return sm.tot[q]; });
-    __syncthreads();
-}
-
 // one workgroup per CU (512 registers per lane: what does not fit the 256 VGPRs spills to AGPRs, not to scratch memory — with two
 // workgroups per CU the adjoint loop carried 43 scratch accesses per step and ran 3x slower)
 template <int M>

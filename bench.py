@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "c2_iris_traj_h50_p128.yaml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--latency-reps", type=int, default=10)
+    ap.add_argument("--latency-reps", type=int, default=40)
     ap.add_argument("--mlp-dtype", default="f32", choices=["f32", "f16"],
                     help="f32: bit-reproducible path (default, the reported metric); f16: fp16-operand MLP contractions (SPEC.md 9)")
     args = ap.parse_args()
@@ -217,6 +217,8 @@ def main():
                                    f"cold-start solves from the hover guess, max_iter={cfg.max_iter} maxls={cfg.ls_maxls}",
                        "instances_per_gpu": B, "noise": "threefry2x32 keys (seed 10 split per instance), normal draws generated on the device", "N_it_mean": n_it, "N_ls_mean": n_ls, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "p50_solve_latency_ms": float(np.median(lat)),
+            "p95_solve_latency_ms": float(np.percentile(lat, 95)),
+            "latency_reps": len(lat),
             "p50_solve_latency_note": "one instance alone on the GPU (B = 1 launch of the same C-ABI entry point): the library spreads it over ceil(P/4) x 5 workgroups "
                                       "(one particle per wave; two line-search trials and the candidate gradients of the next iteration evaluated at once); bit-identical results",
             "p50_batch_latency_ms": float(np.median(ev_ms)),

@@ -716,12 +716,15 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : MODE ? 2 : s
         float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
         xk[e] = v; yk[e] = v;
     }
-    const float c_init = team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xk, b, tid, false, nullptr);
+    // wave-uniform optimiser scalars are pinned to SGPRs (uni_f): a uniform value left in a VGPR can be spilled under the partial EXEC
+    // mask of a divergent block and restored under the full one (seen in the speculative kernel; see sdempc_spec.inc.h)
+    const float c_init = uni_f(team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xk, b, tid, false, nullptr));
     float c_x = c_init, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f;
     int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1;
     for (int k = 0; k < a.A.max_iter; ++k) {
-        const float c_y = team_cost_grad<Team, M, F16, PK, solve_waves_per_simd<Team, PK>() == 2, MODE>(a, sm, ww, LW, CC, yk, g, b, tid);
-        gsq = block_dot<Team>(sm, g, g, N, tid);
+        c_x = uni_f(c_x); s = uni_f(s); sum_ls = uni_f(sum_ls); sum_s = uni_f(sum_s);
+        const float c_y = uni_f(team_cost_grad<Team, M, F16, PK, solve_waves_per_simd<Team, PK>() == 2, MODE>(a, sm, ww, LW, CC, yk, g, b, tid));
+        gsq = uni_f(block_dot<Team>(sm, g, g, N, tid));
         if (!(gsq < __builtin_inff())) break;   // SPEC.md §8 non-finite guard (team-uniform): keep xk, report gsq
         float c_n = 0.0f;
         int nls = 0;
@@ -735,8 +738,8 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : MODE ? 2 : s
                     float v = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
                     xn[e] = v; d1[e] = v - yk[e];
                 }
-                c_n = team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xn, b, tid, false, nullptr);
-                float gd = block_dot<Team>(sm, g, d1, N, tid);
+                c_n = uni_f(team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xn, b, tid, false, nullptr));
+                float gd = uni_f(block_dot<Team>(sm, g, d1, N, tid));
                 nls = jl + 1;
                 if (c_n <= FMA(a.A.coef, gd, c_y)) break;
                 if (jl < a.A.maxls - 1) s = s * a.A.dec;
@@ -745,7 +748,7 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : MODE ? 2 : s
             s = a.A.stepsize;
             Team::sync();
             for (int e = tid; e < N; e += Team::NT) { int jj = e % m; xn[e] = clampf(FMA(-s, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]); }
-            c_n = team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xn, b, tid, false, nullptr);
+            c_n = uni_f(team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xn, b, tid, false, nullptr));
             nls = 1;
         }
         sum_ls = sum_ls + (float)nls; sum_s = sum_s + s; nit = k + 1; nls_tot += nls;

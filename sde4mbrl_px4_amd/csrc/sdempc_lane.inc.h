@@ -17,6 +17,7 @@
 // the oracle. State, rigid body and cost are wave-uniform and reuse fwd_head / fwd_tail / vjp_head / vjp_tail.
 // ================================================================================================
 DI int koff(int r) { return (r & 3) + 8 * (r >> 2); }   // rowmap(r, 0)
+DI float uni_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }   // wave-uniform value -> SGPR
 DI float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 // base_bytes: byte address of the chain's first source lane, kept below 256 so that the compiler can fold the constant part into the
 // instruction's offset field (one VALU address add per gather otherwise)
@@ -104,9 +105,16 @@ DI void lane_fwd_mlp(const KArgs& a, const LaneW& W, const float* ust, int lane,
     }
     h2 = lane_tanh(a2, lane);
     const float Mreg = hh ? h1 : h2;     // lanes 0..31: layer-2 activations, lanes 32..63: density hidden units
+    // all 16 gathers first, ONE wait, then the fma chain (left to itself the compiler waits before every fma: for a lone wave a
+    // s_waitcnt costs as much issue time as a vector instruction, tools/salu_probe.hip)
+    float gsrc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gsrc[r] = bperm_f(W.obase << 2, koff(r), Mreg);
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0) (vmcnt 63, expcnt 7: not waited for)
+    __builtin_amdgcn_sched_barrier(0);
     float P = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) P = FMA(W.wo[r], bperm_f(W.obase << 2, koff(r), Mreg), P);
+    for (int r = 0; r < 16; ++r) P = FMA(W.wo[r], gsrc[r], P);
     const float Pc = P + dpp_f<0x128>(P);   // row_ror:8 -> lane c: P_0 + P_1
 #pragma unroll
     for (int i = 0; i < 6; ++i) o[i] = readlane_f(Pc, i) + a.M.b3[i];
@@ -136,15 +144,19 @@ DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp&
     const float ad = accB * g1;
     const float an = (W.w3nk * T.ebraw) * g1;
     const float Abar = hh ? an : ad;
+    float gsrc[32];                     // all gathers, one wait, then the chains (see lane_fwd_mlp)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { gsrc[p] = bperm_f(W.zbase << 2, 32 + koff(p), Abar); gsrc[16 + p] = bperm_f(W.zbase << 2, koff(p), Abar); }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0) (vmcnt 63, expcnt 7: not waited for)
+    __builtin_amdgcn_sched_barrier(0);
     float Pz = 0.0f;
 #pragma unroll
     for (int p = 0; p < 16; ++p) {       // density units first (z-bar chains only)
-        const float src = bperm_f(W.zbase << 2, 32 + koff(p), Abar);
-        const float nv = FMA(W.wz[p], src, Pz);
+        const float nv = FMA(W.wz[p], gsrc[p], Pz);
         Pz = W.is_u ? Pz : nv;
     }
 #pragma unroll
-    for (int p = 0; p < 16; ++p) Pz = FMA(W.wz[16 + p], bperm_f(W.zbase << 2, koff(p), Abar), Pz);
+    for (int p = 0; p < 16; ++p) Pz = FMA(W.wz[16 + p], gsrc[16 + p], Pz);
     const float Pc = Pz + dpp_f<0x128>(Pz);
 #pragma unroll
     for (int kk = 0; kk < NN; ++kk) zb[kk] = readlane_f(Pc, kk);

@@ -116,6 +116,11 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             else { iact = spec; iu = y1; igrad = true; islot = 2; }
             if (grp == 2 && spec && !two) { iact = true; iu = y1; igrad = true; islot = 2; }
         }
+        // The optimiser's scalars are identical in every lane; pinning them to SGPRs across the particle work keeps them out of the
+        // VGPR allocator's way (with 343 registers in use LLVM saved two of them to AGPRs under the partial EXEC mask of a preceding
+        // divergent block and restored them under the full mask: wrong telemetry in lane 0; SGPR spills are whole-wave and safe)
+        c_init = uni_f(c_init); c_x = uni_f(c_x); s = uni_f(s); gsq = uni_f(gsq); sum_ls = uni_f(sum_ls); sum_s = uni_f(sum_s);
+        c_y = uni_f(c_y); c_n = uni_f(c_n);
         if (iact) {      // the only call site of the particle work
             __syncthreads();
             block_prepass<Team>(a, sm, iu, tid);

@@ -25,6 +25,35 @@ DI float bperm_f(int base_bytes, int lane_off, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((base_bytes & 252) + 4 * lane_off, __builtin_bit_cast(int, v)));
 }
 
+// 16 gathers of `src` from lanes (base_bytes/4 + koff(r) + EXTRA) mod 64, r = 0..15, in ONE asm block: the constant part of every address rides
+// in the instruction's offset field (the builtin costs a VALU address op per gather) and a single wait follows (for a lone wave a
+// s_waitcnt costs as much issue time as a vector instruction, tools/salu_probe.hip). koff(r)*4 = 0,4,8,12,32,36,40,44,64,...,108.
+template <int EXTRA_BYTES>
+DI void gather16(int base_bytes, float src, float* g) {
+    static_assert(EXTRA_BYTES == 0 || EXTRA_BYTES == 128, "lane offset 0 or 32");
+    if constexpr (EXTRA_BYTES == 0) {
+        asm volatile(
+            "ds_bpermute_b32 %0, %16, %17\n ds_bpermute_b32 %1, %16, %17 offset:4\n ds_bpermute_b32 %2, %16, %17 offset:8\n ds_bpermute_b32 %3, %16, %17 offset:12\n"
+            "ds_bpermute_b32 %4, %16, %17 offset:32\n ds_bpermute_b32 %5, %16, %17 offset:36\n ds_bpermute_b32 %6, %16, %17 offset:40\n ds_bpermute_b32 %7, %16, %17 offset:44\n"
+            "ds_bpermute_b32 %8, %16, %17 offset:64\n ds_bpermute_b32 %9, %16, %17 offset:68\n ds_bpermute_b32 %10, %16, %17 offset:72\n ds_bpermute_b32 %11, %16, %17 offset:76\n"
+            "ds_bpermute_b32 %12, %16, %17 offset:96\n ds_bpermute_b32 %13, %16, %17 offset:100\n ds_bpermute_b32 %14, %16, %17 offset:104\n ds_bpermute_b32 %15, %16, %17 offset:108\n"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]),
+              "=&v"(g[8]), "=&v"(g[9]), "=&v"(g[10]), "=&v"(g[11]), "=&v"(g[12]), "=&v"(g[13]), "=&v"(g[14]), "=&v"(g[15])
+            : "v"(base_bytes), "v"(src));
+    } else {
+        asm volatile(
+            "ds_bpermute_b32 %0, %16, %17 offset:128\n ds_bpermute_b32 %1, %16, %17 offset:132\n ds_bpermute_b32 %2, %16, %17 offset:136\n ds_bpermute_b32 %3, %16, %17 offset:140\n"
+            "ds_bpermute_b32 %4, %16, %17 offset:160\n ds_bpermute_b32 %5, %16, %17 offset:164\n ds_bpermute_b32 %6, %16, %17 offset:168\n ds_bpermute_b32 %7, %16, %17 offset:172\n"
+            "ds_bpermute_b32 %8, %16, %17 offset:192\n ds_bpermute_b32 %9, %16, %17 offset:196\n ds_bpermute_b32 %10, %16, %17 offset:200\n ds_bpermute_b32 %11, %16, %17 offset:204\n"
+            "ds_bpermute_b32 %12, %16, %17 offset:224\n ds_bpermute_b32 %13, %16, %17 offset:228\n ds_bpermute_b32 %14, %16, %17 offset:232\n ds_bpermute_b32 %15, %16, %17 offset:236\n"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7]),
+              "=&v"(g[8]), "=&v"(g[9]), "=&v"(g[10]), "=&v"(g[11]), "=&v"(g[12]), "=&v"(g[13]), "=&v"(g[14]), "=&v"(g[15])
+            : "v"(base_bytes), "v"(src));
+    }
+}
+
 struct LaneW {
     float w1[NN];        // W1z[32*hh + k][0..5]
     float c1n;           // b1[32 + k] (C operand of the density rows; drift rows take c_t[k] from LDS)
@@ -108,10 +137,7 @@ DI void lane_fwd_mlp(const KArgs& a, const LaneW& W, const float* ust, int lane,
     // all 16 gathers first, ONE wait, then the fma chain (left to itself the compiler waits before every fma: for a lone wave a
     // s_waitcnt costs as much issue time as a vector instruction, tools/salu_probe.hip)
     float gsrc[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gsrc[r] = bperm_f(W.obase << 2, koff(r), Mreg);
-    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0) (vmcnt 63, expcnt 7: not waited for)
-    __builtin_amdgcn_sched_barrier(0);
+    gather16<0>(W.obase << 2, Mreg, gsrc);
     float P = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) P = FMA(W.wo[r], gsrc[r], P);
@@ -144,11 +170,9 @@ DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp&
     const float ad = accB * g1;
     const float an = (W.w3nk * T.ebraw) * g1;
     const float Abar = hh ? an : ad;
-    float gsrc[32];                     // all gathers, one wait, then the chains (see lane_fwd_mlp)
-#pragma unroll
-    for (int p = 0; p < 16; ++p) { gsrc[p] = bperm_f(W.zbase << 2, 32 + koff(p), Abar); gsrc[16 + p] = bperm_f(W.zbase << 2, koff(p), Abar); }
-    __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0) (vmcnt 63, expcnt 7: not waited for)
-    __builtin_amdgcn_sched_barrier(0);
+    float gsrc[32];                     // all gathers first (density units: +32 lanes), then the chains (see lane_fwd_mlp)
+    gather16<128>(W.zbase << 2, Abar, gsrc);
+    gather16<0>(W.zbase << 2, Abar, gsrc + 16);
     float Pz = 0.0f;
 #pragma unroll
     for (int p = 0; p < 16; ++p) {       // density units first (z-bar chains only)

@@ -170,17 +170,17 @@ DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp&
     const float ad = accB * g1;
     const float an = (W.w3nk * T.ebraw) * g1;
     const float Abar = hh ? an : ad;
-    float gsrc[32];                     // all gathers first (density units: +32 lanes), then the chains (see lane_fwd_mlp)
-    gather16<128>(W.zbase << 2, Abar, gsrc);
-    gather16<0>(W.zbase << 2, Abar, gsrc + 16);
+    float gsrc[16];                     // gather (one block, one wait: see lane_fwd_mlp), then the chain; density units first
     float Pz = 0.0f;
+    gather16<128>(W.zbase << 2, Abar, gsrc);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {       // density units first (z-bar chains only)
+    for (int p = 0; p < 16; ++p) {       // density units (z-bar chains only)
         const float nv = FMA(W.wz[p], gsrc[p], Pz);
         Pz = W.is_u ? Pz : nv;
     }
+    gather16<0>(W.zbase << 2, Abar, gsrc);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) Pz = FMA(W.wz[16 + p], gsrc[16 + p], Pz);
+    for (int p = 0; p < 16; ++p) Pz = FMA(W.wz[16 + p], gsrc[p], Pz);
     const float Pc = Pz + dpp_f<0x128>(Pz);
 #pragma unroll
     for (int kk = 0; kk < NN; ++kk) zb[kk] = readlane_f(Pc, kk);

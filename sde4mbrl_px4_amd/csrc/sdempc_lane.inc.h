@@ -174,10 +174,8 @@ DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp&
     float Pz = 0.0f;
     gather16<128>(W.zbase << 2, Abar, gsrc);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {       // density units (z-bar chains only)
-        const float nv = FMA(W.wz[p], gsrc[p], Pz);
-        Pz = W.is_u ? Pz : nv;
-    }
+    for (int p = 0; p < 16; ++p) Pz = FMA(W.wz[p], gsrc[p], Pz);     // density units
+    Pz = W.is_u ? 0.0f : Pz;             // the gu-bar chains start at the drift units (whatever the density part produced in those lanes is dropped)
     gather16<0>(W.zbase << 2, Abar, gsrc);
 #pragma unroll
     for (int p = 0; p < 16; ++p) Pz = FMA(W.wz[16 + p], gsrc[p], Pz);

@@ -91,7 +91,8 @@ def main():
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "c2_iris_traj_h50_p128.yaml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--latency-reps", type=int, default=40)
+    ap.add_argument("--latency-reps", type=int, default=1000)
+    ap.add_argument("--latency-warmup", type=int, default=20)
     ap.add_argument("--mlp-dtype", default="f32", choices=["f32", "f16"],
                     help="f32: bit-reproducible path (default, the reported metric); f16: fp16-operand MLP contractions (SPEC.md 9)")
     args = ap.parse_args()
@@ -199,15 +200,19 @@ def main():
                 traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        # p50 latency of a single solve (B=1 launches), outside the timed region
+        # p50 / p95 latency of a single solve (B=1 launches), outside the timed region: SURVEY.md §8(d) protocol, >= 20 warm-up
+        # and >= 1000 timed solves by default, one problem instance after the other (host timestamps around a device sync)
         lat = []
-        for _ in range(args.latency_reps):
+        nv = noise.view(B, -1)
+        for r in range(-args.latency_warmup, args.latency_reps):
+            i = r % B
             torch.cuda.synchronize()
             t = time.perf_counter()
-            solver.solve_dev(1, x0.data_ptr(), xref.data_ptr(), noise.data_ptr(), u0.data_ptr(), step_in.data_ptr(),
-                             uopt.data_ptr(), xevol.data_ptr(), info.data_ptr(), stream)
+            solver.solve_dev(1, x0[i:].data_ptr(), xref[i:].data_ptr(), nv[i:].data_ptr(), u0[i:].data_ptr(), step_in[i:].data_ptr(),
+                             uopt[i:].data_ptr(), xevol[i:].data_ptr(), info[i:].data_ptr(), stream)
             torch.cuda.synchronize()
-            lat.append((time.perf_counter() - t) * 1e3)
+            if r >= 0:
+                lat.append((time.perf_counter() - t) * 1e3)
         out = {
             "metric": "MPC solves/sec, Iris H=50 P=128 (p50 solve latency in p50_solve_latency_ms)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -139,10 +139,12 @@ int sdempc_grad_batch(sdempc_handle* h, int32_t B, const float* x0, const float*
  * Execution layout is chosen per call and never changes a bit of the result: P = 1 instances (all YAMLs the reference ships) run in a
  * single-particle layout; batches small enough that all workgroups are resident at once (C2: up to 15 instances) are spread over many
  * workgroups, one particle per wave, with one bounded grid barrier per rollout, and for the smallest batches additionally evaluate two
- * line-search trials and the candidate gradients of the next iteration at once (C2 single solve: 41 ms instead of 158 ms); larger
+ * line-search trials and the candidate gradients of the next iteration at once (C2 single solve: 33 ms instead of 158 ms); larger
  * batches run one workgroup per instance in the 32-particle MFMA tile layout (throughput). The cooperative layouts assume that no other
  * kernel occupies the GPU while they run; if their workgroups cannot all become resident the barrier gives up after a bounded number of
- * polls: the telemetry of the call is NaN and the host-pointer entry points return SDEMPC_EDEVICE. */
+ * polls and the telemetry of the launch is NaN. The host-pointer entry points then run the same batch once more in the
+ * one-workgroup-per-instance layout (identical results) and the handle stays off the cooperative layouts from then on
+ * (sdempc_layout_fallbacks counts these events); callers of sdempc_solve_batch_dev ask sdempc_solve_status. */
 int sdempc_solve_batch(sdempc_handle* h, int32_t B, const float* x0, const float* xref,
                        const float* noise, const float* u_init /*[B][H][m]*/,
                        const float* stepsize_in /*[B]*/,
@@ -187,6 +189,14 @@ int sdempc_noise_from_keys(sdempc_handle* h, int32_t B, const uint32_t* keys, fl
 int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const float* xref, const uint32_t* keys,
                             const float* u_init /*[B][H][m]*/, const float* stepsize_in /*[B]*/,
                             float* uopt /*[B][H][m]*/, float* xevol /*[B][H+1][13]*/, sdempc_info* info /*[B]*/);
+
+/* After the stream of the last sdempc_solve_batch_dev call has been synchronised: SDEMPC_OK, or SDEMPC_EDEVICE when a grid barrier of
+ * a cooperative layout gave up (results of that call invalid, telemetry NaN). The handle then stays off the cooperative layouts, so
+ * repeating the call runs in the one-workgroup-per-instance layout. New in this build (no reference counterpart: the reference's
+ * solver call, sde_control.py:405-416, either returns or kills the process). */
+int sdempc_solve_status(sdempc_handle* h);
+/* Number of times this handle left the cooperative layouts because a grid barrier gave up (0 in normal operation). */
+int32_t sdempc_layout_fallbacks(const sdempc_handle* h);
 
 /* Times the last *_dev launch on its own stream with HIP events (ms); <0 if unavailable. */
 float sdempc_last_kernel_ms(const sdempc_handle* h);

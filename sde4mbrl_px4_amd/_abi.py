@@ -104,6 +104,10 @@ def load_library():
     lib.sdempc_noise_from_keys_dev.argtypes = [vp, i32, u32p, vp, vp]
     lib.sdempc_noise_from_keys.argtypes = [vp, i32, u32p, fp]
     lib.sdempc_solve_batch_keys.argtypes = [vp, i32, fp, fp, u32p, fp, fp, fp, fp, C.POINTER(SdempcInfo)]
+    lib.sdempc_solve_status.argtypes = [vp]
+    lib.sdempc_solve_status.restype = C.c_int
+    lib.sdempc_layout_fallbacks.argtypes = [vp]
+    lib.sdempc_layout_fallbacks.restype = C.c_int32
     lib.sdempc_last_kernel_ms.argtypes = [vp]
     lib.sdempc_last_kernel_ms.restype = C.c_float
     for name in ("sdempc_set_device", "sdempc_reset", "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch",
@@ -119,6 +123,6 @@ EXPORTED_SYMBOLS = [
     "sdempc_create", "sdempc_destroy", "sdempc_last_error", "sdempc_abi_version", "sdempc_set_device", "sdempc_reset",
     "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch", "sdempc_noise_dev_floats",
     "sdempc_traj_dev_floats", "sdempc_noise_to_device_layout", "sdempc_solve_batch_dev", "sdempc_rollout_batch_dev",
-    "sdempc_grad_batch_dev", "sdempc_last_kernel_ms", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev",
+    "sdempc_grad_batch_dev", "sdempc_last_kernel_ms", "sdempc_solve_status", "sdempc_layout_fallbacks", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev",
     "sdempc_noise_from_keys_dev", "sdempc_noise_from_keys", "sdempc_solve_batch_keys",
 ]

@@ -69,6 +69,8 @@ struct sdempc_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int last_coop_B = 0;      // > 0: the last solve launch took the cooperative path with this many instances (error flags to check)
+    bool coop_off = false;    // a grid barrier timed out once: this handle stays on the one-workgroup-per-instance layouts
+    int layout_fallbacks = 0; // how often that happened (sdempc_layout_fallbacks)
 };
 
 namespace {
@@ -209,12 +211,19 @@ int noise_from_keys(sdempc_handle* h, int B, const uint32_t* keys, float* out_de
 }
 
 // after a synchronised cooperative solve: did any grid barrier give up? (telemetry is NaN in that case as well)
-int check_coop_flags(sdempc_handle* h) {
+// Did a grid barrier of the last (cooperative-layout) solve launch give up? Call after the launch's stream has been synchronised.
+int coop_timed_out(sdempc_handle* h, bool* timed_out) {
+    *timed_out = false;
     if (h->last_coop_B <= 0) return 0;
     std::vector<unsigned> f(2 * (size_t)h->last_coop_B);
     HIPCHK(h, hipMemcpy(f.data(), h->d_coop_bar.p, sizeof(unsigned) * f.size(), hipMemcpyDeviceToHost));
     for (int b = 0; b < h->last_coop_B; ++b)
-        if (f[2 * b + 1] != 0u) return fail(h, SDEMPC_EDEVICE, "cooperative solve: a grid barrier timed out (workgroups not co-resident?)%s");
+        if (f[2 * b + 1] != 0u) *timed_out = true;
+    if (*timed_out) {                    // the workgroups were not all resident (GPU shared with other work): no second try on this handle
+        h->coop_off = true;
+        h->layout_fallbacks += 1;
+        h->last_coop_B = 0;
+    }
     return 0;
 }
 
@@ -228,6 +237,8 @@ int timed_launch(sdempc_handle* h, hipStream_t st, F&& f) {
     return 0;
 }
 
+
+int solve_staged(sdempc_handle* h, int32_t B, float* uopt, float* xevol, sdempc_info* info);
 }  // namespace
 
 extern "C" {
@@ -425,8 +436,9 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     // Small batches of multi-particle instances: one instance over ceil(P/4) workgroups, one particle per wave (latency path).
     // Same results bit for bit; only taken when every workgroup of the grid is resident at once.
-    const int smax = (!a.fast && !a.f16) ? spec_max_instances(h->P, h->H, h->m) : 0;
-    int cmax = (!a.fast && !a.f16) ? coop_max_instances(h->P, h->H, h->m) : 0;
+    const bool coop_ok = !a.fast && !a.f16 && !h->coop_off;
+    const int smax = coop_ok ? spec_max_instances(h->P, h->H, h->m) : 0;
+    int cmax = coop_ok ? coop_max_instances(h->P, h->H, h->m) : 0;
     if (smax > cmax) cmax = smax;
     if (B <= cmax) {
         if (!h->d_coop_bar.p) {
@@ -523,13 +535,7 @@ int sdempc_solve_batch(sdempc_handle* h, int32_t B, const float* x0, const float
     if ((rc = ensure_device(h))) return rc;
     if ((rc = stage_common(h, B, x0, u_init, xref, noise))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_step.p, stepsize_in, sizeof(float) * B, hipMemcpyHostToDevice, h->stream));
-    rc = sdempc_solve_batch_dev(h, B, h->d_x0.p, h->d_xref.p, h->d_noise.p, h->d_u.p, h->d_step.p, h->d_uopt.p, h->d_xmean.p, h->d_info.p, h->stream);
-    if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(uopt, h->d_uopt.p, sizeof(float) * B * h->H * h->m, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(xevol, h->d_xmean.p, sizeof(float) * B * (h->H + 1) * SDEMPC_NX, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof(float) * B * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return check_coop_flags(h);
+    return solve_staged(h, B, uopt, xevol, info);
 }
 
 int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const float* xref, const uint32_t* keys, const float* u_init,
@@ -544,13 +550,38 @@ int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const 
     HIPCHK(h, hipMemcpyAsync(h->d_xref.p, xref, sizeof(float) * B * (H + 1) * SDEMPC_NX, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_step.p, stepsize_in, sizeof(float) * B, hipMemcpyHostToDevice, h->stream));
     if ((rc = noise_from_keys(h, B, keys, (float*)h->d_noise.p, h->stream))) return rc;
-    rc = sdempc_solve_batch_dev(h, B, h->d_x0.p, h->d_xref.p, h->d_noise.p, h->d_u.p, h->d_step.p, h->d_uopt.p, h->d_xmean.p, h->d_info.p, h->stream);
-    if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(uopt, h->d_uopt.p, sizeof(float) * B * H * m, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(xevol, h->d_xmean.p, sizeof(float) * B * (H + 1) * SDEMPC_NX, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof(float) * B * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return check_coop_flags(h);
+    return solve_staged(h, B, uopt, xevol, info);
 }
 
+int sdempc_solve_status(sdempc_handle* h) {
+    if (!h) return SDEMPC_EINVAL;
+    bool to = false;
+    int rc = coop_timed_out(h, &to);
+    if (rc) return rc;
+    return to ? fail(h, SDEMPC_EDEVICE, "cooperative solve: a grid barrier timed out (workgroups not co-resident); results invalid, "
+                                        "the handle now stays on the one-workgroup-per-instance layouts%s") : SDEMPC_OK;
+}
+
+int32_t sdempc_layout_fallbacks(const sdempc_handle* h) { return h ? h->layout_fallbacks : 0; }
+
 }  // extern "C"
+
+namespace {
+// Solve on the staged inputs (handle buffers) and fetch the results. If a grid barrier of the cooperative layouts gave up — their
+// workgroups were not all resident, i.e. the GPU is shared with other work — the same batch runs once more in the one-workgroup-per-
+// instance layout (bit-identical results by construction) and the handle keeps off the cooperative layouts from then on.
+int solve_staged(sdempc_handle* h, int32_t B, float* uopt, float* xevol, sdempc_info* info) {
+    for (int attempt = 0;; ++attempt) {
+        int rc = sdempc_solve_batch_dev(h, B, h->d_x0.p, h->d_xref.p, h->d_noise.p, h->d_u.p, h->d_step.p, h->d_uopt.p, h->d_xmean.p, h->d_info.p, h->stream);
+        if (rc) return rc;
+        HIPCHK(h, hipMemcpyAsync(uopt, h->d_uopt.p, sizeof(float) * B * h->H * h->m, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(xevol, h->d_xmean.p, sizeof(float) * B * (h->H + 1) * SDEMPC_NX, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(info, h->d_info.p, sizeof(float) * B * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        bool to = false;
+        if ((rc = coop_timed_out(h, &to))) return rc;
+        if (!to) return SDEMPC_OK;
+        if (attempt) return fail(h, SDEMPC_EDEVICE, "cooperative solve: a grid barrier timed out twice%s");
+    }
+}
+}  // namespace

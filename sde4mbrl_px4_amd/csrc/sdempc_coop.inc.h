@@ -12,11 +12,10 @@
 struct CoopCtx {
     int nwg, wgi, Ppad;
     unsigned* bar;          // this instance's arrival counter (zeroed by the host before the launch), bar[1] = error flag
-    unsigned epoch;
+    unsigned epoch, spin_limit;
     float* pp;              // [2][PS][Ppad] per-particle outputs, double-buffered by rollout parity
     float* ck;              // [P][H+1][COOP_ROW] checkpoint rows
 };
-constexpr unsigned COOP_SPIN_LIMIT = 8u * 1000u * 1000u;     // polls of one barrier before giving up (several seconds)
 
 DI void coop_barrier(CoopCtx& C, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's (sc1) stores of the handed-off values have completed
@@ -30,7 +29,7 @@ DI void coop_barrier(CoopCtx& C, int tid) {
         while (__hip_atomic_load(C.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if (__hip_atomic_load(C.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;      // another workgroup gave up
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > COOP_SPIN_LIMIT) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (++spins > C.spin_limit) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
         if (SDEMPC_COOP_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }

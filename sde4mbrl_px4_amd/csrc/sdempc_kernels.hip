@@ -664,7 +664,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     int b_;                                                                          \
     if constexpr (MODE == 2) {                                                       \
         b_ = blockIdx.x / a.coop_nwg;                                                \
-        CC.nwg = a.coop_nwg; CC.wgi = blockIdx.x - b_ * a.coop_nwg; CC.Ppad = a.G * 32; CC.epoch = 0u;            \
+        CC.nwg = a.coop_nwg; CC.wgi = blockIdx.x - b_ * a.coop_nwg; CC.Ppad = a.G * 32; CC.epoch = 0u; CC.spin_limit = a.coop_spin; \
         CC.bar = a.coop_bar + 2 * b_;                                                \
         CC.pp = a.coop_pp + (size_t)b_ * 2 * part_stride(a.H) * CC.Ppad;             \
         CC.ck = a.coop_ck + (size_t)b_ * a.P * (a.H + 1) * COOP_ROW;                 \
@@ -901,6 +901,12 @@ int spec_max_instances(int P, int H, int m) {
     if (smem_bytes(H, m, 1, true) + 4 * nv * sizeof(float) > 160 * 1024) return 0;
     return device_cus() / (2 * coop_nwg(P));                    // built for one workgroup per CU; at least two groups per instance
 }
+// polls of one grid barrier before it gives up and raises the instance's error flag: several seconds by default; SDEMPC_COOP_SPIN
+// (read per launch) lets the tests provoke the timeout
+static unsigned coop_spin_limit() {
+    const char* e = getenv("SDEMPC_COOP_SPIN");
+    return e ? (unsigned)strtoul(e, nullptr, 10) : 8u * 1000u * 1000u;
+}
 template <int M>
 static hipError_t launch_spec_m(const KArgs& k, hipStream_t st) {
     auto kern = sdempc_solve_spec_kernel<M>;
@@ -914,6 +920,7 @@ hipError_t launch_solve_spec(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B; k.coop_nwg = coop_nwg(k.P);
     if (B < 1 || B > spec_max_instances(k.P, k.H, k.m) || !k.coop_bar || !k.coop_pp || !k.coop_ck) return hipErrorInvalidValue;
     k.coop_ngrp = device_cus() / (B * k.coop_nwg);
+    k.coop_spin = coop_spin_limit();
     if (k.coop_ngrp > SPEC_GROUPS) k.coop_ngrp = SPEC_GROUPS;
     if (k.m == 4) return launch_spec_m<4>(k, st);
     if (k.m == 6) return launch_spec_m<6>(k, st);
@@ -938,6 +945,7 @@ static hipError_t launch_coop_m(const KArgs& k, hipStream_t st) {
 hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B; k.coop_nwg = coop_nwg(k.P);
     if (B < 1 || B > coop_max_instances(k.P, k.H, k.m) || !k.coop_bar || !k.coop_pp || !k.coop_ck) return hipErrorInvalidValue;
+    k.coop_spin = coop_spin_limit();
     if (k.m == 4) return launch_coop_m<4>(k, st);
     if (k.m == 6) return launch_coop_m<6>(k, st);
     return launch_coop_m<8>(k, st);

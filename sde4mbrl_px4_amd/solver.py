@@ -172,5 +172,13 @@ class SdeMpcSolver:
     def grad_dev(self, B, x0, u, xref, noise_dev, cost, grad, stream=0):
         self._check(self.lib.sdempc_grad_batch_dev(self._h, B, x0, u, xref, noise_dev, cost, grad, C.c_void_p(stream)))
 
+    def solve_status(self):
+        """After synchronising the stream of the last solve_dev call: raises SdempcError if a grid barrier of a cooperative layout
+        gave up (results invalid; the handle then stays on the one-workgroup-per-instance layouts, so the call can be repeated)."""
+        self._check(self.lib.sdempc_solve_status(self._h))
+
+    def layout_fallbacks(self) -> int:
+        return int(self.lib.sdempc_layout_fallbacks(self._h))
+
     def last_kernel_ms(self) -> float:
         return float(self.lib.sdempc_last_kernel_ms(self._h))

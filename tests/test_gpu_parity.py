@@ -502,3 +502,46 @@ def test_single_instance_full_length_solve_bit_exact(cfg_name, iters, layout):
     _close(uopt[0], uo, "uopt")
     assert io[2] > 50 and bits_differ(uopt[0], uo) == 0 and bits_differ(xevol[0], xe) == 0 and bits_differ(info[0], io) == 0
     S.close()
+
+
+# ---- cooperative layouts on a GPU they cannot have to themselves: bounded barrier, fallback to the tile layout ----------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", ["1", "0"])
+def test_barrier_timeout_falls_back_to_tile_layout(spec, monkeypatch):
+    """SDEMPC_COOP_SPIN=0 makes every grid barrier give up on its first unsuccessful poll (what happens, after seconds, when the
+    workgroups of a cooperative launch are not all resident). Device API: NaN telemetry + sdempc_solve_status = EDEVICE, and the handle
+    leaves the cooperative layouts; host-pointer API: the batch is re-run in the tile layout, results equal the oracle's bit for bit."""
+    import torch
+    from sde4mbrl_px4_amd.solver import SdempcError
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(horizon=12, num_short_dt=12, num_particles=72, max_iter=6, max_no_improvement_iter=6)
+    B = 2
+    x0, xref, noise, u = _problem(cfg, B, 5)
+    s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
+    uo, xo, io = orc.Oracle(cfg, synthetic_iris()).solve_batch(x0, xref, noise, u, s0)
+    monkeypatch.setenv("SDEMPC_SPEC", spec)
+    monkeypatch.setenv("SDEMPC_COOP_SPIN", "0")
+    # host-pointer entry point: transparent fallback
+    S = _solver(cfg, synthetic_iris(), B)
+    ug, xg, ig = S.solve(x0, xref, noise, u, s0)
+    assert S.layout_fallbacks() == 1
+    assert bits_differ(ug, uo) == 0 and bits_differ(xg, xo) == 0 and bits_differ(ig, io) == 0
+    ug, xg, ig = S.solve(x0, xref, noise, u, s0)                  # the handle stays on the tile layout: no second timeout
+    assert S.layout_fallbacks() == 1 and bits_differ(ug, uo) == 0
+    S.close()
+    # device entry point: the caller asks for the status
+    S = _solver(cfg, synthetic_iris(), B)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d = dict(x0=t(x0), xref=t(xref), nd=t(S.noise_to_device_layout(noise)), u=t(u), s=t(s0))
+    uopt, xev, info = torch.zeros((B, 12, 4), device="cuda"), torch.zeros((B, 13, 13), device="cuda"), torch.zeros((B, 8), device="cuda")
+    run = lambda: S.solve_dev(B, d["x0"].data_ptr(), d["xref"].data_ptr(), d["nd"].data_ptr(), d["u"].data_ptr(), d["s"].data_ptr(),
+                              uopt.data_ptr(), xev.data_ptr(), info.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    run()
+    torch.cuda.synchronize()
+    with pytest.raises(SdempcError, match="barrier"):
+        S.solve_status()
+    assert np.isnan(info.cpu().numpy()).any() and S.layout_fallbacks() == 1
+    run()
+    torch.cuda.synchronize()
+    S.solve_status()
+    assert bits_differ(uopt.cpu().numpy(), uo) == 0 and bits_differ(info.cpu().numpy(), io) == 0
+    S.close()

@@ -898,7 +898,7 @@ int spec_max_instances(int P, int H, int m) {
     const char* fc = getenv("SDEMPC_COOP");
     if ((force && force[0] == '0') || (fc && fc[0] == '0')) return 0;      // P == 1 is welcome here (one wave per workgroup is active)
     const size_t nv = (size_t)((H * m + 3) & ~3);
-    if (smem_bytes(H, m, 1, true) + 4 * nv * sizeof(float) > 160 * 1024) return 0;
+    if (smem_bytes(H, m, 1, true) + (4 * nv + SPEC_MRED) * sizeof(float) > 160 * 1024) return 0;
     return device_cus() / (2 * coop_nwg(P));                    // built for one workgroup per CU; at least two groups per instance
 }
 // polls of one grid barrier before it gives up and raises the instance's error flag: several seconds by default; SDEMPC_COOP_SPIN
@@ -910,7 +910,7 @@ static unsigned coop_spin_limit() {
 template <int M>
 static hipError_t launch_spec_m(const KArgs& k, hipStream_t st) {
     auto kern = sdempc_solve_spec_kernel<M>;
-    const size_t sb = smem_bytes(k.H, k.m, 1, true) + 4 * (size_t)((k.H * k.m + 3) & ~3) * sizeof(float);
+    const size_t sb = smem_bytes(k.H, k.m, 1, true) + (4 * (size_t)((k.H * k.m + 3) & ~3) + SPEC_MRED) * sizeof(float);
     hipError_t e = set_smem_attr((const void*)kern, sb);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(k.B * k.coop_ngrp * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);

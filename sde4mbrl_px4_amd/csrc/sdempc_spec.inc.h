@@ -36,6 +36,26 @@ DI float spec_cost(const KArgs& a, const Smem& sm, const CoopCtx& C, int tid, un
     __syncthreads();
     return FMA(sm.red[12], a.invP, cu);
 }
+// K reductions of SPEC.md §6.2 with one pair of barriers (each one the arithmetic of team_reduce256: chain e = tid, tid + 256, ...;
+// 64-lane butterflies; ((w0+w1)+w2)+w3) — a lone workgroup pays ~1.4 us per separate reduction, and an iteration has nine of them
+template <int K, class F>
+DI void spec_reduce_n(float* mred, int N, int tid, float (&out)[K], F&& elem) {
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+    for (int e = tid; e < N; e += 256) elem(e, acc);
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = wave_bfly64(acc[k]);
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) mred[4 * k + (tid >> 6)] = acc[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = ((mred[4 * k] + mred[4 * k + 1]) + mred[4 * k + 2]) + mred[4 * k + 3];
+}
+constexpr int SPEC_MRED = 32;      // floats of reduction scratch behind the four extra control vectors
 // one workgroup per CU (512 registers per lane: what does not fit the 256 VGPRs spills to AGPRs, not to scratch memory — with two
 // workgroups per CU the adjoint loop carried 43 scratch accesses per step and ran 3x slower)
 template <int M>
@@ -65,7 +85,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     load_common<Team>(a, sm, b, tid);
     const int nv = (N + 3) & ~3;
     float* ex = sm.tot + ((H * 12 + 3) & ~3);
-    float *xn1 = ex, *xn2 = ex + nv, *y1 = ex + 2 * nv, *y2 = ex + 3 * nv;
+    float *xn1 = ex, *xn2 = ex + nv, *y1 = ex + 2 * nv, *y2 = ex + 3 * nv, *mred = ex + 4 * nv;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
     for (int e = tid; e < N; e += Team::NT) {
         int jj = e % m;
@@ -80,6 +100,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     unsigned red_cnt = 0u, red_par = 0u; int red_slot = 0;
     int phase = PH_INIT;
     float c_init = 0.0f, c_x = 0.0f, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f, c_y = 0.0f, c_n = 0.0f;
+    float gd_1 = 0.0f, gd_2 = 0.0f, rs_1 = 0.0f, rs_2 = 0.0f, cu_1 = 0.0f, cu_2 = 0.0f;      // of the two parallel trials, known before they run
     int k = 0, kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1, nls = 0, jsel = 0, jl = 0;
     unsigned par_cnt = 0u, par_spec = 0u;
     bool spec = false, two = false;
@@ -121,6 +142,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         // divergent block and restored them under the full mask: wrong telemetry in lane 0; SGPR spills are whole-wave and safe)
         c_init = uni_f(c_init); c_x = uni_f(c_x); s = uni_f(s); gsq = uni_f(gsq); sum_ls = uni_f(sum_ls); sum_s = uni_f(sum_s);
         c_y = uni_f(c_y); c_n = uni_f(c_n);
+        gd_1 = uni_f(gd_1); gd_2 = uni_f(gd_2); rs_1 = uni_f(rs_1); rs_2 = uni_f(rs_2); cu_1 = uni_f(cu_1); cu_2 = uni_f(cu_2);
         if (iact) {      // the only call site of the particle work
             __syncthreads();
             block_prepass<Team>(a, sm, iu, tid);
@@ -155,24 +177,31 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             __syncthreads();
             head = true;
         } else if (phase == PH_PAR) {
+            // both trial costs at once: particle totals by waves 0 / 1, control costs and g.d known since the head of the iteration
+            const int PSs = part_stride(H);
             __syncthreads();
-            for (int e = tid; e < N; e += Team::NT) { xn[e] = xn1[e]; d1[e] = xn1[e] - yk[e]; }
-            c_n = spec_cost(a, sm, C, tid, par, xn1, 0);
+            if (wave < (two ? 2 : 1)) {
+                const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + wave) * PSs * C.Ppad;
+                const float t0 = coop_total(pbuf + (size_t)(PSs - 1) * C.Ppad, a.P, a.G, lane);
+                if (lane == 0) sm.red[12 + wave] = t0;
+            }
+            __syncthreads();
+            c_n = FMA(sm.red[12], a.invP, cu_1);
             nls = 1; jsel = 1;
             bool done = !has_ls;
             if (has_ls) {
-                const float gd = block_dot<Team>(sm, g, d1, N, tid);
-                if (c_n <= FMA(a.A.coef, gd, c_y)) done = true;
+                if (c_n <= FMA(a.A.coef, gd_1, c_y)) done = true;
                 else if (0 < a.A.maxls - 1) s = s * a.A.dec;
             }
             if (!done && two) {
-                __syncthreads();
-                for (int e = tid; e < N; e += Team::NT) { xn[e] = xn2[e]; d1[e] = xn2[e] - yk[e]; }
-                c_n = spec_cost(a, sm, C, tid, par, xn2, 1);
-                const float gd = block_dot<Team>(sm, g, d1, N, tid);
+                c_n = FMA(sm.red[13], a.invP, cu_2);
                 nls = 2; jsel = 2;
-                if (c_n <= FMA(a.A.coef, gd, c_y)) done = true;
+                if (c_n <= FMA(a.A.coef, gd_2, c_y)) done = true;
                 else if (1 < a.A.maxls - 1) s = s * a.A.dec;
+            }
+            {
+                const float* xj = jsel == 2 ? xn2 : xn1;
+                for (int e = tid; e < N; e += Team::NT) xn[e] = xj[e];
             }
             if (!done && 2 < a.A.maxls) {        // further trials one at a time
                 jl = 2;
@@ -227,14 +256,17 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             int hit_slot = -1;
             __syncthreads();
             if (c_n < c_x) {
-                for (int e = tid; e < N; e += Team::NT) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
-                float rs = block_dot<Team>(sm, d1, d2, N, tid);
+                float rs = jsel == 1 ? rs_1 : rs_2;          // restart test of a parallel trial: known since the head
+                if (jsel == 0) {
+                    for (int e = tid; e < N; e += Team::NT) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
+                    rs = block_dot<Team>(sm, d1, d2, N, tid);
+                }
                 if (rs > 0.0f) {
                     kr = 0; plain = 1;
                     for (int e = tid; e < N; e += Team::NT) { yk[e] = xn[e]; xk[e] = xn[e]; }
                 } else {
                     float bt = a.beta[kr];
-                    for (int e = tid; e < N; e += Team::NT) { int jj = e % m; yk[e] = clampf(FMA(bt, d2[e], xn[e]), a.C.ulo[jj], a.C.uhi[jj]); xk[e] = xn[e]; }
+                    for (int e = tid; e < N; e += Team::NT) { int jj = e % m; const float dd = xn[e] - xk[e]; yk[e] = clampf(FMA(bt, dd, xn[e]), a.C.ulo[jj], a.C.uhi[jj]); xk[e] = xn[e]; }
                     kr = kr + 1; plain = 0;
                 }
                 c_x = c_n; noimp = 0;
@@ -255,17 +287,14 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             else phase = PH_GRAD;
         }
         if (head) {      // start of iteration k with (c_y, g) in hand
-            gsq = block_dot<Team>(sm, g, g, N, tid);
-            if (!(gsq < __builtin_inff())) { phase = PH_FINAL; continue; }
+            float sn = s;
             if (has_ls) {
-                if (k > 0 && a.A.reset_inc) s = s * a.A.inc;
-                if (s > a.A.smax) s = a.A.smax;
+                if (k > 0 && a.A.reset_inc) sn = sn * a.A.inc;
+                if (sn > a.A.smax) sn = a.A.smax;
             } else {
-                s = a.A.stepsize;
+                sn = a.A.stepsize;
             }
-            two = (has_ls ? a.A.maxls : 1) > 1;
-            spec = (k + 1 < a.A.max_iter);
-            const float s1 = s, s2 = s * a.A.dec;
+            const float s1 = sn, s2 = sn * a.A.dec;
             __syncthreads();
             for (int e = tid; e < N; e += Team::NT) {
                 int jj = e % m;
@@ -273,16 +302,34 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 xn2[e] = clampf(FMA(-s2, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
             }
             __syncthreads();
+            // everything the optimiser will ask about the two parallel trials except their particle costs, in one reduction:
+            // |g|^2; g.(xn_j - yk) of the Armijo tests; the restart tests (yk - xn_j).(xn_j - xk); the control costs of xn_j
+            float r7[7];
+            spec_reduce_n<7>(mred, N, tid, r7, [&](int e, float (&acc)[7]) {
+                const float ge = g[e], ye = yk[e], xe = xk[e], x1 = xn1[e], x2 = xn2[e];
+                acc[0] = FMA(ge, ge, acc[0]);
+                acc[1] = FMA(ge, x1 - ye, acc[1]);
+                acc[2] = FMA(ge, x2 - ye, acc[2]);
+                acc[3] = FMA(ye - x1, x1 - xe, acc[3]);
+                acc[4] = FMA(ye - x2, x2 - xe, acc[4]);
+                acc[5] = FMA(ucost_elem(a, sm, xn1, e, m), 1.0f, acc[5]);
+                acc[6] = FMA(ucost_elem(a, sm, xn2, e, m), 1.0f, acc[6]);
+            });
+            gsq = r7[0];
+            if (!(gsq < __builtin_inff())) { phase = PH_FINAL; continue; }      // (s keeps the value of the last completed iteration)
+            s = sn;
+            gd_1 = r7[1]; gd_2 = r7[2]; rs_1 = r7[3]; rs_2 = r7[4]; cu_1 = r7[5]; cu_2 = r7[6];
+            two = (has_ls ? a.A.maxls : 1) > 1;
+            spec = (k + 1 < a.A.max_iter);
             // where the optimiser moves if it ends on trial j with an improvement (the expressions of the tail above)
-            for (int jtr = 0; jtr < (two ? 2 : 1); ++jtr) {
-                const float* xj = jtr ? xn2 : xn1;
-                float* yj = jtr ? y2 : y1;
-                for (int e = tid; e < N; e += Team::NT) { d1[e] = yk[e] - xj[e]; d2[e] = xj[e] - xk[e]; }
-                const float rs = block_dot<Team>(sm, d1, d2, N, tid);
-                const float bt = a.beta[kr];
-                for (int e = tid; e < N; e += Team::NT) { int jj = e % m; yj[e] = (rs > 0.0f) ? xj[e] : clampf(FMA(bt, d2[e], xj[e]), a.C.ulo[jj], a.C.uhi[jj]); }
-                __syncthreads();
+            const float bt = a.beta[kr];
+            for (int e = tid; e < N; e += Team::NT) {
+                int jj = e % m;
+                const float x1 = xn1[e], x2 = xn2[e], xe = xk[e];
+                y1[e] = (rs_1 > 0.0f) ? x1 : clampf(FMA(bt, x1 - xe, x1), a.C.ulo[jj], a.C.uhi[jj]);
+                if (two) y2[e] = (rs_2 > 0.0f) ? x2 : clampf(FMA(bt, x2 - xe, x2), a.C.ulo[jj], a.C.uhi[jj]);
             }
+            __syncthreads();
             phase = PH_PAR;
         }
     }

@@ -907,14 +907,32 @@ static unsigned coop_spin_limit() {
     const char* e = getenv("SDEMPC_COOP_SPIN");
     return e ? (unsigned)strtoul(e, nullptr, 10) : 8u * 1000u * 1000u;
 }
+// All workgroups of a cooperative-layout grid must be resident at once. Default: a plain launch of a grid sized to fit
+// (coop_max_instances / spec_max_instances) with every barrier bounded (sdempc_coop.inc.h). SDEMPC_COOP_LAUNCH=1 goes through
+// hipLaunchCooperativeKernel instead: the runtime validates the grid against the kernel's occupancy and schedules it as a unit —
+// same latency and same results on MI355X (all parity tests), but a process that used it crashes at exit under rocprofv3
+// (ROCm 7.2: SIGSEGV in the exit handlers after the profile is written), so it is opt-in.
+template <class K>
+static hipError_t launch_resident(K kern, dim3 grid, dim3 block, size_t sb, hipStream_t st, const KArgs& k) {
+    const char* e = getenv("SDEMPC_COOP_LAUNCH");
+    if (e && e[0] == '1') {
+        KArgs kk = k;
+        void* args[] = {(void*)&kk};
+        const hipError_t rc = hipLaunchCooperativeKernel((const void*)kern, grid, block, args, (unsigned)sb, st);
+        if (rc == hipSuccess) return rc;
+        (void)hipGetLastError();
+        if (rc != hipErrorCooperativeLaunchTooLarge && rc != hipErrorNotSupported && rc != hipErrorInvalidConfiguration) return rc;
+    }
+    hipLaunchKernelGGL(kern, grid, block, sb, st, k);
+    return hipGetLastError();
+}
 template <int M>
 static hipError_t launch_spec_m(const KArgs& k, hipStream_t st) {
     auto kern = sdempc_solve_spec_kernel<M>;
     const size_t sb = smem_bytes(k.H, k.m, 1, true) + (4 * (size_t)((k.H * k.m + 3) & ~3) + SPEC_MRED) * sizeof(float);
     hipError_t e = set_smem_attr((const void*)kern, sb);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(k.B * k.coop_ngrp * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);
-    return hipGetLastError();
+    return launch_resident(kern, dim3(k.B * k.coop_ngrp * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);
 }
 hipError_t launch_solve_spec(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B; k.coop_nwg = coop_nwg(k.P);
@@ -933,14 +951,12 @@ static hipError_t launch_coop_m(const KArgs& k, hipStream_t st) {
         auto kern = sdempc_solve_kernel<TeamBlock, M, false, true, 2>;
         hipError_t e = set_smem_attr((const void*)kern, sb);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(k.B * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);
-        return hipGetLastError();
+        return launch_resident(kern, dim3(k.B * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);
     }
     auto kern = sdempc_solve_kernel<TeamBlock, M, false, false, 2>;
     hipError_t e = set_smem_attr((const void*)kern, sb);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(k.B * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);
-    return hipGetLastError();
+    return launch_resident(kern, dim3(k.B * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);
 }
 hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B; k.coop_nwg = coop_nwg(k.P);

@@ -545,3 +545,21 @@ def test_barrier_timeout_falls_back_to_tile_layout(spec, monkeypatch):
     S.solve_status()
     assert bits_differ(uopt.cpu().numpy(), uo) == 0 and bits_differ(info.cpu().numpy(), io) == 0
     S.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", ["1", "0"])
+def test_runtime_cooperative_launch_bit_exact(spec, monkeypatch):
+    """SDEMPC_COOP_LAUNCH=1: the cooperative layouts launched through hipLaunchCooperativeKernel give the oracle's bits too."""
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(horizon=12, num_short_dt=12, num_particles=72, max_iter=6, max_no_improvement_iter=6)
+    B = 2
+    x0, xref, noise, u = _problem(cfg, B, 6)
+    s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
+    uo, xo, io = orc.Oracle(cfg, synthetic_iris()).solve_batch(x0, xref, noise, u, s0)
+    monkeypatch.setenv("SDEMPC_SPEC", spec)
+    monkeypatch.setenv("SDEMPC_COOP_LAUNCH", "1")
+    S = _solver(cfg, synthetic_iris(), B)
+    ug, xg, ig = S.solve(x0, xref, noise, u, s0)
+    assert S.layout_fallbacks() == 0
+    assert bits_differ(ug, uo) == 0 and bits_differ(xg, xo) == 0 and bits_differ(ig, io) == 0
+    S.close()

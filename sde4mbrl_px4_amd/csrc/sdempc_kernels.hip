@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : MODE ? 2 : s
         Team::sync();
         if (c_n < c_x) {
             for (int e = tid; e < N; e += Team::NT) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
-            float rs = block_dot<Team>(sm, d1, d2, N, tid);
+            float rs = uni_f(block_dot<Team>(sm, d1, d2, N, tid));
             if (rs > 0.0f) {
                 kr = 0; plain = 1;
                 for (int e = tid; e < N; e += Team::NT) { yk[e] = xn[e]; xk[e] = xn[e]; }

@@ -137,7 +137,8 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             else { iact = spec; iu = y1; igrad = true; islot = 2; }
             if (grp == 2 && spec && !two) { iact = true; iu = y1; igrad = true; islot = 2; }
         }
-        // The optimiser's scalars are identical in every lane; pinning them to SGPRs across the particle work keeps them out of the
+        // The optimiser's scalars are identical in every lane (and made provably so where they are produced, so that every branch of
+        // the state machine is uniform for the compiler); pinning them to SGPRs across the particle work keeps them out of the
         // VGPR allocator's way (with 343 registers in use LLVM saved two of them to AGPRs under the partial EXEC mask of a preceding
         // divergent block and restored them under the full mask: wrong telemetry in lane 0; SGPR spills are whole-wave and safe)
         c_init = uni_f(c_init); c_x = uni_f(c_x); s = uni_f(s); gsq = uni_f(gsq); sum_ls = uni_f(sum_ls); sum_s = uni_f(sum_s);
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         // ---- the optimiser (SPEC.md §8), advanced as far as the data of this phase allows ----
         bool head = false, tail = false;
         if (phase == PH_INIT) {
-            c_init = spec_cost(a, sm, C, tid, par, xk, SLOT_SEQ);
+            c_init = uni_f(spec_cost(a, sm, C, tid, par, xk, SLOT_SEQ));
             c_x = c_init;
             phase = a.A.max_iter > 0 ? PH_GRAD : PH_FINAL;
         } else if (phase == PH_GRAD) {
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             if (tid == 0) sm.red[12] = coop_load(gt + PS - 1);
             const float cu = block_ucost<Team>(a, sm, yk, tid);        // (contains the barriers that publish sm.tot / sm.red)
             __syncthreads();
-            c_y = FMA(sm.red[12], a.invP, cu);
+            c_y = uni_f(FMA(sm.red[12], a.invP, cu));
             assemble_gradient<Team, M>(a, sm, yk, g, tid, [&](int q) { return sm.tot[q]; });
             __syncthreads();
             head = true;
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 if (lane == 0) sm.red[12 + wave] = t0;
             }
             __syncthreads();
-            c_n = FMA(sm.red[12], a.invP, cu_1);
+            c_n = uni_f(FMA(sm.red[12], a.invP, cu_1));
             nls = 1; jsel = 1;
             bool done = !has_ls;
             if (has_ls) {
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 else if (0 < a.A.maxls - 1) s = s * a.A.dec;
             }
             if (!done && two) {
-                c_n = FMA(sm.red[13], a.invP, cu_2);
+                c_n = uni_f(FMA(sm.red[13], a.invP, cu_2));
                 nls = 2; jsel = 2;
                 if (c_n <= FMA(a.A.coef, gd_2, c_y)) done = true;
                 else if (1 < a.A.maxls - 1) s = s * a.A.dec;
@@ -215,8 +216,8 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 phase = PH_SEQ;
             } else tail = true;
         } else if (phase == PH_SEQ) {
-            c_n = spec_cost(a, sm, C, tid, par, xn, SLOT_SEQ);
-            const float gd = block_dot<Team>(sm, g, d1, N, tid);
+            c_n = uni_f(spec_cost(a, sm, C, tid, par, xn, SLOT_SEQ));
+            const float gd = uni_f(block_dot<Team>(sm, g, d1, N, tid));
             nls = jl + 1; jsel = 0;
             bool done = c_n <= FMA(a.A.coef, gd, c_y);
             if (!done && jl < a.A.maxls - 1) s = s * a.A.dec;
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 float rs = jsel == 1 ? rs_1 : rs_2;          // restart test of a parallel trial: known since the head
                 if (jsel == 0) {
                     for (int e = tid; e < N; e += Team::NT) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
-                    rs = block_dot<Team>(sm, d1, d2, N, tid);
+                    rs = uni_f(block_dot<Team>(sm, d1, d2, N, tid));
                 }
                 if (rs > 0.0f) {
                     kr = 0; plain = 1;
@@ -315,10 +316,10 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 acc[5] = FMA(ucost_elem(a, sm, xn1, e, m), 1.0f, acc[5]);
                 acc[6] = FMA(ucost_elem(a, sm, xn2, e, m), 1.0f, acc[6]);
             });
-            gsq = r7[0];
+            gsq = uni_f(r7[0]);
             if (!(gsq < __builtin_inff())) { phase = PH_FINAL; continue; }      // (s keeps the value of the last completed iteration)
             s = sn;
-            gd_1 = r7[1]; gd_2 = r7[2]; rs_1 = r7[3]; rs_2 = r7[4]; cu_1 = r7[5]; cu_2 = r7[6];
+            gd_1 = uni_f(r7[1]); gd_2 = uni_f(r7[2]); rs_1 = uni_f(r7[3]); rs_2 = uni_f(r7[4]); cu_1 = uni_f(r7[5]); cu_2 = uni_f(r7[6]);
             two = (has_ls ? a.A.maxls : 1) > 1;
             spec = (k + 1 < a.A.max_iter);
             // where the optimiser moves if it ends on trial j with an improvement (the expressions of the tail above)

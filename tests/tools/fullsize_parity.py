@@ -1,0 +1,38 @@
+"""Full-size, full-length solves of the BASELINE configurations against the oracle, bit for bit, in every execution layout.
+usage: python tests/tools/fullsize_parity.py c3_hexa_traj_h50_p256 c5_iris_traj_h200_p1024   (C5: the oracle needs a few minutes)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from sde4mbrl_px4_amd import load_mpc_config, synthetic_iris, synthetic_hexa, prng
+from sde4mbrl_px4_amd import workload as W
+from sde4mbrl_px4_amd.solver import SdeMpcSolver
+import orc
+
+def bits(a, b):
+    a = np.ascontiguousarray(a, np.float32).view(np.uint32); b = np.ascontiguousarray(b, np.float32).view(np.uint32)
+    return int((a != b).sum())
+
+for name in sys.argv[1:]:
+    cfg = load_mpc_config(os.path.join(ROOT, "configs", name + ".yaml"))
+    H, P, m = cfg.horizon, cfg.num_particles, cfg.num_motors
+    model = synthetic_iris() if m == 4 else synthetic_hexa()
+    x0 = W.random_initial_states(1, 3)
+    xref = np.stack([W.reference_window(0.35, cfg.time_steps)])
+    key = prng.split(prng.PRNGKey(10), 4)[3:4]
+    got = {}
+    for layout, env in (("auto", {}), ("coop", {"SDEMPC_SPEC": "0"}), ("tile", {"SDEMPC_COOP": "0", "SDEMPC_SPEC": "0"})):
+        for k in ("SDEMPC_SPEC", "SDEMPC_COOP"): os.environ.pop(k, None)
+        os.environ.update(env)
+        S = SdeMpcSolver(cfg, model, max_batch=1)
+        yk, i0 = S.reset()
+        s0 = np.array([i0["stepsize"]], np.float32)
+        t = time.time(); got[layout] = S.solve_keys(x0, xref, key, yk[None], s0); dt = time.time() - t
+        print(f"{name} [{layout}]: {dt * 1e3:.1f} ms (first call), N_it {got[layout][2][0, 2]:.0f} N_ls {got[layout][2][0, 7]:.0f}", flush=True)
+        noise = S.noise_from_keys(key)
+        S.close()
+    t = time.time()
+    uo, xe, io, _ = orc.Oracle(cfg, model).solve(x0[0], xref[0], noise[0], yk, float(s0[0]))
+    print(f"{name}: oracle {time.time() - t:.1f} s on one core", flush=True)
+    for layout, (u, x, i) in got.items():
+        print(f"{name} [{layout}]: mismatched words uopt {bits(u[0], uo)}/{uo.size}, xevol {bits(x[0], xe)}/{xe.size}, info {bits(i[0], io)}/8", flush=True)

@@ -928,7 +928,7 @@ static hipError_t launch_resident(K kern, dim3 grid, dim3 block, size_t sb, hipS
 }
 template <int M>
 static hipError_t launch_spec_m(const KArgs& k, hipStream_t st) {
-    auto kern = sdempc_solve_spec_kernel<M>;
+    auto kern = k.P == 1 ? sdempc_solve_spec_kernel<M, true> : sdempc_solve_spec_kernel<M, false>;
     const size_t sb = smem_bytes(k.H, k.m, 1, true) + (4 * (size_t)((k.H * k.m + 3) & ~3) + SPEC_MRED) * sizeof(float);
     hipError_t e = set_smem_attr((const void*)kern, sb);
     if (e != hipSuccess) return e;

@@ -58,7 +58,8 @@ DI void spec_reduce_n(float* mred, int N, int tid, float (&out)[K], F&& elem) {
 constexpr int SPEC_MRED = 32;      // floats of reduction scratch behind the four extra control vectors
 // one workgroup per CU (512 registers per lane: what does not fit the 256 VGPRs spills to AGPRs, not to scratch memory — with two
 // workgroups per CU the adjoint loop carried 43 scratch accesses per step and ran 3x slower)
-template <int M>
+// DIRECT: single-particle instances (P == 1, every MPC YAML the reference ships): a particle is its own total, no reduction phase
+template <int M, bool DIRECT>
 __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     using Team = TeamBlock;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -157,13 +158,15 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         }
         coop_barrier(C, tid);
         // ---- the optimiser (SPEC.md §8), advanced as far as the data of this phase allows ----
-        bool head = false, tail = false;
+        bool head = false, tail = false, fin = false;
         if (phase == PH_INIT) {
             c_init = uni_f(spec_cost(a, sm, C, tid, par, xk, SLOT_SEQ));
             c_x = c_init;
             phase = a.A.max_iter > 0 ? PH_GRAD : PH_FINAL;
         } else if (phase == PH_GRAD) {
-            red_slot = SLOT_GRAD; red_par = par; phase = PH_RED;
+            red_slot = SLOT_GRAD; red_par = par;
+            if constexpr (DIRECT) fin = true;
+            else phase = PH_RED;
         } else if (phase == PH_RED) {
             constexpr int nq = M + 4;
             const float* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
@@ -284,8 +287,28 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             if (noimp >= a.A.max_noimp) stop = 1;
             k += 1;
             if (stop || k >= a.A.max_iter) phase = PH_FINAL;
-            else if (hit_slot >= 0) { red_slot = hit_slot; red_par = par_spec; phase = PH_RED; }
+            else if (hit_slot >= 0) {
+                red_slot = hit_slot; red_par = par_spec;
+                if constexpr (DIRECT) fin = true;
+                else phase = PH_RED;
+            }
             else phase = PH_GRAD;
+        }
+        if constexpr (DIRECT) {
+            if (fin) {   // (c_y, g) straight from the particle's outputs in (red_par, red_slot): v + 0 is what the butterflies and the slot
+                         // order of SPEC.md §6.1 make of one value and zeros, so no reduction phase and no barrier for it
+                constexpr int nq = M + 4;
+                const float* pbuf = C.pp + (size_t)(red_par * SPEC_SLOTS + red_slot) * PS * C.Ppad;
+                for (int q = tid; q < H * 12; q += Team::NT)
+                    if ((q % 12) < nq) sm.tot[q] = coop_load(pbuf + (size_t)q * C.Ppad) + 0.0f;
+                if (tid == 0) sm.red[12] = coop_load(pbuf + (size_t)(PS - 1) * C.Ppad) + 0.0f;
+                const float cu = block_ucost<Team>(a, sm, yk, tid);
+                __syncthreads();
+                c_y = uni_f(FMA(sm.red[12], a.invP, cu));
+                assemble_gradient<Team, M>(a, sm, yk, g, tid, [&](int q) { return sm.tot[q]; });
+                __syncthreads();
+                head = true;
+            }
         }
         if (head) {      // start of iteration k with (c_y, g) in hand
             float sn = s;

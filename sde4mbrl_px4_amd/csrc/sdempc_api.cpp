@@ -59,6 +59,7 @@ struct sdempc_handle {
     // device tables
     DevBuf d_dt, d_sdt, d_disc, d_beta, d_wts;
     // workspace + staging (sized for max_batch)
+    DevBuf d_ustg;            // per-step control table [B][H][36] of the solve kernel's long-horizon instantiation (KArgs::ustg)
     DevBuf d_part, d_act, d_traj, d_x0, d_u, d_xref, d_noise, d_step, d_cost, d_grad, d_xmean, d_uopt, d_info;
     // canonical-layout staging of the host-pointer entry points (allocated on their first use)
     DevBuf d_noise_canon, d_traj_canon, d_keys;
@@ -137,6 +138,7 @@ int ensure_device_impl(sdempc_handle* h) {
     HIPCHK(h, hipMemset(h->d_traj.p, 0, h->d_traj.bytes));
     if ((rc = dev_alloc(h, h->d_act, sizeof(float) * (size_t)B * h->G * H * ACT_STRIDE))) return rc;
     if ((rc = dev_alloc(h, h->d_part, sizeof(float) * (size_t)B * h->G * part_stride(H)))) return rc;
+    if ((rc = dev_alloc(h, h->d_ustg, sizeof(float) * (size_t)B * H * 36))) return rc;
     if ((rc = dev_alloc(h, h->d_x0, sizeof(float) * B * SDEMPC_NX))) return rc;
     if ((rc = dev_alloc(h, h->d_u, sizeof(float) * B * H * m))) return rc;
     if ((rc = dev_alloc(h, h->d_xref, sizeof(float) * B * (H + 1) * SDEMPC_NX))) return rc;
@@ -155,6 +157,7 @@ int ensure_device_impl(sdempc_handle* h) {
     h->base.traj = (float*)h->d_traj.p;
     h->base.act = (float*)h->d_act.p;
     h->base.part = (float*)h->d_part.p;
+    h->base.ustg = (float*)h->d_ustg.p;
     h->dev_ready = true;
     return 0;
 }
@@ -336,7 +339,7 @@ namespace {
 void release_device(sdempc_handle* h) {
     if (h->dev_ready || h->stream || h->d_dt.p) {
         (void)hipSetDevice(h->device);
-        for (DevBuf* b : {&h->d_part, &h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys, &h->d_coop_bar, &h->d_coop_pp, &h->d_coop_ck,
+        for (DevBuf* b : {&h->d_ustg, &h->d_part, &h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys, &h->d_coop_bar, &h->d_coop_pp, &h->d_coop_ck,
                           &h->d_step, &h->d_cost, &h->d_grad, &h->d_xmean, &h->d_uopt, &h->d_info})
             dev_free(*b);
         if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -55,6 +55,7 @@ struct KArgs {
     int coop_nwg;
     int coop_ngrp;             // speculative variant: groups of coop_nwg workgroups per instance (2..5)
     unsigned* coop_bar;        // [B][2]: arrival counter, error flag (zeroed before every launch)
+    float* ustg;               // [B][H][36] per-step control table in global memory (long horizons: keeps it out of LDS), or NULL
     unsigned coop_spin;        // polls of one grid barrier before it gives up (COOP_SPIN_DEFAULT; test hook SDEMPC_COOP_SPIN)
     float* coop_pp;            // [B][2][part_stride(H)][G*32]
     float* coop_ck;            // [B][P][H+1][160]

@@ -109,7 +109,7 @@ struct Smem {
 };
 constexpr int UST = 36;
 
-DI Smem carve(float* base, int H, int m, int team, bool coop = false) {
+DI Smem carve(float* base, int H, int m, int team, bool coop = false, bool ust_lds = true) {
     Smem s;
     float* p = base;
     // ---- shared by every team of the workgroup ----
@@ -128,9 +128,9 @@ DI Smem carve(float* base, int H, int m, int team, bool coop = false) {
     s.disc = p; p += (H + 1 + 3) & ~3;
     // ---- per team ----
     const int nv = (H * m + 3) & ~3;
-    const int per_team = H * UST + (((H + 1) * NX + 3) & ~3) + 16 + 6 * nv;
+    const int per_team = (ust_lds ? H * UST : 0) + (((H + 1) * NX + 3) & ~3) + 16 + 6 * nv;
     p += team * per_team;
-    s.ust = p; p += H * UST;
+    s.ust = p; if (ust_lds) p += H * UST;      // !ust_lds: the kernel points s.ust at its row of KArgs::ustg instead
     s.xref = p; p += ((H + 1) * NX + 3) & ~3;
     s.red = p; p += 16;
     for (int i = 0; i < 6; ++i) { s.v[i] = p; p += nv; }
@@ -138,9 +138,9 @@ DI Smem carve(float* base, int H, int m, int team, bool coop = false) {
     (void)coop;
     return s;
 }
-size_t smem_bytes(int H, int m, int ipb, bool coop = false) {
+size_t smem_bytes(int H, int m, int ipb, bool coop = false, bool ust_lds = true) {
     size_t shared = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + 2 * HID * HID + 512 + ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3);
-    size_t per_team = (size_t)H * UST + (((H + 1) * NX + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
+    size_t per_team = (ust_lds ? (size_t)H * UST : 0) + (((H + 1) * NX + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
     return (shared + ipb * per_team + (coop ? (size_t)((H * 12 + 3) & ~3) : 0)) * sizeof(float);
 }
 
@@ -656,7 +656,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
 // kernels
 // ------------------------------------------------------------------------------------------------
 // Common kernel prologue: carve LDS, stage weights (whole workgroup), then each team takes its instance.
-#define SDEMPC_KERNEL_PROLOGUE()                                                     \
+#define SDEMPC_KERNEL_PROLOGUE(USTG_)                                                \
     extern __shared__ __attribute__((aligned(16))) float smem[];                     \
     LaneW LW;                                                                        \
     CoopCtx CC;                                                                      \
@@ -672,7 +672,8 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
         b_ = blockIdx.x * Team::IPB + Team::team();                                  \
     }                                                                                \
     const int b = __builtin_amdgcn_readfirstlane(b_);                                \
-    Smem sm = carve(smem, a.H, a.m, Team::team(), MODE == 2);                        \
+    Smem sm = carve(smem, a.H, a.m, Team::team(), MODE == 2, !(USTG_));              \
+    if constexpr (USTG_) sm.ust = a.ustg + (size_t)b * a.H * UST;                    \
     WaveW ww;                                                                        \
     load_weights(a, sm, ww, threadIdx.x, Team::BNT);                                 \
     __syncthreads();                                                                 \
@@ -682,7 +683,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
 
 template <class Team, bool F16, int MODE = 0>
 __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_rollout_kernel(KArgs a) {
-    SDEMPC_KERNEL_PROLOGUE();
+    SDEMPC_KERNEL_PROLOGUE(false);
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
     float c = team_rollout<Team, F16, false, MODE>(a, sm, ww, LW, CC, sm.v[5], b, tid, a.store_traj != 0, a.xmean ? a.xmean + (size_t)b * (a.H + 1) * NX : nullptr);
@@ -691,7 +692,7 @@ __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_rollout_kern
 
 template <class Team, int M, bool F16, int MODE = 0>
 __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_grad_kernel(KArgs a) {
-    SDEMPC_KERNEL_PROLOGUE();
+    SDEMPC_KERNEL_PROLOGUE(false);
     const int N = a.H * a.m;
     for (int e = tid; e < N; e += Team::NT) sm.v[5][e] = a.u[(size_t)b * N + e];
     float c = team_cost_grad<Team, M, F16, false, false, MODE>(a, sm, ww, LW, CC, sm.v[5], sm.v[3], b, tid);   // tiles: three waves per SIMD, no prefetch buffer
@@ -706,9 +707,11 @@ __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_grad_kernel(
 // latency instantiation (PK) and the one-wave teams (LDS allows two workgroups per CU anyway) keep two.
 template <class Team, bool PK> constexpr int solve_waves_per_simd() { return PK ? 2 : 3; }
 // MODE 1 / 2: lane layouts (weights in VGPRs, two waves per SIMD; MODE 2 with PK: one workgroup per CU, spills go to AGPRs)
-template <class Team, int M, bool F16, bool PK = false, int MODE = 0>
+// USTG: the per-step control table [H][36] lives in global memory (KArgs::ustg, L1/L2-resident) instead of LDS: long horizons keep three
+// workgroups per CU (C5: 79 KB -> 50 KB per instance)
+template <class Team, int M, bool F16, bool PK = false, int MODE = 0, bool USTG = false>
 __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : MODE ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
-    SDEMPC_KERNEL_PROLOGUE();
+    SDEMPC_KERNEL_PROLOGUE(USTG);
     const int m = a.m, N = a.H * m;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
     for (int e = tid; e < N; e += Team::NT) {
@@ -806,8 +809,8 @@ static bool use_wave_team(int G, int H, int m) { return G == 1 && smem_bytes(H, 
 int team_ipb(int G, int H, int m) { return use_wave_team(G, H, m) ? TeamWave::IPB : TeamBlock::IPB; }
 
 template <class Kern>
-static hipError_t launch_k(Kern k, const KArgs& a, hipStream_t st, int ipb, int bnt = 256) {
-    const size_t sb = smem_bytes(a.H, a.m, ipb);
+static hipError_t launch_k(Kern k, const KArgs& a, hipStream_t st, int ipb, int bnt = 256, bool ust_lds = true) {
+    const size_t sb = smem_bytes(a.H, a.m, ipb, false, ust_lds);
     hipError_t e = set_smem_attr((const void*)k, sb);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((a.B + ipb - 1) / ipb), dim3(bnt), sb, st, a);
@@ -833,6 +836,13 @@ static int device_cus() {
     }
     return cus;
 }
+// Throughput launches of the workgroup-wide team: is the per-step control table better kept in global memory? (SDEMPC_USTG=0/1 forces)
+bool use_global_ust(int H, int m) {
+    const char* force = getenv("SDEMPC_USTG");
+    if (force) return force[0] == '1';
+    const size_t cap = 160 * 1024;
+    return 3 * smem_bytes(H, m, 1) > cap && 3 * smem_bytes(H, m, 1, false, false) <= cap;
+}
 template <class Team, bool F16>
 static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
     if constexpr (!F16 && !FAST) {
@@ -851,6 +861,14 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
             if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, false, true>, a, st, Team::IPB);
             if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, false, true>, a, st, Team::IPB);
             return launch_k(sdempc_solve_kernel<Team, 8, false, true>, a, st, Team::IPB);
+        }
+    }
+    if constexpr (Team::IPB == 1 && !FAST) {
+        // long horizons: with the control table in LDS only two workgroups fit a CU; without it three do (the kernel is built for three)
+        if (use_global_ust(a.H, a.m) && a.ustg) {
+            if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16, false, 0, true>, a, st, 1, Team::BNT, false);
+            if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, F16, false, 0, true>, a, st, 1, Team::BNT, false);
+            return launch_k(sdempc_solve_kernel<Team, 8, F16, false, 0, true>, a, st, 1, Team::BNT, false);
         }
     }
     if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16>, a, st, Team::IPB);

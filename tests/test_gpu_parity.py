@@ -563,3 +563,33 @@ def test_runtime_cooperative_launch_bit_exact(spec, monkeypatch):
     assert S.layout_fallbacks() == 0
     assert bits_differ(ug, uo) == 0 and bits_differ(xg, xo) == 0 and bits_differ(ig, io) == 0
     S.close()
+
+
+# ---- long horizons: the per-step control table of the throughput solve kernel moves from LDS to global memory -------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,P,m", [(200, 40, 4), (50, 70, 4), (64, 33, 6)])
+def test_global_control_table_instantiation_bit_exact(H, P, m, monkeypatch):
+    """SDEMPC_USTG=1 + SDEMPC_PK=0 force the instantiation that long-horizon throughput launches pick by themselves (three workgroups per
+    CU instead of two at C5): same bits as the oracle, and as the LDS-table instantiation."""
+    kw = dict(horizon=H, num_short_dt=H, num_particles=P, u_slew_coeff=1.0, max_iter=4, max_no_improvement_iter=4)
+    if m == 6:
+        kw.update(input_id=list(range(6)), input_bound=[[1e-4, 1.0]] * 6, uref=[0.42] * 6)
+    cfg = MPCConfig(**kw)
+    model = synthetic_iris() if m == 4 else synthetic_hexa()
+    B = 3
+    x0, xref, noise, u = _problem(cfg, B, 9)
+    s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
+    O = orc.Oracle(cfg, model)
+    monkeypatch.setenv("SDEMPC_COOP", "0")
+    monkeypatch.setenv("SDEMPC_PK", "0")
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SDEMPC_USTG", flag)
+        S = _solver(cfg, model, B)
+        res[flag] = S.solve(x0, xref, noise, u, s0)
+        S.close()
+    for b in range(B):
+        uo, xe, io, _ = O.solve(x0[b], xref[b], noise[b], u[b], float(s0[b]))
+        for flag in ("1", "0"):
+            ug, xg, ig = res[flag]
+            assert bits_differ(ug[b], uo) == 0 and bits_differ(xg[b], xe) == 0 and bits_differ(ig[b], io) == 0, (flag, b)

@@ -840,8 +840,10 @@ static int device_cus() {
 bool use_global_ust(int H, int m) {
     const char* force = getenv("SDEMPC_USTG");
     if (force) return force[0] == '1';
+    // workgroups per CU: at most three by registers (launch bounds), otherwise what the 160 KB of LDS hold
     const size_t cap = 160 * 1024;
-    return 3 * smem_bytes(H, m, 1) > cap && 3 * smem_bytes(H, m, 1, false, false) <= cap;
+    auto per_cu = [&](size_t bytes) { const size_t n = bytes ? cap / bytes : 3; return n > 3 ? (size_t)3 : n; };
+    return per_cu(smem_bytes(H, m, 1, false, false)) > per_cu(smem_bytes(H, m, 1));
 }
 template <class Team, bool F16>
 static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {

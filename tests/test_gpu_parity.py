@@ -567,7 +567,7 @@ def test_runtime_cooperative_launch_bit_exact(spec, monkeypatch):
 
 # ---- long horizons: the per-step control table of the throughput solve kernel moves from LDS to global memory -------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("H,P,m", [(200, 40, 4), (50, 70, 4), (64, 33, 6)])
+@pytest.mark.parametrize("H,P,m", [(200, 40, 4), (50, 70, 4), (64, 33, 6), (300, 8, 4)])
 def test_global_control_table_instantiation_bit_exact(H, P, m, monkeypatch):
     """SDEMPC_USTG=1 + SDEMPC_PK=0 force the instantiation that long-horizon throughput launches pick by themselves (three workgroups per
     CU instead of two at C5): same bits as the oracle, and as the LDS-table instantiation."""
@@ -583,13 +583,16 @@ def test_global_control_table_instantiation_bit_exact(H, P, m, monkeypatch):
     monkeypatch.setenv("SDEMPC_COOP", "0")
     monkeypatch.setenv("SDEMPC_PK", "0")
     res = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("SDEMPC_USTG", flag)
+    for flag in ("1", "0", "auto"):          # auto: H = 200 / 300 choose the global table by themselves (3 instead of 2 / 2 instead of 1 per CU)
+        if flag == "auto":
+            monkeypatch.delenv("SDEMPC_USTG", raising=False)
+        else:
+            monkeypatch.setenv("SDEMPC_USTG", flag)
         S = _solver(cfg, model, B)
         res[flag] = S.solve(x0, xref, noise, u, s0)
         S.close()
     for b in range(B):
         uo, xe, io, _ = O.solve(x0[b], xref[b], noise[b], u[b], float(s0[b]))
-        for flag in ("1", "0"):
+        for flag in ("1", "0", "auto"):
             ug, xg, ig = res[flag]
             assert bits_differ(ug[b], uo) == 0 and bits_differ(xg[b], xe) == 0 and bits_differ(ig[b], io) == 0, (flag, b)

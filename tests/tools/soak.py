@@ -1,4 +1,5 @@
-"""Randomised soak: GPU (C ABI) vs CPU oracle, bit for bit, over many random configurations."""
+"""Randomised soak: GPU (C ABI) vs CPU oracle, bit for bit, over many random configurations. Every configuration also draws one of the
+execution layouts / kernel instantiations (environment switches of INTEGRATION.md, read per launch): all must give the same bits."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +11,10 @@ from cases import bits_differ
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0; nonfinite = 0; t0 = time.time()
+LAYOUTS = [("auto", {}), ("coop", {"SDEMPC_SPEC": "0"}), ("coop-rt", {"SDEMPC_COOP_LAUNCH": "1"}), ("tile-pk", {"SDEMPC_COOP": "0", "SDEMPC_PK": "1"}),
+           ("tile", {"SDEMPC_COOP": "0", "SDEMPC_PK": "0"}), ("tile-gtab", {"SDEMPC_COOP": "0", "SDEMPC_PK": "0", "SDEMPC_USTG": "1"}),
+           ("tile-nolane", {"SDEMPC_COOP": "0", "SDEMPC_LANE": "0", "SDEMPC_PK": "0"})]
+used = {}
 for it in range(n):
     rng = np.random.default_rng(seed0 + it)
     m = int(rng.integers(1, 9)); H = int(rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 55, 70])); P = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 65, 100, 128, 130, 257]))
@@ -24,6 +29,9 @@ for it in range(n):
     if rng.random() < 0.4: kw.update(u_slew_constr=[[-float(rng.uniform(0.01, 0.1)), float(rng.uniform(0.01, 0.1))]] * m, u_slew_constr_coeff=float(rng.uniform(1, 20)))
     if rng.random() < 0.3: kw.update(moment_scale=float(rng.uniform(0.1, 1.0)))
     cfg = MPCConfig(**kw); model = synthetic_multirotor(m, seed=it)
+    lname, lenv = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
+    for k in ("SDEMPC_SPEC", "SDEMPC_COOP", "SDEMPC_COOP_LAUNCH", "SDEMPC_PK", "SDEMPC_USTG", "SDEMPC_LANE"): os.environ.pop(k, None)
+    os.environ.update(lenv); used[lname] = used.get(lname, 0) + 1
     B = int(rng.integers(1, 6))
     x0 = W.random_initial_states(B, 1000 + it); xref = np.stack([W.reference_window(0.2 * b, cfg.time_steps) for b in range(B)]); noise = W.make_noise(B, P, H, it)
     u = np.clip(np.asarray(cfg.uref, np.float32) + 0.15 * rng.standard_normal((B, H, m)), 1e-4, 1).astype(np.float32)
@@ -42,7 +50,7 @@ for it in range(n):
         nzo = orc.noise_from_key(keys[b], P, H)
         uo2, xo2, io2, _ = O.solve(x0[b], xref[b], nzo, u[b], float(cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize))
         nb += bits_differ(nk[b], nzo) + bits_differ(uk[b], uo2) + bits_differ(xk[b], xo2) + bits_differ(ik[b], io2)
-    if nb: print(f"MISMATCH case {seed0+it}: m={m} H={H} P={P} B={B} words={nb} cfg={kw}"); bad += 1
+    if nb: print(f"MISMATCH case {seed0+it} [{lname}]: m={m} H={H} P={P} B={B} words={nb} cfg={kw}"); bad += 1
     S.close()
-print(f"soak: {n} configurations ({nonfinite} with non-finite trajectories), {bad} with mismatches, {time.time()-t0:.1f} s")
+print(f"soak: {n} configurations ({nonfinite} with non-finite trajectories), {bad} with mismatches, {time.time()-t0:.1f} s; layouts {used}")
 sys.exit(1 if bad else 0)

@@ -224,8 +224,8 @@ def main():
             "p50_solve_latency_ms": float(np.median(lat)),
             "p95_solve_latency_ms": float(np.percentile(lat, 95)),
             "latency_reps": len(lat),
-            "p50_solve_latency_note": "one instance alone on the GPU (B = 1 launch of the same C-ABI entry point): the library spreads it over ceil(P/4) x 5 workgroups "
-                                      "(one particle per wave; two line-search trials and the candidate gradients of the next iteration evaluated at once); bit-identical results",
+            "p50_solve_latency_note": "one instance alone on the GPU (B = 1 launch of the same C-ABI entry point): the library spreads it over ceil(P/4) x 7 workgroups "
+                                      "(one particle per wave; three line-search trials and the candidate gradients of the next iteration evaluated at once); bit-identical results",
             "p50_batch_latency_ms": float(np.median(ev_ms)),
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
                          "traffic": traffic, "kernel": "sdempc::exact::sdempc_solve_kernel<sdempc::exact::%s, %d, %s, false, 0>" % ("TeamBlock" if P > 32 else "TeamWave", m if m in (4, 6) else 8, "true" if args.mlp_dtype == "f16" else "false"), "kernel_ms": k_ms,

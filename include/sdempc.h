@@ -138,8 +138,8 @@ int sdempc_grad_batch(sdempc_handle* h, int32_t B, const float* x0, const float*
 /* A3: the solve. u_init = warm start (opt_state.yk), stepsize_in = opt_state.stepsize.
  * Execution layout is chosen per call and never changes a bit of the result: P = 1 instances (all YAMLs the reference ships) run in a
  * single-particle layout; batches small enough that all workgroups are resident at once (C2: up to 15 instances) are spread over many
- * workgroups, one particle per wave, with one bounded grid barrier per rollout, and for the smallest batches additionally evaluate two
- * line-search trials and the candidate gradients of the next iteration at once (C2 single solve: 32 ms instead of 158 ms); larger
+ * workgroups, one particle per wave, with one bounded grid barrier per rollout, and for the smallest batches additionally evaluate up to three
+ * line-search trials and the candidate gradients of the next iteration at once (C2 single solve: 31 ms instead of 158 ms); larger
  * batches run one workgroup per instance in the 32-particle MFMA tile layout (throughput). The cooperative layouts assume that no other
  * kernel occupies the GPU while they run; if their workgroups cannot all become resident the barrier gives up after a bounded number of
  * polls and the telemetry of the launch is NaN. The host-pointer entry points then run the same batch once more in the

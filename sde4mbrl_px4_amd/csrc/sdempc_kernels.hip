@@ -912,13 +912,13 @@ int coop_max_instances(int P, int H, int m) {
 // per-instance workspace, sized for the speculative variant (7 output slots, 3 checkpoint regions); the plain cooperative kernel
 // uses a prefix of it
 size_t coop_pp_floats(int H, int G) { return (size_t)2 * SPEC_SLOTS * part_stride(H) * G * 32 + 2 * (size_t)part_stride(H); }
-size_t coop_ck_floats(int H, int P) { return (size_t)3 * P * (H + 1) * COOP_ROW; }
+size_t coop_ck_floats(int H, int P) { return (size_t)SPEC_CKS * P * (H + 1) * COOP_ROW; }
 int spec_max_instances(int P, int H, int m) {
     const char* force = getenv("SDEMPC_SPEC");                  // "0" disables the speculative variant (A/B, tests; read per launch)
     const char* fc = getenv("SDEMPC_COOP");
     if ((force && force[0] == '0') || (fc && fc[0] == '0')) return 0;      // P == 1 is welcome here (one wave per workgroup is active)
     const size_t nv = (size_t)((H * m + 3) & ~3);
-    if (smem_bytes(H, m, 1, true) + (4 * nv + SPEC_MRED) * sizeof(float) > 160 * 1024) return 0;
+    if (smem_bytes(H, m, 1, true) + (SPEC_XV * nv + SPEC_MRED) * sizeof(float) > 160 * 1024) return 0;
     return device_cus() / (2 * coop_nwg(P));                    // built for one workgroup per CU; at least two groups per instance
 }
 // polls of one grid barrier before it gives up and raises the instance's error flag: several seconds by default; SDEMPC_COOP_SPIN
@@ -949,7 +949,7 @@ static hipError_t launch_resident(K kern, dim3 grid, dim3 block, size_t sb, hipS
 template <int M>
 static hipError_t launch_spec_m(const KArgs& k, hipStream_t st) {
     auto kern = k.P == 1 ? sdempc_solve_spec_kernel<M, true> : sdempc_solve_spec_kernel<M, false>;
-    const size_t sb = smem_bytes(k.H, k.m, 1, true) + (4 * (size_t)((k.H * k.m + 3) & ~3) + SPEC_MRED) * sizeof(float);
+    const size_t sb = smem_bytes(k.H, k.m, 1, true) + (SPEC_XV * (size_t)((k.H * k.m + 3) & ~3) + SPEC_MRED) * sizeof(float);
     hipError_t e = set_smem_attr((const void*)kern, sb);
     if (e != hipSuccess) return e;
     return launch_resident(kern, dim3(k.B * k.coop_ngrp * k.coop_nwg), dim3(TeamBlock::BNT), sb, st, k);

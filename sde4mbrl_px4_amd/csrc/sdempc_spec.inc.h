@@ -2,8 +2,9 @@
 // Fragment of sdempc_kernels.hip: included inside namespace sdempc::{exact|fastm} (it is compiled twice, see there); not a
 // stand-alone header.
 // ================================================================================================
-// Speculative cooperative solve (smallest batches): FIVE groups of ceil(P/4) workgroups per instance. While groups 0 and 1
-// evaluate the first two line-search trials of iteration k side by side, groups 2, 3 and 4 already evaluate the gradient of
+// Speculative cooperative solve (smallest batches): up to SEVEN groups of ceil(P/4) workgroups per instance. While groups 0 and 1
+// (and 5: the third trial, with group 6 evaluating the gradient behind it) evaluate the first line-search trials of iteration k side
+// by side, groups 2, 3 and 4 already evaluate the gradient of
 // iteration k+1 at the three points the optimiser can move to: where it goes if it ends on trial 1 resp. trial 2 with an
 // improvement, and xk (no improvement). The step sizes of the trials are known before any of them is evaluated (s, s*dec, ...),
 // so are the restart tests. One grid barrier per phase. The optimiser itself is unchanged and runs redundantly in every
@@ -12,8 +13,9 @@
 // Written as a state machine with ONE call site of the particle work, so that the rollout and the gradient sweep are each
 // instantiated once (the first version inlined them at seven sites: 140 KB of code, 2x slower sweeps).
 // ================================================================================================
-constexpr int SPEC_GROUPS = 5, SPEC_SLOTS = 7;
-constexpr int SLOT_SEQ = 6, SLOT_GRAD = 5;        // slots 0..4: the five items of a parallel phase
+constexpr int SPEC_GROUPS = 7, SPEC_SLOTS = 9, SPEC_CKS = 4;
+constexpr int SLOT_SEQ = 6, SLOT_GRAD = 5;        // slots 0..4 and 7, 8: the items of a parallel phase
+constexpr int SLOT_T3 = 7, SLOT_Y3 = 8;           // third parallel trial and the candidate gradient behind it (groups 5, 6)
 
 DI LaneIO lane_io_slot(const KArgs& a, const CoopCtx& C, int b, int p, unsigned par, int slot) {
     const int H = a.H;
@@ -55,7 +57,7 @@ DI void spec_reduce_n(float* mred, int N, int tid, float (&out)[K], F&& elem) {
 #pragma unroll
     for (int k = 0; k < K; ++k) out[k] = ((mred[4 * k] + mred[4 * k + 1]) + mred[4 * k + 2]) + mred[4 * k + 3];
 }
-constexpr int SPEC_MRED = 32;      // floats of reduction scratch behind the four extra control vectors
+constexpr int SPEC_MRED = 48, SPEC_XV = 6;       // extra control vectors xn1..3, y1..3      // floats of reduction scratch behind the four extra control vectors
 // one workgroup per CU (512 registers per lane: what does not fit the 256 VGPRs spills to AGPRs, not to scratch memory — with two
 // workgroups per CU the adjoint loop carried 43 scratch accesses per step and ran 3x slower)
 // DIRECT: single-particle instances (P == 1, every MPC YAML the reference ships): a particle is its own total, no reduction phase
@@ -64,18 +66,18 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     using Team = TeamBlock;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // a.coop_ngrp groups (2..5) per instance take the roles T1, T2, S(y2), S(xk), S(y1) in this order of usefulness
+    // a.coop_ngrp groups (2..7) per instance take the roles T1, T2, S(y2), S(xk), S(y1), T3, S(y3) in this order of usefulness
     // (measured at C2: the line search ends on trial 2 in 60 %, there is no improvement in 31 %, it ends on trial 1 in 28 % of the iterations)
     const int nwg = a.coop_nwg, ng = a.coop_ngrp, per = ng * nwg, H = a.H, m = a.m, N = H * m, PS = part_stride(H);
     const int b_ = blockIdx.x / per, r_ = blockIdx.x - b_ * per, grp = r_ / nwg;
-    const bool have_y2 = ng >= 3, have_xk = ng >= 4, have_y1 = ng >= 5;
+    const bool have_y2 = ng >= 3, have_xk = ng >= 4, have_y1 = ng >= 5, have_t3 = ng >= 6, have_y3 = ng >= 7;
     const int grad_grp = ng >= 3 ? 2 : 0;          // who evaluates a gradient outside the parallel phase
     const int b = __builtin_amdgcn_readfirstlane(b_);
     CoopCtx C;
     C.nwg = per; C.wgi = r_ - grp * nwg; C.Ppad = a.G * 32; C.epoch = 0u; C.spin_limit = a.coop_spin;
     C.bar = a.coop_bar + 2 * b;
     C.pp = a.coop_pp + (size_t)b * ((size_t)2 * SPEC_SLOTS * PS * C.Ppad + 2 * (size_t)PS);
-    C.ck = a.coop_ck + ((size_t)b * 3 + (grp >= 2 ? grp - 2 : 0)) * a.P * (H + 1) * COOP_ROW;    // gradients run on groups 2..4 (or 0 when there are only two)
+    C.ck = a.coop_ck + ((size_t)b * SPEC_CKS + (grp == 6 ? 3 : grp >= 2 && grp <= 4 ? grp - 2 : 0)) * a.P * (H + 1) * COOP_ROW;    // gradients run on groups 2..4 and 6 (or 0 when there are only two)
     Smem sm = carve(smem, H, m, 0, true);
     WaveW ww;
     LaneW LW;
@@ -86,7 +88,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     load_common<Team>(a, sm, b, tid);
     const int nv = (N + 3) & ~3;
     float* ex = sm.tot + ((H * 12 + 3) & ~3);
-    float *xn1 = ex, *xn2 = ex + nv, *y1 = ex + 2 * nv, *y2 = ex + 3 * nv, *mred = ex + 4 * nv;
+    float *xn1 = ex, *xn2 = ex + nv, *y1 = ex + 2 * nv, *y2 = ex + 3 * nv, *xn3 = ex + 4 * nv, *y3 = ex + 5 * nv, *mred = ex + SPEC_XV * nv;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
     for (int e = tid; e < N; e += Team::NT) {
         int jj = e % m;
@@ -101,10 +103,11 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     unsigned red_cnt = 0u, red_par = 0u; int red_slot = 0;
     int phase = PH_INIT;
     float c_init = 0.0f, c_x = 0.0f, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f, c_y = 0.0f, c_n = 0.0f;
-    float gd_1 = 0.0f, gd_2 = 0.0f, rs_1 = 0.0f, rs_2 = 0.0f, cu_1 = 0.0f, cu_2 = 0.0f;      // of the two parallel trials, known before they run
+    float gd_1 = 0.0f, gd_2 = 0.0f, rs_1 = 0.0f, rs_2 = 0.0f, cu_1 = 0.0f, cu_2 = 0.0f;      // of the parallel trials, known before they run
+    float gd_3 = 0.0f, rs_3 = 0.0f, cu_3 = 0.0f;
     int k = 0, kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1, nls = 0, jsel = 0, jl = 0;
     unsigned par_cnt = 0u, par_spec = 0u;
-    bool spec = false, two = false;
+    bool spec = false, two = false, three = false;
     const bool has_ls = a.A.maxls > 0;
     while (phase != PH_DONE) {
         // ---- this workgroup's work item of the phase ----
@@ -135,7 +138,9 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             else if (grp == 1) { iact = two; iu = xn2; islot = 1; }
             else if (grp == 2) { iact = spec && two; iu = y2; igrad = true; islot = 3; }     // when there is one trial only, y1 takes this group
             else if (grp == 3) { iact = spec; iu = xk; igrad = true; islot = 4; }
-            else { iact = spec; iu = y1; igrad = true; islot = 2; }
+            else if (grp == 4) { iact = spec; iu = y1; igrad = true; islot = 2; }
+            else if (grp == 5) { iact = three; iu = xn3; islot = SLOT_T3; }
+            else { iact = spec && three; iu = y3; igrad = true; islot = SLOT_Y3; }
             if (grp == 2 && spec && !two) { iact = true; iu = y1; igrad = true; islot = 2; }
         }
         // The optimiser's scalars are identical in every lane (and made provably so where they are produced, so that every branch of
@@ -145,6 +150,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         c_init = uni_f(c_init); c_x = uni_f(c_x); s = uni_f(s); gsq = uni_f(gsq); sum_ls = uni_f(sum_ls); sum_s = uni_f(sum_s);
         c_y = uni_f(c_y); c_n = uni_f(c_n);
         gd_1 = uni_f(gd_1); gd_2 = uni_f(gd_2); rs_1 = uni_f(rs_1); rs_2 = uni_f(rs_2); cu_1 = uni_f(cu_1); cu_2 = uni_f(cu_2);
+        gd_3 = uni_f(gd_3); rs_3 = uni_f(rs_3); cu_3 = uni_f(cu_3);
         if (iact) {      // the only call site of the particle work
             __syncthreads();
             block_prepass<Team>(a, sm, iu, tid);
@@ -184,8 +190,8 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             // both trial costs at once: particle totals by waves 0 / 1, control costs and g.d known since the head of the iteration
             const int PSs = part_stride(H);
             __syncthreads();
-            if (wave < (two ? 2 : 1)) {
-                const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + wave) * PSs * C.Ppad;
+            if (wave < (three ? 3 : two ? 2 : 1)) {
+                const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + (wave == 2 ? SLOT_T3 : wave)) * PSs * C.Ppad;
                 const float t0 = coop_total(pbuf + (size_t)(PSs - 1) * C.Ppad, a.P, a.G, lane);
                 if (lane == 0) sm.red[12 + wave] = t0;
             }
@@ -203,12 +209,19 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 if (c_n <= FMA(a.A.coef, gd_2, c_y)) done = true;
                 else if (1 < a.A.maxls - 1) s = s * a.A.dec;
             }
+            if (!done && three) {
+                c_n = uni_f(FMA(sm.red[14], a.invP, cu_3));
+                nls = 3; jsel = 3;
+                if (c_n <= FMA(a.A.coef, gd_3, c_y)) done = true;
+                else if (2 < a.A.maxls - 1) s = s * a.A.dec;
+            }
             {
-                const float* xj = jsel == 2 ? xn2 : xn1;
+                const float* xj = jsel == 3 ? xn3 : jsel == 2 ? xn2 : xn1;
                 for (int e = tid; e < N; e += Team::NT) xn[e] = xj[e];
             }
-            if (!done && 2 < a.A.maxls) {        // further trials one at a time
-                jl = 2;
+            const int npar = three ? 3 : 2;
+            if (!done && npar < a.A.maxls) {     // further trials one at a time
+                jl = npar;
                 __syncthreads();
                 for (int e = tid; e < N; e += Team::NT) {
                     int jj = e % m;
@@ -260,7 +273,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             int hit_slot = -1;
             __syncthreads();
             if (c_n < c_x) {
-                float rs = jsel == 1 ? rs_1 : rs_2;          // restart test of a parallel trial: known since the head
+                float rs = jsel == 1 ? rs_1 : jsel == 2 ? rs_2 : rs_3;          // restart test of a parallel trial: known since the head
                 if (jsel == 0) {
                     for (int e = tid; e < N; e += Team::NT) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
                     rs = uni_f(block_dot<Team>(sm, d1, d2, N, tid));
@@ -276,6 +289,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 c_x = c_n; noimp = 0;
                 // the new yk is exactly y_jsel: was its gradient among the speculated ones?
                 if (spec && jsel == 2 && have_y2) hit_slot = 3;
+                if (spec && jsel == 3 && have_y3) hit_slot = SLOT_Y3;
                 if (spec && jsel == 1 && (have_y1 || (have_y2 && !two))) hit_slot = 2;
             } else {
                 if (!plain) stop = 0;
@@ -318,19 +332,20 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             } else {
                 sn = a.A.stepsize;
             }
-            const float s1 = sn, s2 = sn * a.A.dec;
+            const float s1 = sn, s2 = sn * a.A.dec, s3 = s2 * a.A.dec;
             __syncthreads();
             for (int e = tid; e < N; e += Team::NT) {
                 int jj = e % m;
                 xn1[e] = clampf(FMA(-s1, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
                 xn2[e] = clampf(FMA(-s2, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                xn3[e] = clampf(FMA(-s3, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
             }
             __syncthreads();
             // everything the optimiser will ask about the two parallel trials except their particle costs, in one reduction:
             // |g|^2; g.(xn_j - yk) of the Armijo tests; the restart tests (yk - xn_j).(xn_j - xk); the control costs of xn_j
-            float r7[7];
-            spec_reduce_n<7>(mred, N, tid, r7, [&](int e, float (&acc)[7]) {
-                const float ge = g[e], ye = yk[e], xe = xk[e], x1 = xn1[e], x2 = xn2[e];
+            float r7[10];
+            spec_reduce_n<10>(mred, N, tid, r7, [&](int e, float (&acc)[10]) {
+                const float ge = g[e], ye = yk[e], xe = xk[e], x1 = xn1[e], x2 = xn2[e], x3 = xn3[e];
                 acc[0] = FMA(ge, ge, acc[0]);
                 acc[1] = FMA(ge, x1 - ye, acc[1]);
                 acc[2] = FMA(ge, x2 - ye, acc[2]);
@@ -338,20 +353,26 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 acc[4] = FMA(ye - x2, x2 - xe, acc[4]);
                 acc[5] = FMA(ucost_elem(a, sm, xn1, e, m), 1.0f, acc[5]);
                 acc[6] = FMA(ucost_elem(a, sm, xn2, e, m), 1.0f, acc[6]);
+                acc[7] = FMA(ge, x3 - ye, acc[7]);
+                acc[8] = FMA(ye - x3, x3 - xe, acc[8]);
+                acc[9] = FMA(ucost_elem(a, sm, xn3, e, m), 1.0f, acc[9]);
             });
             gsq = uni_f(r7[0]);
             if (!(gsq < __builtin_inff())) { phase = PH_FINAL; continue; }      // (s keeps the value of the last completed iteration)
             s = sn;
             gd_1 = uni_f(r7[1]); gd_2 = uni_f(r7[2]); rs_1 = uni_f(r7[3]); rs_2 = uni_f(r7[4]); cu_1 = uni_f(r7[5]); cu_2 = uni_f(r7[6]);
+            gd_3 = uni_f(r7[7]); rs_3 = uni_f(r7[8]); cu_3 = uni_f(r7[9]);
             two = (has_ls ? a.A.maxls : 1) > 1;
+            three = have_t3 && has_ls && a.A.maxls > 2;          // third trial side by side with the first two
             spec = (k + 1 < a.A.max_iter);
             // where the optimiser moves if it ends on trial j with an improvement (the expressions of the tail above)
             const float bt = a.beta[kr];
             for (int e = tid; e < N; e += Team::NT) {
                 int jj = e % m;
-                const float x1 = xn1[e], x2 = xn2[e], xe = xk[e];
+                const float x1 = xn1[e], x2 = xn2[e], x3 = xn3[e], xe = xk[e];
                 y1[e] = (rs_1 > 0.0f) ? x1 : clampf(FMA(bt, x1 - xe, x1), a.C.ulo[jj], a.C.uhi[jj]);
                 if (two) y2[e] = (rs_2 > 0.0f) ? x2 : clampf(FMA(bt, x2 - xe, x2), a.C.ulo[jj], a.C.uhi[jj]);
+                if (three) y3[e] = (rs_3 > 0.0f) ? x3 : clampf(FMA(bt, x3 - xe, x3), a.C.ulo[jj], a.C.uhi[jj]);
             }
             __syncthreads();
             phase = PH_PAR;

@@ -228,7 +228,7 @@ def main():
                                       "(one particle per wave; three line-search trials and the candidate gradients of the next iteration evaluated at once); bit-identical results",
             "p50_batch_latency_ms": float(np.median(ev_ms)),
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
-                         "traffic": traffic, "kernel": "sdempc::exact::sdempc_solve_kernel<sdempc::exact::%s, %d, %s, false, 0>" % ("TeamBlock" if P > 32 else "TeamWave", m if m in (4, 6) else 8, "true" if args.mlp_dtype == "f16" else "false"), "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel": "sdempc::exact::sdempc_solve_kernel<sdempc::exact::%s, %d, %s, false, 0, false>" % ("TeamBlock" if P > 32 else "TeamWave", m if m in (4, 6) else 8, "true" if args.mlp_dtype == "f16" else "false"), "kernel_ms": k_ms,
                          "note": "f32-exact path: MLP contractions on v_mfma_f32_32x32x2_f32 (157.3 TF dense peak = f32 vector peak); "
                                  "algorithmic flops = SURVEY §8d MLP formula x P*H*(2*N_it+N_ls+2)"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,

@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the MPC inner loop on MI355X: MPC solves/sec (+ p50 solve latency), Iris H=50 P=128.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N>1 launched under torch.distributed.run,
-one rank per GPU over RCCL). A "step" = one launch of the solve kernel over one batch of B independent
-MPC problem instances per GPU (synthetic initial states; inputs already resident in HBM). Weak scaling:
-B per GPU is fixed, instances are sharded one batch per GPU with no data-path collective; rank 0
-broadcasts the shared model blob once over RCCL at start-up. Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`. For N>1 either launch it under torch.distributed.run
+(one rank per GPU over RCCL; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or call it plainly:
+without WORLD_SIZE in the environment the parent — before anything touches the GPU — starts the N ranks itself as
+child processes (rendezvous on 127.0.0.1), relays rank 0's JSON line and exits with the children's return code.
+A "step" = one launch of the solve kernel over one batch of B independent MPC problem instances per GPU
+(synthetic initial states; inputs already resident in HBM). Weak scaling: B per GPU is fixed, instances are
+sharded one batch per GPU with no data-path collective; rank 0 broadcasts the shared model blob once over RCCL
+at start-up. Rank 0 prints ONE JSON line. The timed launch's outputs of the first instances are compared bit for
+bit with the CPU oracle solving the same instances (verified_instances / verified_bit_exact in the line).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -61,25 +67,102 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(cfg, model, n_threads, x0, xref, noise, u0, s0):
-    """Oracle (CPU restatement, kind 'port') on the host cores: one solve per thread, wall clock."""
+def cpu_oracle():
+    """The CPU restatement (oracle/, test infrastructure): bench.py touches it only in its CPU legs below — as the checker of the
+    timed launch's outputs and as the reported cpu_baseline, never inside the timed region."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    oracles = [orc.Oracle(cfg, model) for _ in range(n_threads)]
-    out = [None] * n_threads
+    return orc
 
-    reps = 2   # solves per thread: keeps the sample at ~10-15 s of wall time
+
+def cpu_solve_instances(cfg, model, n_threads, x0, xref, keys, u0, s0, fast=False):
+    """CPU leg, kind 'port': the C oracle (CPU restatement of SPEC.md) solves the given instances — the first ones of the GPU
+    batch, noise derived from the same threefry keys — one solve at a time per thread, all usable host cores. fast=False: the
+    bit-exact -O2 build the parity tests use (its outputs are what the GPU results are compared with); fast=True: the same source
+    built -O3 -march=native (oracle/Makefile: liborc_fast.so), the credible CPU timing. Returns (solves/s, wall s, outputs)."""
+    orc = cpu_oracle()
+    n = len(x0)
+    O = [orc.Oracle(cfg, model, fast=fast) for _ in range(n_threads)]
+    P, H = cfg.num_particles, cfg.horizon
+    noise = [None] * n
+    out = [None] * n
+    nxt = [0]
+    lock = threading.Lock()
+
+    def draw(i):
+        while True:
+            with lock:
+                j = nxt[0]; nxt[0] += 1
+            if j >= n:
+                return
+            noise[j] = orc.noise_from_key(keys[j], P, H)
+
+    th = [threading.Thread(target=draw, args=(i,)) for i in range(n_threads)]
+    [t.start() for t in th]; [t.join() for t in th]
+    nxt[0] = 0
 
     def work(i):
-        for _ in range(reps):
-            out[i] = oracles[i].solve(x0[i], xref[i], noise[i], u0[i], s0)
+        while True:
+            with lock:
+                j = nxt[0]; nxt[0] += 1
+            if j >= n:
+                return
+            out[j] = O[i].solve(x0[j], xref[j], noise[j], u0[j], s0)[:3]
 
     t0 = time.time()
     th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
-    [t.start() for t in th]
-    [t.join() for t in th]
+    [t.start() for t in th]; [t.join() for t in th]
     dt = time.time() - t0
-    return reps * n_threads / dt, dt, out
+    return n / dt, dt, out
+
+
+def words_differ(a, b):
+    """f32 words whose bits differ (NaNs compared as a class: x86 and gfx950 produce different NaN signs, SPEC.md §3.7)."""
+    fa, fb = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    both_nan = np.isnan(fa) & np.isnan(fb)
+    return int(((fa.view(np.uint32) != fb.view(np.uint32)) & ~both_nan).sum())
+
+
+def cpu_c1_single_solve_ms(model_blob, reps=3):
+    """BASELINE config 1 (Iris posctrl YAML, H=20, 32 particles, CPU path, single solve, no GPU): one thread, -O3 -march=native
+    build of the oracle, median wall time of a full cold-start solve."""
+    orc = cpu_oracle()
+    from sde4mbrl_px4_amd import load_mpc_config, prng
+    from sde4mbrl_px4_amd import workload as W
+    cfg = load_mpc_config(os.path.join(ROOT, "configs", "c1_iris_posctrl_h20_p32.yaml"))
+    O = orc.Oracle(cfg, model_blob, fast=True)
+    x0 = W.random_initial_states(reps, 0)
+    keys = prng.split(prng.PRNGKey(10), reps)
+    u0 = np.tile(np.asarray(cfg.uref, np.float32)[None], (cfg.horizon, 1))
+    ms, nit = [], []
+    for r in range(reps):
+        noise = orc.noise_from_key(keys[r], cfg.num_particles, cfg.horizon)
+        xref = W.constant_reference(W.HOVER, cfg.horizon)
+        t = time.perf_counter()
+        _, _, info, _ = O.solve(x0[r], xref, noise, u0, cfg.ls_init_stepsize)
+        ms.append((time.perf_counter() - t) * 1e3)
+        nit.append(float(info[2]))
+    return float(np.median(ms)), float(np.mean(nit)), cfg
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: start the N ranks as children (nothing in this process has touched the GPU), relay
+    rank 0's output, return the worst child's return code. Rendezvous on 127.0.0.1 with a free port."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -95,7 +178,13 @@ def main():
     ap.add_argument("--latency-warmup", type=int, default=20)
     ap.add_argument("--mlp-dtype", default="f32", choices=["f32", "f16"],
                     help="f32: bit-reproducible path (default, the reported metric); f16: fp16-operand MLP contractions (SPEC.md 9)")
+    ap.add_argument("--verify", type=int, default=-1, help="instances of the timed launch checked bit for bit against the CPU oracle "
+                    "(-1: as many as the cpu_baseline leg solves, or 4 with --no-cpu-baseline; 0: none)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-start: this process never touches the GPU (no torch.cuda / HIP call has been made yet)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -184,6 +273,9 @@ def main():
     n_it = float(info_h[:, 2].mean())
     n_ls = float(info_h[:, 7].mean())
 
+    # outputs of the timed configuration (last launch: same inputs, deterministic kernel), kept for the verification below
+    uopt_h, xevol_h = uopt.cpu().numpy(), xevol.cpu().numpy()
+
     if rank == 0:
         solves = world * B * args.steps
         value = solves / elapsed
@@ -213,6 +305,7 @@ def main():
             torch.cuda.synchronize()
             if r >= 0:
                 lat.append((time.perf_counter() - t) * 1e3)
+            solver.solve_status()     # raises if a grid barrier of the cooperative layout gave up (results would be invalid)
         out = {
             "metric": "MPC solves/sec, Iris H=50 P=128 (p50 solve latency in p50_solve_latency_ms)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,7 +316,7 @@ def main():
                        "instances_per_gpu": B, "noise": "threefry2x32 keys (seed 10 split per instance), normal draws generated on the device", "N_it_mean": n_it, "N_ls_mean": n_ls, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "p50_solve_latency_ms": float(np.median(lat)),
             "p95_solve_latency_ms": float(np.percentile(lat, 95)),
-            "latency_reps": len(lat),
+            "latency_reps": len(lat), "latency_layout_fallbacks": solver.layout_fallbacks(),
             "p50_solve_latency_note": "one instance alone on the GPU (B = 1 launch of the same C-ABI entry point): the library spreads it over ceil(P/4) x 7 workgroups "
                                       "(one particle per wave; three line-search trials and the candidate gradients of the next iteration evaluated at once); bit-identical results",
             "p50_batch_latency_ms": float(np.median(ev_ms)),
@@ -236,18 +329,44 @@ def main():
                              "checkpoint_bytes_per_solve": checkpoint_bytes(cfg, n_it),
                              "note": "achieved = SURVEY 8d algorithmic bytes / kernel time; measured traffic additionally contains the activation-checkpoint stream"},
         }
-        if not args.no_cpu_baseline and world == 1:
-            nthr = args.cpu_threads or min(effective_cores(), 64)
-            from sde4mbrl_px4_amd.model import RotorSDEModel  # noqa: F401
-            noise_h = W.make_noise(nthr, P, H, 777)
-            xb = W.random_initial_states(nthr, 0)
-            xr = np.stack([W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(nthr)])
-            ub = np.tile(yk[None], (nthr, 1, 1))
-            v, dt, _ = cpu_baseline(cfg, blob, nthr, xb, xr, noise_h, ub, s0)
+        # ---- CPU legs (rank 0): verification of the timed launch + the reported CPU baseline ------------------------------------
+        nthr = args.cpu_threads or min(effective_cores(), 64)
+        do_cpu = not args.no_cpu_baseline and world == 1
+        n_ver = args.verify if args.verify >= 0 else (nthr if do_cpu else 4)
+        n_ver = min(n_ver, B)
+        if n_ver > 0 and args.mlp_dtype == "f32":
+            # the SAME instances the GPU solved (first n_ver of rank 0's batch: same x0 / xref / keys / warm start), bit-exact oracle build
+            v_exact, dt_exact, outs = cpu_solve_instances(cfg, blob, min(nthr, n_ver), x0_h[:n_ver], xref_h[:n_ver], keys[:n_ver], u0_h[:n_ver], s0)
+            bad = 0
+            for i, (uo, xe, io) in enumerate(outs):
+                bad += words_differ(uopt_h[i], uo) + words_differ(xevol_h[i], xe) + words_differ(info_h[i], io)
+            out["verified_instances"] = n_ver
+            out["verified_bit_exact"] = bad == 0
+            out["verified_note"] = ("uopt, xevol and the 8 telemetry words of the first %d instances of the timed launch compared bit for bit with the "
+                                    "CPU oracle (oracle/sde_mpc_oracle.c, -O2 build) solving the same instances from the same keys; %d words differ" % (n_ver, bad))
+            if bad:
+                print(json.dumps(out))
+                raise SystemExit(f"bench.py: the timed launch's outputs differ from the oracle in {bad} words")
+        else:
+            out["verified_instances"] = 0
+            out["verified_bit_exact"] = None
+        if do_cpu:
+            # reported baseline: the same source built -O3 -march=native, one solve at a time per thread on every usable core,
+            # on 2 instances per thread of the same workload (first instances of the GPU batch)
+            n_cpu = min(2 * nthr, B)
+            v, dt, outs_f = cpu_solve_instances(cfg, blob, nthr, x0_h[:n_cpu], xref_h[:n_cpu], keys[:n_cpu], u0_h[:n_cpu], s0, fast=True)
+            md = max(float(np.max(np.abs(outs_f[i][0] - uopt_h[i]))) for i in range(n_cpu))
+            c1_ms, c1_nit, c1cfg = cpu_c1_single_solve_ms(blob)
             out["cpu_baseline"] = {"value": v, "unit": "solves/s", "cores": nthr, "kind": "port",
-                                   "sample": f"{2 * nthr} solves of the same workload (two per thread, one thread per usable host core: os.cpu_count {os.cpu_count()}, "
-                                             f"cgroup/affinity limit {effective_cores()}; {dt:.1f} s wall) by the C oracle "
-                                             "(CPU restatement, not the reference JAX path: that cannot run here)"}
+                                   "threads_used": nthr, "os_cpu_count": os.cpu_count(), "usable_cores": effective_cores(),
+                                   "sample": f"{n_cpu} solves of the same workload (the first {n_cpu} instances of the GPU batch, one solve at a time per thread, "
+                                             f"{nthr} threads = usable host cores: os.cpu_count {os.cpu_count()}, cgroup/affinity limit {effective_cores()}; {dt:.1f} s wall) "
+                                             "by the C oracle built -O3 -march=native (CPU restatement of SPEC.md, not the reference JAX path: that cannot run here); "
+                                             f"max |uopt - GPU uopt| over the sample {md:.1e}",
+                                   "value_bit_exact_build": (n_ver / dt_exact) if n_ver > 0 and args.mlp_dtype == "f32" else None,
+                                   "cpu_c1_single_solve_ms": c1_ms,
+                                   "cpu_c1_note": f"BASELINE config 1: {os.path.basename('c1_iris_posctrl_h20_p32.yaml')} H={c1cfg.horizon} P={c1cfg.num_particles}, one cold-start solve "
+                                                  f"(N_it {c1_nit:.0f}) on ONE thread, -O3 -march=native oracle build, median of 3"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

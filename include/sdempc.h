@@ -121,6 +121,41 @@ int sdempc_abi_version(void);
 /* Binds the handle to a HIP device ordinal (default 0). Must precede the first device call. */
 int sdempc_set_device(sdempc_handle* h, int32_t device);
 
+/* 1 once the handle has initialised the GPU (first device call), else 0. Host-only, no HIP call: lets the caller of a forked
+ * process (the reference forks mpc_process after building its solvers, sde_control.py:69-75,723-728) tell a handle that is safe
+ * to use from one whose HIP state belongs to the parent and must be abandoned without sdempc_destroy. */
+int sdempc_device_ready(const sdempc_handle* h);
+
+/* ---- execution options (per handle) ---------------------------------------------------------
+ * How a call is laid out on the GPU; none of them changes a bit of any result. No reference counterpart (the reference's
+ * solver objects, sde_control.py:681-721, have no such knobs). The environment variables named below only give the DEFAULT of
+ * a handle created afterwards (read once inside sdempc_create); nothing on the launch path reads the environment.
+ *   key                       values                         default  environment default
+ *   SDEMPC_OPT_LANE           0 / 1                          1        SDEMPC_LANE          P == 1 instances in the single-particle lane layout
+ *   SDEMPC_OPT_COOP           0 / 1                          1        SDEMPC_COOP          small batches spread over many workgroups (latency layouts);
+ *                                                                                          setting 1 also re-arms a handle that fell back (sdempc_layout_fallbacks)
+ *   SDEMPC_OPT_SPEC           0 / 1                          1        SDEMPC_SPEC          speculative variant of the cooperative layout (smallest batches)
+ *   SDEMPC_OPT_PK             -1 auto / 0 / 1                -1       SDEMPC_PK            packed-f32 tanh instantiation of the tile layout (auto: grid <= CUs)
+ *   SDEMPC_OPT_USTG           -1 auto / 0 / 1                -1       SDEMPC_USTG          per-step control table in global memory instead of LDS (auto: long horizons)
+ *   SDEMPC_OPT_COOP_LAUNCH    0 / 1                          0        SDEMPC_COOP_LAUNCH   hipLaunchCooperativeKernel for the cooperative layouts
+ *   SDEMPC_OPT_COOP_FENCE     0 / 1                          0        SDEMPC_COOP_FENCE    agent-scope release / acquire fences around the grid barrier
+ *   SDEMPC_OPT_COOP_SPIN_US   -1 derived / >= 0 microseconds -1       SDEMPC_COOP_SPIN_US  how long one grid barrier of a cooperative layout may wait
+ *                                                                                          before the launch gives up (derived: 5 x the handle's last completed
+ *                                                                                          cooperative solve, clamped to 2..100 ms; 100 ms before the first)
+ *   SDEMPC_OPT_DEVICE_CUS     read-only                                                    compute units of the handle's device (after the first device call)
+ */
+#define SDEMPC_OPT_LANE 1
+#define SDEMPC_OPT_COOP 2
+#define SDEMPC_OPT_SPEC 3
+#define SDEMPC_OPT_PK 4
+#define SDEMPC_OPT_USTG 5
+#define SDEMPC_OPT_COOP_LAUNCH 6
+#define SDEMPC_OPT_COOP_FENCE 7
+#define SDEMPC_OPT_COOP_SPIN_US 8
+#define SDEMPC_OPT_DEVICE_CUS 9
+int sdempc_set_option(sdempc_handle* h, int32_t key, int32_t value);
+int sdempc_get_option(const sdempc_handle* h, int32_t key, int32_t* value);
+
 /* ---- m_reset (sde_control.py:702-707,345-346,389-394) -------------------------------------- */
 /* Host-only. Fills yk[H][m] with the hover guess uref and info with the initial telemetry. */
 int sdempc_reset(sdempc_handle* h, const float* x, const float* xdes, float* yk, sdempc_info* info);
@@ -141,8 +176,8 @@ int sdempc_grad_batch(sdempc_handle* h, int32_t B, const float* x0, const float*
  * workgroups, one particle per wave, with one bounded grid barrier per rollout, and for the smallest batches additionally evaluate up to three
  * line-search trials and the candidate gradients of the next iteration at once (C2 single solve: 31 ms instead of 158 ms); larger
  * batches run one workgroup per instance in the 32-particle MFMA tile layout (throughput). The cooperative layouts assume that no other
- * kernel occupies the GPU while they run; if their workgroups cannot all become resident the barrier gives up after a bounded number of
- * polls and the telemetry of the launch is NaN. The host-pointer entry points then run the same batch once more in the
+ * kernel occupies the GPU while they run; if their workgroups cannot all become resident the barrier gives up after a bounded time
+ * (SDEMPC_OPT_COOP_SPIN_US) and the telemetry of the launch is NaN. The host-pointer entry points then run the same batch once more in the
  * one-workgroup-per-instance layout (identical results) and the handle stays off the cooperative layouts from then on
  * (sdempc_layout_fallbacks counts these events); callers of sdempc_solve_batch_dev ask sdempc_solve_status. */
 int sdempc_solve_batch(sdempc_handle* h, int32_t B, const float* x0, const float* xref,

@@ -55,6 +55,9 @@ class SdempcInfo(C.Structure):
 
 INFO_FIELDS = [f[0] for f in SdempcInfo._fields_]
 
+# execution options of a handle (include/sdempc.h, SDEMPC_OPT_*)
+OPTIONS = {"lane": 1, "coop": 2, "spec": 3, "pk": 4, "ustg": 5, "coop_launch": 6, "coop_fence": 7, "coop_spin_us": 8, "device_cus": 9}
+
 _LIB = None
 
 
@@ -86,6 +89,12 @@ def load_library():
     lib.sdempc_last_error.restype = C.c_char_p
     lib.sdempc_abi_version.restype = C.c_int
     lib.sdempc_set_device.argtypes = [vp, i32]
+    lib.sdempc_device_ready.argtypes = [vp]
+    lib.sdempc_device_ready.restype = C.c_int
+    lib.sdempc_set_option.argtypes = [vp, i32, i32]
+    lib.sdempc_set_option.restype = C.c_int
+    lib.sdempc_get_option.argtypes = [vp, i32, C.POINTER(i32)]
+    lib.sdempc_get_option.restype = C.c_int
     lib.sdempc_reset.argtypes = [vp, fp, fp, fp, C.POINTER(SdempcInfo)]
     lib.sdempc_rollout_batch.argtypes = [vp, i32, fp, fp, fp, fp, fp, fp, fp]
     lib.sdempc_grad_batch.argtypes = [vp, i32, fp, fp, fp, fp, fp, fp]
@@ -120,7 +129,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "sdempc_create", "sdempc_destroy", "sdempc_last_error", "sdempc_abi_version", "sdempc_set_device", "sdempc_reset",
+    "sdempc_create", "sdempc_destroy", "sdempc_last_error", "sdempc_abi_version", "sdempc_set_device", "sdempc_device_ready", "sdempc_set_option", "sdempc_get_option", "sdempc_reset",
     "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch", "sdempc_noise_dev_floats",
     "sdempc_traj_dev_floats", "sdempc_noise_to_device_layout", "sdempc_solve_batch_dev", "sdempc_rollout_batch_dev",
     "sdempc_grad_batch_dev", "sdempc_last_kernel_ms", "sdempc_solve_status", "sdempc_layout_fallbacks", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev",

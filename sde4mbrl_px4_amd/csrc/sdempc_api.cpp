@@ -69,6 +69,8 @@ struct sdempc_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    int spin_us = -1;         // SDEMPC_OPT_COOP_SPIN_US: budget of one grid barrier in microseconds; -1 = derived (coop_spin_ticks)
+    float coop_ms_last = 0.0f;   // duration of the last cooperative-layout solve that completed (0: none measured yet)
     int last_coop_B = 0;      // > 0: the last solve launch took the cooperative path with this many instances (error flags to check)
     bool coop_off = false;    // a grid barrier timed out once: this handle stays on the one-workgroup-per-instance layouts
     int layout_fallbacks = 0; // how often that happened (sdempc_layout_fallbacks)
@@ -93,6 +95,40 @@ int fail(sdempc_handle* h, int code, const char* fmt, const char* detail = "") {
             return SDEMPC_EDEVICE;                                                      \
         }                                                                               \
     } while (0)
+
+// Environment variables give the DEFAULTS of a new handle's options, read once here (sdempc_create); the launch path never reads the
+// environment. Unset or malformed -> the built-in default.
+int env_int(const char* name, int dflt, int lo, int hi) {
+    const char* e = getenv(name);
+    if (!e || !*e) return dflt;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || v < lo || v > hi) return dflt;
+    return (int)v;
+}
+void default_options(sdempc_handle* h) {
+    LaunchOpts& o = h->base.opt;
+    o.cus = 256;                                       // replaced by the device's count when the device is bound (ensure_device)
+    o.lane = env_int("SDEMPC_LANE", 1, 0, 1);
+    o.coop = env_int("SDEMPC_COOP", 1, 0, 1);
+    o.spec = env_int("SDEMPC_SPEC", 1, 0, 1);
+    o.pk = env_int("SDEMPC_PK", -1, -1, 1);
+    o.ustg = env_int("SDEMPC_USTG", -1, -1, 1);
+    o.coop_launch = env_int("SDEMPC_COOP_LAUNCH", 0, 0, 1);
+    o.coop_fence = env_int("SDEMPC_COOP_FENCE", 0, 0, 1);
+    h->spin_us = env_int("SDEMPC_COOP_SPIN_US", -1, -1, 10 * 1000 * 1000);
+}
+// Budget of one grid barrier of the cooperative layouts, in 10 ns ticks (KArgs::coop_spin). A barrier is passed ~780 times per C2
+// solve, microseconds each; one that waits this long means the grid is not fully resident (the GPU is shared) and the launch gives
+// up so that the caller's control tick falls back to the one-workgroup-per-instance layout instead of stalling. Derived: five times
+// the last completed cooperative solve of this handle, between 2 ms and 100 ms; 100 ms before the first one.
+unsigned coop_spin_ticks(const sdempc_handle* h) {
+    if (h->spin_us >= 0) return (unsigned)((uint64_t)h->spin_us * 100u > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)h->spin_us * 100u);
+    float ms = h->coop_ms_last > 0.0f ? 5.0f * h->coop_ms_last : 100.0f;
+    if (ms < 2.0f) ms = 2.0f;
+    if (ms > 100.0f) ms = 100.0f;
+    return (unsigned)(ms * 1e5f);
+}
 
 int dev_alloc(sdempc_handle* h, DevBuf& b, size_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -119,6 +155,11 @@ int ensure_device_impl(sdempc_handle* h) {
     if (e != hipSuccess || n <= 0) return fail(h, SDEMPC_EDEVICE, "no HIP device available (%s); sdempc has no CPU fallback", hipGetErrorString(e));
     if (h->device >= n) return fail(h, SDEMPC_EDEVICE, "device ordinal out of range%s");
     HIPCHK(h, hipSetDevice(h->device));
+    {   // compute units of THIS handle's device (the layout heuristics count workgroups against it)
+        int cus = 0;
+        HIPCHK(h, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        if (cus > 0) h->base.opt.cus = cus;
+    }
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreate(&h->ev0));
     HIPCHK(h, hipEventCreate(&h->ev1));
@@ -226,6 +267,9 @@ int coop_timed_out(sdempc_handle* h, bool* timed_out) {
         h->coop_off = true;
         h->layout_fallbacks += 1;
         h->last_coop_B = 0;
+    } else if (h->timed) {               // completed: its duration scales the next launch's barrier budget (coop_spin_ticks)
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess && ms > 0.0f) h->coop_ms_last = ms;
     }
     return 0;
 }
@@ -323,6 +367,7 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     a.A.reset_inc = cfg->ls_reset_option == 1;
     a.A.atol = cfg->atol; a.A.rtol = cfg->rtol; a.A.stepsize = cfg->stepsize; a.A.smax = cfg->ls_max_stepsize;
     a.A.coef = cfg->ls_coef; a.A.dec = cfg->ls_decrease_factor; a.A.inc = cfg->ls_increase_factor;
+    default_options(h);
     *out = h;
     return SDEMPC_OK;
 }
@@ -358,6 +403,47 @@ int sdempc_set_device(sdempc_handle* h, int32_t device) {
     if (h->dev_ready) return fail(h, SDEMPC_EINVAL, "sdempc_set_device must precede the first device call%s");
     if (device < 0) return fail(h, SDEMPC_EINVAL, "negative device ordinal%s");
     h->device = device;
+    return SDEMPC_OK;
+}
+
+int sdempc_device_ready(const sdempc_handle* h) { return h && h->dev_ready ? 1 : 0; }
+
+int sdempc_set_option(sdempc_handle* h, int32_t key, int32_t value) {
+    if (!h) return SDEMPC_EINVAL;
+    LaunchOpts& o = h->base.opt;
+    auto flag = [&](int& dst) { if (value != 0 && value != 1) return fail(h, SDEMPC_EINVAL, "option value must be 0 or 1%s"); dst = value; return (int)SDEMPC_OK; };
+    auto tri = [&](int& dst) { if (value < -1 || value > 1) return fail(h, SDEMPC_EINVAL, "option value must be -1 (auto), 0 or 1%s"); dst = value; return (int)SDEMPC_OK; };
+    switch (key) {
+        case SDEMPC_OPT_LANE: return flag(o.lane);
+        case SDEMPC_OPT_COOP: { int rc = flag(o.coop); if (rc == SDEMPC_OK && value == 1) h->coop_off = false; return rc; }
+        case SDEMPC_OPT_SPEC: return flag(o.spec);
+        case SDEMPC_OPT_PK: return tri(o.pk);
+        case SDEMPC_OPT_USTG: return tri(o.ustg);
+        case SDEMPC_OPT_COOP_LAUNCH: return flag(o.coop_launch);
+        case SDEMPC_OPT_COOP_FENCE: return flag(o.coop_fence);
+        case SDEMPC_OPT_COOP_SPIN_US:
+            if (value < -1) return fail(h, SDEMPC_EINVAL, "spin budget must be -1 (derived) or >= 0 microseconds%s");
+            h->spin_us = value;
+            return SDEMPC_OK;
+        default: return fail(h, SDEMPC_EINVAL, "unknown option key%s");
+    }
+}
+
+int sdempc_get_option(const sdempc_handle* h, int32_t key, int32_t* value) {
+    if (!h || !value) return SDEMPC_EINVAL;
+    const LaunchOpts& o = h->base.opt;
+    switch (key) {
+        case SDEMPC_OPT_LANE: *value = o.lane; break;
+        case SDEMPC_OPT_COOP: *value = o.coop && !h->coop_off; break;
+        case SDEMPC_OPT_SPEC: *value = o.spec; break;
+        case SDEMPC_OPT_PK: *value = o.pk; break;
+        case SDEMPC_OPT_USTG: *value = o.ustg; break;
+        case SDEMPC_OPT_COOP_LAUNCH: *value = o.coop_launch; break;
+        case SDEMPC_OPT_COOP_FENCE: *value = o.coop_fence; break;
+        case SDEMPC_OPT_COOP_SPIN_US: *value = h->spin_us >= 0 ? h->spin_us : (int32_t)(coop_spin_ticks(h) / 100u); break;
+        case SDEMPC_OPT_DEVICE_CUS: *value = o.cus; break;
+        default: return SDEMPC_EINVAL;
+    }
     return SDEMPC_OK;
 }
 
@@ -440,8 +526,8 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
     // Small batches of multi-particle instances: one instance over ceil(P/4) workgroups, one particle per wave (latency path).
     // Same results bit for bit; only taken when every workgroup of the grid is resident at once.
     const bool coop_ok = !a.fast && !a.f16 && !h->coop_off;
-    const int smax = coop_ok ? spec_max_instances(h->P, h->H, h->m) : 0;
-    int cmax = coop_ok ? coop_max_instances(h->P, h->H, h->m) : 0;
+    const int smax = coop_ok ? spec_max_instances(h->P, h->H, h->m, a.opt) : 0;
+    int cmax = coop_ok ? coop_max_instances(h->P, h->H, h->m, a.opt) : 0;
     if (smax > cmax) cmax = smax;
     if (B <= cmax) {
         if (!h->d_coop_bar.p) {
@@ -454,9 +540,10 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
         if (B <= h->coop_cap) {
             HIPCHK(h, hipMemsetAsync(h->d_coop_bar.p, 0, sizeof(unsigned) * 2 * (size_t)B, st));
             a.coop_bar = (unsigned*)h->d_coop_bar.p; a.coop_pp = (float*)h->d_coop_pp.p; a.coop_ck = (float*)h->d_coop_ck.p;
+            a.coop_spin = coop_spin_ticks(h);
             h->last_coop_B = B;
             if (B <= smax) return timed_launch(h, st, [&] { return launch_solve_spec(a, B, st); });
-            if (B <= coop_max_instances(h->P, h->H, h->m)) return timed_launch(h, st, [&] { return launch_solve_coop(a, B, st); });
+            if (B <= coop_max_instances(h->P, h->H, h->m, a.opt)) return timed_launch(h, st, [&] { return launch_solve_coop(a, B, st); });
             h->last_coop_B = 0;
         }
     }

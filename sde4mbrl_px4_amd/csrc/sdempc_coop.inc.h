@@ -12,26 +12,41 @@
 struct CoopCtx {
     int nwg, wgi, Ppad;
     unsigned* bar;          // this instance's arrival counter (zeroed by the host before the launch), bar[1] = error flag
-    unsigned epoch, spin_limit;
+    unsigned epoch, spin_limit;   // spin_limit: ticks of the 100 MHz s_memrealtime clock one barrier may wait (KArgs::coop_spin)
+    int fence;              // KArgs::opt.coop_fence: agent-scope release / acquire fences around the barrier
     float* pp;              // [2][PS][Ppad] per-particle outputs, double-buffered by rollout parity
     float* ck;              // [P][H+1][COOP_ROW] checkpoint rows
 };
 
+// Grid barrier of the cooperative layouts. Memory ordering of the hand-off ("grid barrier"): every handed-off word is
+// written with an agent-scope (sc1, write-through) store and read with an agent-scope (sc1, L1-bypassing) global load; every storing
+// wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup barrier behind which ONE lane adds to the counter; the polling
+// lane's workgroup loads only after the workgroup barrier that follows its poll. That is the fence-free form listed as valid (and
+// measured on gfx950 / ROCm 7.2, not an architectural guarantee) in MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement &
+// inter-workgroup visibility", Consumer conditions (1)-(4), first table row. C.fence adds the language-level release / acquire pair
+// of the HIP memory model on top (buffer_wbl2 sc1 / buffer_inv sc1): SDEMPC_OPT_COOP_FENCE, same results, measured cost in DESIGN.md.
+// The wait is bounded in TIME (s_memrealtime, 100 MHz): a grid that is not fully resident gives up instead of hanging the GPU.
 DI void coop_barrier(CoopCtx& C, int tid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's (sc1) stores of the handed-off values have completed
     __syncthreads();
     C.epoch += 1;
     if (tid == 0) {
-        if (SDEMPC_COOP_FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (C.fence) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the wait behind buffer_wbl2 (ROCm 7.2): keep it explicit
+        }
         __hip_atomic_fetch_add(C.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = C.epoch * (unsigned)C.nwg;
-        unsigned spins = 0;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(C.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             if (__hip_atomic_load(C.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;      // another workgroup gave up
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > C.spin_limit) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 >= (uint64_t)C.spin_limit) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
-        if (SDEMPC_COOP_FENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (C.fence) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the invalidate completes asynchronously: hold the workgroup barrier until it has
+        }
     }
     __syncthreads();
 }

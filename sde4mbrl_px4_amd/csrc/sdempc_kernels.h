@@ -22,6 +22,18 @@ struct ApgK {
     int max_iter, max_noimp, maxls, reset_inc;
     float atol, rtol, stepsize, smax, coef, dec, inc;
 };
+// Host-side dispatch options of one handle (include/sdempc.h: sdempc_set_option / SDEMPC_OPT_*). Travels inside KArgs so that the
+// launchers see it; device code reads only coop_fence.
+struct LaunchOpts {
+    int cus;           // compute units of the handle's device (hipDeviceAttributeMultiprocessorCount), set when the device is bound
+    int lane;          // 1: single-particle lane layout for P == 1 (default), 0: tile layout
+    int coop;          // 1: cooperative multi-workgroup layouts for small batches (default), 0: off
+    int spec;          // 1: speculative variant of the cooperative layout for the smallest batches (default), 0: off
+    int pk;            // -1: packed-f32 tanh instantiation when the grid leaves one wave per SIMD (default), 0 / 1: forced
+    int ustg;          // -1: per-step control table in global memory when that raises occupancy (default), 0 / 1: forced
+    int coop_launch;   // 1: hipLaunchCooperativeKernel for the cooperative layouts, 0: plain launch of a grid sized to be resident (default)
+    int coop_fence;    // 1: agent-scope release / acquire fences around the grid barrier, 0: sc1 write-through hand-off only (default)
+};
 struct KArgs {
     int H, P, m, G;
     int B;                     // instances in this launch (set by the launcher)
@@ -56,10 +68,11 @@ struct KArgs {
     int coop_ngrp;             // speculative variant: groups of coop_nwg workgroups per instance (2..5)
     unsigned* coop_bar;        // [B][2]: arrival counter, error flag (zeroed before every launch)
     float* ustg;               // [B][H][36] per-step control table in global memory (long horizons: keeps it out of LDS), or NULL
-    unsigned coop_spin;        // polls of one grid barrier before it gives up (COOP_SPIN_DEFAULT; test hook SDEMPC_COOP_SPIN)
+    unsigned coop_spin;        // time one grid barrier may wait before it gives up, in ticks of the 100 MHz s_memrealtime clock (10 ns)
     float* coop_pp;            // [B][2][part_stride(H)][G*32]
     float* coop_ck;            // [B][P][H+1][160]
     int fast;                  // SPEC.md §10: hardware transcendentals (selects the fastm translation unit; host-side switch)
+    LaunchOpts opt;
 };
 
 // floats per (instance, group) row of KArgs::part: max(H*12 adjoint sums, (H+1)*13 state sums) + the group's cost total in the
@@ -75,12 +88,12 @@ size_t smem_bytes(int H, int m, int ipb);   // ipb: instances (teams) per workgr
 // Cooperative latency path of the solve (exact f32, P >= 2): workgroups per instance, workspace sizes, launcher.
 // coop_max_instances: how many instances fit one workgroup per CU on the current device (0 = path unavailable for this shape)
 int coop_nwg(int P);
-int coop_max_instances(int P, int H, int m);
+int coop_max_instances(int P, int H, int m, const LaunchOpts& o);
 size_t coop_pp_floats(int H, int G);           // per instance
 size_t coop_ck_floats(int H, int P);           // per instance
 hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st);
 // speculative variant for the smallest batches (4 groups of workgroups per instance: two trials and two candidate gradients at once)
-int spec_max_instances(int P, int H, int m);
+int spec_max_instances(int P, int H, int m, const LaunchOpts& o);
 hipError_t launch_solve_spec(const KArgs& a, int B, hipStream_t st);
 int team_ipb(int G, int H, int m);            // 4 when one wave owns an instance (G == 1 and LDS permits), else 1
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st);

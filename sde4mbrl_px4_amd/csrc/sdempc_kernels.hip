@@ -664,7 +664,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     int b_;                                                                          \
     if constexpr (MODE == 2) {                                                       \
         b_ = blockIdx.x / a.coop_nwg;                                                \
-        CC.nwg = a.coop_nwg; CC.wgi = blockIdx.x - b_ * a.coop_nwg; CC.Ppad = a.G * 32; CC.epoch = 0u; CC.spin_limit = a.coop_spin; \
+        CC.nwg = a.coop_nwg; CC.wgi = blockIdx.x - b_ * a.coop_nwg; CC.Ppad = a.G * 32; CC.epoch = 0u; CC.spin_limit = a.coop_spin; CC.fence = a.opt.coop_fence; \
         CC.bar = a.coop_bar + 2 * b_;                                                \
         CC.pp = a.coop_pp + (size_t)b_ * 2 * part_stride(a.H) * CC.Ppad;             \
         CC.ck = a.coop_ck + (size_t)b_ * a.P * (a.H + 1) * COOP_ROW;                 \
@@ -826,20 +826,12 @@ static hipError_t launch_grad_team(const KArgs& a, hipStream_t st) {
     if (a.m == 6) return launch_k(sdempc_grad_kernel<Team, 6, F16>, a, st, Team::IPB);
     return launch_k(sdempc_grad_kernel<Team, 8, F16>, a, st, Team::IPB);
 }
-// Number of compute units of the current device (cached): a grid of at most that many workgroups leaves one wave per SIMD.
-static int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else return 256;
-    }
-    return cus;
-}
-// Throughput launches of the workgroup-wide team: is the per-step control table better kept in global memory? (SDEMPC_USTG=0/1 forces)
-bool use_global_ust(int H, int m) {
-    const char* force = getenv("SDEMPC_USTG");
-    if (force) return force[0] == '1';
+// LaunchOpts::cus = compute units of the handle's device (set by the C ABI when the device is bound): a grid of at most that many
+// workgroups leaves one wave per SIMD. Every dispatch decision below comes from the handle's LaunchOpts (sdempc_set_option); no
+// environment variable is read on the launch path.
+// Throughput launches of the workgroup-wide team: is the per-step control table better kept in global memory? (SDEMPC_OPT_USTG forces)
+bool use_global_ust(int H, int m, const LaunchOpts& o) {
+    if (o.ustg >= 0) return o.ustg == 1;
     // workgroups per CU: at most three by registers (launch bounds), otherwise what the 160 KB of LDS hold
     const size_t cap = 160 * 1024;
     auto per_cu = [&](size_t bytes) { const size_t n = bytes ? cap / bytes : 3; return n > 3 ? (size_t)3 : n; };
@@ -850,8 +842,7 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
     if constexpr (!F16 && !FAST) {
         // small-batch (latency) launches: one workgroup per CU at most -> a lone wave per SIMD is issue-bound -> packed tanh
         const int wgs = (a.B + Team::IPB - 1) / Team::IPB;
-        const char* force = getenv("SDEMPC_PK");            // "0" / "1": A/B switch for tools and tests (read per launch); unset: by grid size
-        const bool pk = force ? force[0] == '1' : wgs <= device_cus();
+        const bool pk = a.opt.pk >= 0 ? a.opt.pk == 1 : wgs <= a.opt.cus;     // SDEMPC_OPT_PK forces either instantiation (A/B, tests)
         if (pk) {
             if constexpr (Team::IPB == 1) {
                 if (a.G > 4) {   // more particle groups than the four waves of a workgroup: eight waves halve the sequential depth
@@ -867,7 +858,7 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
     }
     if constexpr (Team::IPB == 1 && !FAST) {
         // long horizons: with the control table in LDS only two workgroups fit a CU; without it three do (the kernel is built for three)
-        if (use_global_ust(a.H, a.m) && a.ustg) {
+        if (use_global_ust(a.H, a.m, a.opt) && a.ustg) {
             if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16, false, 0, true>, a, st, 1, Team::BNT, false);
             if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, F16, false, 0, true>, a, st, 1, Team::BNT, false);
             return launch_k(sdempc_solve_kernel<Team, 8, F16, false, 0, true>, a, st, 1, Team::BNT, false);
@@ -877,11 +868,10 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
     if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, F16>, a, st, Team::IPB);
     return launch_k(sdempc_solve_kernel<Team, 8, F16>, a, st, Team::IPB);
 }
-// Single-particle lane layout: exact f32 arithmetic only, one wave per instance (SDEMPC_LANE=0 forces the tile layout: A/B, tests)
+// Single-particle lane layout: exact f32 arithmetic only, one wave per instance (SDEMPC_OPT_LANE = 0 forces the tile layout: A/B, tests)
 static bool use_lane(const KArgs& k) {
     if (FAST || k.f16 || k.P != 1 || !use_wave_team(k.G, k.H, k.m)) return false;
-    const char* force = getenv("SDEMPC_LANE");
-    return !(force && force[0] == '0');
+    return k.opt.lane != 0;
 }
 #if SDEMPC_FAST
 static hipError_t launch_lane_m(int, const KArgs&, hipStream_t) { return hipErrorInvalidValue; }   // never selected (use_lane)
@@ -901,41 +891,33 @@ static hipError_t launch_lane_m(int what, const KArgs& k, hipStream_t st) {
 #if !SDEMPC_FAST
 // ---- cooperative latency path (exact arithmetic only) ----
 int coop_nwg(int P) { return (P + 3) / 4; }
-int coop_max_instances(int P, int H, int m) {
-    const char* force = getenv("SDEMPC_COOP");                  // "0" disables the path (A/B, tests; read per launch)
-    if ((force && force[0] == '0') || P < 2) return 0;
+int coop_max_instances(int P, int H, int m, const LaunchOpts& o) {
+    if (!o.coop || P < 2 || o.cus < 16) return 0;               // SDEMPC_OPT_COOP = 0 disables the path (A/B, tests)
     if (smem_bytes(H, m, 1, true) > 160 * 1024) return 0;
     // every workgroup of the grid must be resident at once: the kernel is built for two waves per SIMD, i.e. two workgroups per CU
     // (its LDS footprint allows more); a margin of 16 workgroups is left
-    return (2 * device_cus() - 16) / coop_nwg(P);
+    return (2 * o.cus - 16) / coop_nwg(P);
 }
 // per-instance workspace, sized for the speculative variant (7 output slots, 3 checkpoint regions); the plain cooperative kernel
 // uses a prefix of it
 size_t coop_pp_floats(int H, int G) { return (size_t)2 * SPEC_SLOTS * part_stride(H) * G * 32 + 2 * (size_t)part_stride(H); }
 size_t coop_ck_floats(int H, int P) { return (size_t)SPEC_CKS * P * (H + 1) * COOP_ROW; }
-int spec_max_instances(int P, int H, int m) {
-    const char* force = getenv("SDEMPC_SPEC");                  // "0" disables the speculative variant (A/B, tests; read per launch)
-    const char* fc = getenv("SDEMPC_COOP");
-    if ((force && force[0] == '0') || (fc && fc[0] == '0')) return 0;      // P == 1 is welcome here (one wave per workgroup is active)
+int spec_max_instances(int P, int H, int m, const LaunchOpts& o) {
+    if (!o.spec || !o.coop) return 0;      // SDEMPC_OPT_SPEC / SDEMPC_OPT_COOP = 0; P == 1 is welcome here (one wave per workgroup is active)
     const size_t nv = (size_t)((H * m + 3) & ~3);
     if (smem_bytes(H, m, 1, true) + (SPEC_XV * nv + SPEC_MRED) * sizeof(float) > 160 * 1024) return 0;
-    return device_cus() / (2 * coop_nwg(P));                    // built for one workgroup per CU; at least two groups per instance
+    return o.cus / (2 * coop_nwg(P));                    // built for one workgroup per CU; at least two groups per instance
 }
-// polls of one grid barrier before it gives up and raises the instance's error flag: several seconds by default; SDEMPC_COOP_SPIN
-// (read per launch) lets the tests provoke the timeout
-static unsigned coop_spin_limit() {
-    const char* e = getenv("SDEMPC_COOP_SPIN");
-    return e ? (unsigned)strtoul(e, nullptr, 10) : 8u * 1000u * 1000u;
-}
+// KArgs::coop_spin (how long one grid barrier may wait before it gives up and raises the instance's error flag) is set by the C ABI
+// from the handle's spin budget: sdempc_api.cpp, SDEMPC_OPT_COOP_SPIN_US.
 // All workgroups of a cooperative-layout grid must be resident at once. Default: a plain launch of a grid sized to fit
-// (coop_max_instances / spec_max_instances) with every barrier bounded (sdempc_coop.inc.h). SDEMPC_COOP_LAUNCH=1 goes through
+// (coop_max_instances / spec_max_instances) with every barrier bounded (sdempc_coop.inc.h). SDEMPC_OPT_COOP_LAUNCH = 1 goes through
 // hipLaunchCooperativeKernel instead: the runtime validates the grid against the kernel's occupancy and schedules it as a unit —
 // same latency and same results on MI355X (all parity tests), but a process that used it crashes at exit under rocprofv3
 // (ROCm 7.2: SIGSEGV in the exit handlers after the profile is written), so it is opt-in.
 template <class K>
 static hipError_t launch_resident(K kern, dim3 grid, dim3 block, size_t sb, hipStream_t st, const KArgs& k) {
-    const char* e = getenv("SDEMPC_COOP_LAUNCH");
-    if (e && e[0] == '1') {
+    if (k.opt.coop_launch == 1) {
         KArgs kk = k;
         void* args[] = {(void*)&kk};
         const hipError_t rc = hipLaunchCooperativeKernel((const void*)kern, grid, block, args, (unsigned)sb, st);
@@ -956,9 +938,8 @@ static hipError_t launch_spec_m(const KArgs& k, hipStream_t st) {
 }
 hipError_t launch_solve_spec(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B; k.coop_nwg = coop_nwg(k.P);
-    if (B < 1 || B > spec_max_instances(k.P, k.H, k.m) || !k.coop_bar || !k.coop_pp || !k.coop_ck) return hipErrorInvalidValue;
-    k.coop_ngrp = device_cus() / (B * k.coop_nwg);
-    k.coop_spin = coop_spin_limit();
+    if (B < 1 || B > (spec_max_instances)(k.P, k.H, k.m, k.opt) || !k.coop_bar || !k.coop_pp || !k.coop_ck) return hipErrorInvalidValue;
+    k.coop_ngrp = k.opt.cus / (B * k.coop_nwg);
     if (k.coop_ngrp > SPEC_GROUPS) k.coop_ngrp = SPEC_GROUPS;
     if (k.m == 4) return launch_spec_m<4>(k, st);
     if (k.m == 6) return launch_spec_m<6>(k, st);
@@ -967,7 +948,7 @@ hipError_t launch_solve_spec(const KArgs& a, int B, hipStream_t st) {
 template <int M>
 static hipError_t launch_coop_m(const KArgs& k, hipStream_t st) {
     const size_t sb = smem_bytes(k.H, k.m, 1, true);
-    if (k.B * k.coop_nwg <= device_cus()) {      // one workgroup per CU: the 512-register build (no scratch spills in the sweeps)
+    if (k.B * k.coop_nwg <= k.opt.cus) {      // one workgroup per CU: the 512-register build (no scratch spills in the sweeps)
         auto kern = sdempc_solve_kernel<TeamBlock, M, false, true, 2>;
         hipError_t e = set_smem_attr((const void*)kern, sb);
         if (e != hipSuccess) return e;
@@ -980,8 +961,7 @@ static hipError_t launch_coop_m(const KArgs& k, hipStream_t st) {
 }
 hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B; k.coop_nwg = coop_nwg(k.P);
-    if (B < 1 || B > coop_max_instances(k.P, k.H, k.m) || !k.coop_bar || !k.coop_pp || !k.coop_ck) return hipErrorInvalidValue;
-    k.coop_spin = coop_spin_limit();
+    if (B < 1 || B > (coop_max_instances)(k.P, k.H, k.m, k.opt) || !k.coop_bar || !k.coop_pp || !k.coop_ck) return hipErrorInvalidValue;
     if (k.m == 4) return launch_coop_m<4>(k, st);
     if (k.m == 6) return launch_coop_m<6>(k, st);
     return launch_coop_m<8>(k, st);
@@ -1064,11 +1044,11 @@ hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) { return exact:
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st) { return exact::launch_grad(a, B, st); }
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st) { return exact::launch_solve(a, B, st); }
 int coop_nwg(int P) { return exact::coop_nwg(P); }
-int coop_max_instances(int P, int H, int m) { return exact::coop_max_instances(P, H, m); }
+int coop_max_instances(int P, int H, int m, const LaunchOpts& o) { return exact::coop_max_instances(P, H, m, o); }
 size_t coop_pp_floats(int H, int G) { return exact::coop_pp_floats(H, G); }
 size_t coop_ck_floats(int H, int P) { return exact::coop_ck_floats(H, P); }
 hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st) { return exact::launch_solve_coop(a, B, st); }
-int spec_max_instances(int P, int H, int m) { return exact::spec_max_instances(P, H, m); }
+int spec_max_instances(int P, int H, int m, const LaunchOpts& o) { return exact::spec_max_instances(P, H, m, o); }
 hipError_t launch_solve_spec(const KArgs& a, int B, hipStream_t st) { return exact::launch_solve_spec(a, B, st); }
 hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int P, int G, int C, hipStream_t st) {
     return exact::launch_relayout(to_dev, in, out, B, P, G, C, st);

@@ -198,19 +198,15 @@ struct LaneIO {
     float* out; int os;       // per-particle outputs: quantity q at out[q*os]  (q: t*12+k adjoint sums, t*13+i states, PS-1 cost)
     bool add0;                // P == 1: store v + 0.0f (what the SPEC.md §6.1 butterfly over 31 zero lanes leaves)
 };
-// Cooperative path: the handed-off values are written and read with agent-scope (sc1) accesses, so the grid barrier needs no
-// L2 write-back / invalidate (the per-XCD L2s are not coherent with each other; a release fence would flush every dirty line of
-// the checkpoint stream as well). SDEMPC_COOP_FENCE=1 builds the fence-based variant instead (A/B).
-#ifndef SDEMPC_COOP_FENCE
-#define SDEMPC_COOP_FENCE 0
-#endif
+// Cooperative path: the handed-off values are always written and read with agent-scope (sc1) accesses — write-through stores that
+// do not stay dirty in the XCD's L2, loads that bypass the CU's L1 — so the grid barrier needs no L2 write-back / invalidate (the
+// per-XCD L2s are not coherent with each other; a release fence would flush every dirty line of the checkpoint stream as well).
+// See coop_barrier for the ordering argument and the optional fences.
 DI void out_store(const LaneIO& io, size_t q, float v) {
     if (io.add0) io.out[q] = v + 0.0f;                 // P == 1 team (os == 1)
-    else if (SDEMPC_COOP_FENCE) io.out[q * io.os] = v;
     else __hip_atomic_store(io.out + q * io.os, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 DI float coop_load(const float* p) {
-    if (SDEMPC_COOP_FENCE) return *p;
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -7,6 +7,7 @@ run unmodified apart from its import lines:
 
 Nothing is traced or compiled here: the solver callables already dispatch to pre-built HIP kernels.
 Keys follow JAX's threefry2x32 conventions (prng.py; pinned by public known-answer values)."""
+import logging
 import os
 
 import numpy as np
@@ -14,21 +15,34 @@ import numpy as np
 from . import prng as _prng
 
 
+_log = logging.getLogger("sde4mbrl_px4_amd")
+
+
 class _Compiled:
-    """What `.lower(...).compile()` returns. With SDEMPC_PREFORK=shape in the environment, calls made by the process that
-    "compiled" the callable are treated as the reference's pre-fork warm-up / shape probes (sde_control.py:706,717): they are
-    answered by the callable's `shape_probe` (no HIP call, outputs of the right shapes only); calls from any other process
-    (the forked `mpc_process`, sde_control.py:723-728) run the real solver. Without the variable every call is real."""
+    """What `.lower(...).compile()` returns.
+
+    The reference builds its solvers in the parent and runs each compiled callable ONCE there, before it forks the worker — to warm
+    it up and to learn the output shapes (sde_control.py:706-707, :717-719; the fork is :723-728). A real solve at that point would
+    initialise HIP in the parent, and HIP state does not survive fork(). So the FIRST call of a compiled callable, when it is made by
+    the process that compiled it, is answered by the callable's `shape_probe_*` twin: outputs of the right shapes and dtypes, no GPU
+    work (logged once). Every later call — in the forked `mpc_process`, or in the same process for in-process users — runs the real
+    solver. SDEMPC_PREFORK=solve switches the probe off (every call is real: only for parents that never fork)."""
 
     def __init__(self, f):
         self._f = f
         self._pid = os.getpid()
+        self._calls_here = 0
 
     def __call__(self, *a, **k):
-        if os.environ.get("SDEMPC_PREFORK") == "shape" and os.getpid() == self._pid:
-            probe = getattr(getattr(self._f, "__self__", None), "shape_probe_" + getattr(self._f, "__name__", ""), None)
-            if probe is not None:
-                return probe(*a, **k)
+        if os.getpid() == self._pid:
+            self._calls_here += 1
+            if self._calls_here == 1 and os.environ.get("SDEMPC_PREFORK", "shape") != "solve":
+                name = getattr(self._f, "__name__", "")
+                probe = getattr(getattr(self._f, "__self__", None), "shape_probe_" + name, None)
+                if probe is not None:
+                    _log.info("%s: first call in the compiling process answered by the shape probe (no GPU work; SDEMPC_PREFORK=solve "
+                              "makes it a real solve)", name)
+                    return probe(*a, **k)
         return self._f(*a, **k)
 
 

@@ -10,11 +10,20 @@ with the call signatures the reference node uses:
 Returned arrays are numpy arrays wrapped so that `.block_until_ready()` exists (sde_control.py:420,707,718).
 opt_state exposes yk and the seven telemetry scalars read at sde_control.py:444-450,646-647.
 
+Frame contract (SPEC.md §1a). The node hands over the vehicle state `x` as it arrives in the MPC_FULL_STATE message, documented as
+NED (sde_control.py:228-232,246), while every target it builds is ENU: the position set-point (:186-192), `state_from_traj` (:206,
+trajectory CSVs are ENU), and the hold target `enu2ned(curr_state, np)` (:400), i.e. the NED state flipped to ENU. The factory is
+called with `convert_to_enu=True` (:685): the solver converts `x` itself. So, with convert_to_enu=True, m_mpc maps x -> enu2ned(x)
+(the flip is an involution), solves in ENU / FLU (the frame of SPEC.md §5), takes `xdes` / `state_from_traj` as ENU, and returns
+`xevol` flipped back to the frame of `x` (its body rates, rows 10..12, go to the FCU: sde_control.py:432). `uopt` is frame-free.
+With convert_to_enu=False nothing is converted: x, xdes and the trajectory are taken to be in the solver's frame already.
+
 The solve itself runs in the HIP kernels behind include/sdempc.h; this module is host glue only.
 """
 from __future__ import annotations
 
 import os
+import warnings
 from dataclasses import dataclass, field
 from typing import Callable, NamedTuple, Optional
 
@@ -23,7 +32,7 @@ import numpy as np
 from . import prng, workload
 from .config import MPCConfig, load_mpc_config
 from .model import RotorSDEModel, synthetic_hexa, synthetic_iris
-from .utils import TrajectoryCSV
+from .utils import TrajectoryCSV, enu2ned
 
 
 class DeviceArray(np.ndarray):
@@ -64,13 +73,26 @@ class MpcProblem:
     model: RotorSDEModel
     state_from_traj: Optional[Callable] = None
     shift_warm_start: bool = True
+    convert_to_enu: bool = True           # sde_control.py:685; see the frame contract in the module docstring
     _solver: object = field(default=None, repr=False)
     _pid: int = field(default=-1, repr=False)
 
     def solver(self):
-        # HIP contexts do not survive fork(): the reference builds its solvers in the parent and uses
-        # them in the forked mpc_process (sde_control.py:69-75,723-728); (re)create per process.
-        if self._solver is None or self._pid != os.getpid():
+        # HIP contexts do not survive fork(): the reference builds its solvers in the parent and uses them in the forked mpc_process
+        # (sde_control.py:69-75,723-728), so the handle is (re)created per process. A handle inherited through fork() is never
+        # touched again: no HIP call may run on the parent's context in the child, not even the frees of sdempc_destroy, so it is
+        # detached (leaked). If the parent had already initialised the GPU through it (a real solve before the fork) the child's HIP
+        # runtime is unusable: fail loudly instead of hanging inside the control process.
+        if self._solver is not None and self._pid != os.getpid():
+            inherited, self._solver = self._solver, None
+            was_ready = inherited.device_ready()
+            inherited.detach()
+            if was_ready:
+                raise RuntimeError(
+                    "sde4mbrl_px4_amd: this process was forked after its parent had already run a solve on the GPU (HIP state does "
+                    "not survive fork()). Keep real solver calls out of the parent: the first call of each compiled callable there is "
+                    "answered by a shape probe (jax_shim, SDEMPC_PREFORK), or start the worker with the 'spawn' method.")
+        if self._solver is None:
             from .solver import SdeMpcSolver
             self._solver = SdeMpcSolver(self.cfg, self.model, max_batch=1)
             self._pid = os.getpid()
@@ -97,11 +119,14 @@ class MpcProblem:
 
     def m_mpc(self, x, rng, opt_state: OptState, curr_t=0.0, xdes=None):
         x = np.asarray(x, np.float32).reshape(13)
-        xdes = x if xdes is None else np.asarray(xdes, np.float32).reshape(13)
+        xs = enu2ned(x, np) if self.convert_to_enu else x           # vehicle state in the solver's frame (module docstring)
+        xdes = xs if xdes is None else np.asarray(xdes, np.float32).reshape(13)
         new_rng, sub = _next_key(rng)
         xref = self.xref(float(curr_t), xdes)[None]
         u0 = np.asarray(opt_state.yk, np.float32)[None]
-        uopt, xevol, info = self.solver().solve_keys(x[None], xref, sub[None], u0, np.array([opt_state.stepsize], np.float32))
+        uopt, xevol, info = self.solver().solve_keys(xs[None], xref, sub[None], u0, np.array([opt_state.stepsize], np.float32))
+        if self.convert_to_enu:                                     # predicted states back in the frame of x
+            xevol = np.stack([enu2ned(r, np) for r in xevol[0]])[None]
         uo = uopt[0]
         yk = np.concatenate([uo[1:], uo[-1:]], axis=0) if self.shift_warm_start else uo
         i = info[0]
@@ -110,18 +135,30 @@ class MpcProblem:
         return _arr(uo), st, new_rng, _arr(xevol[0])
 
 
-def _pick_model(cfg: MPCConfig, model) -> RotorSDEModel:
+def _allow_synthetic(flag) -> bool:
+    return bool(flag) if flag is not None else os.environ.get("SDEMPC_ALLOW_SYNTHETIC") == "1"
+
+
+def _pick_model(cfg: MPCConfig, model, allow_synthetic=None) -> RotorSDEModel:
+    """The vehicle model: `model` if given; else what `learned_model_params` names (iris_sitl_traj_mpc.yaml:3). A configured file that
+    cannot be honoured raises — the synthetic vehicle replaces it only on request (allow_synthetic=True / SDEMPC_ALLOW_SYNTHETIC=1),
+    and never silently."""
     if model is not None:
         return model
     lm = os.path.expanduser(cfg.learned_model_params) if cfg.learned_model_params else None
-    if lm and lm.endswith(".npz") and os.path.exists(lm):
+    why = None
+    if lm is None:
+        why = "the MPC YAML names no learned_model_params"
+    elif not os.path.exists(lm):
+        why = f"learned_model_params '{lm}' does not exist (the reference's pickles live in the external sde4mbrl repository)"
+    elif lm.endswith(".npz"):
         m = RotorSDEModel.load_npz(lm)
         if m.num_motors != cfg.num_motors:
             raise ValueError(f"{lm}: model has {m.num_motors} motors, config has {cfg.num_motors}")
         return m
-    if lm and lm.endswith(".pkl") and os.path.exists(lm):
-        # a pickle of the external sde4mbrl repo (iris_sitl_traj_mpc.yaml:3): its layout is not in the reference, so it is read
-        # only when the user states the layout in <name>.mapping.yaml beside it (importer.py)
+    elif lm.endswith(".pkl"):
+        # a pickle of the external sde4mbrl repo: its layout is not in the reference, so it is read only when the user states the
+        # layout in <name>.mapping.yaml beside it (importer.py, SURVEY.md §8f N3)
         mp = lm[:-4] + ".mapping.yaml"
         if os.path.exists(mp):
             from .importer import import_sde_pickle
@@ -129,12 +166,19 @@ def _pick_model(cfg: MPCConfig, model) -> RotorSDEModel:
             if mdl.num_motors != cfg.num_motors:
                 raise ValueError(f"{lm}: model has {mdl.num_motors} motors, config has {cfg.num_motors}")
             return mdl
-    # otherwise: this build's synthetic vehicles
+        why = f"'{lm}' is a pickle without a layout description '{mp}' (importer.py)"
+    else:
+        why = f"learned_model_params '{lm}': unknown file type (expected .npz, or .pkl with a .mapping.yaml)"
+    if lm is not None and not _allow_synthetic(allow_synthetic):
+        raise FileNotFoundError(f"sde4mbrl_px4_amd: {why}. Pass model=..., fix the path, or opt in to the synthetic stand-in vehicle "
+                                "with allow_synthetic=True / SDEMPC_ALLOW_SYNTHETIC=1.")
+    warnings.warn(f"sde4mbrl_px4_amd: {why}: using this build's SYNTHETIC {'iris' if cfg.num_motors == 4 else 'hexa'} vehicle "
+                  "(model.py; random residual weights, not a learned model)", stacklevel=3)
     return synthetic_iris() if cfg.num_motors == 4 else synthetic_hexa()
 
 
 def load_mpc_problem(mpc_dir: str, convert_to_enu: bool = True, model=None, horizon=None, num_particles=None,
-                     trajectory=None, overrides=None) -> MpcProblem:
+                     trajectory=None, overrides=None, allow_synthetic=None) -> MpcProblem:
     cfg = load_mpc_config(mpc_dir)
     over = dict(overrides or {})
     if horizon is not None:
@@ -150,10 +194,14 @@ def load_mpc_problem(mpc_dir: str, convert_to_enu: bool = True, model=None, hori
         path = os.path.expanduser(cfg.trajectory_path)
         if os.path.exists(path):
             sft = TrajectoryCSV(path, ned=not convert_to_enu)
-        else:
-            # the shipped YAMLs point at CSVs of the external repo; fall back to the analytic lemniscate
+        elif _allow_synthetic(allow_synthetic):
+            # the shipped YAMLs point at CSVs of the external repo: analytic lemniscate instead, on request only
+            warnings.warn(f"sde4mbrl_px4_amd: trajectory_path '{path}' does not exist: using the analytic lemniscate stand-in", stacklevel=2)
             sft = workload.lemniscate_state
-    return MpcProblem(cfg=cfg, model=_pick_model(cfg, model), state_from_traj=sft)
+        else:
+            raise FileNotFoundError(f"sde4mbrl_px4_amd: trajectory_path '{path}' does not exist. Pass trajectory=..., fix the path, or opt "
+                                    "in to the analytic lemniscate with allow_synthetic=True / SDEMPC_ALLOW_SYNTHETIC=1.")
+    return MpcProblem(cfg=cfg, model=_pick_model(cfg, model, allow_synthetic), state_from_traj=sft, convert_to_enu=bool(convert_to_enu))
 
 
 def load_mpc_from_cfgfile(mpc_dir: str, convert_to_enu: bool = True, **kw):

@@ -32,7 +32,7 @@ class SdeMpcSolver:
     """One solver handle = one (MPC config, model). Single-threaded, like the reference's solver
     objects (one blocking call at a time, sde_control.py:420)."""
 
-    def __init__(self, mpc_cfg, model, max_batch: int = 1, device: int = 0):
+    def __init__(self, mpc_cfg, model, max_batch: int = 1, device: int = 0, options=None):
         self.lib = _abi.load_library()
         self.cfg_py = mpc_cfg
         self.cfg, self._keep = mpc_cfg.to_cfg()
@@ -47,11 +47,31 @@ class SdeMpcSolver:
         self._h = h
         if device:
             self._check(self.lib.sdempc_set_device(self._h, int(device)))
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    # ---- execution options (include/sdempc.h SDEMPC_OPT_*): layout choices, never a bit of the results ----
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.sdempc_set_option(self._h, _abi.OPTIONS[name], int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int32()
+        self._check(self.lib.sdempc_get_option(self._h, _abi.OPTIONS[name], C.byref(v)))
+        return int(v.value)
 
     def close(self):
         if getattr(self, "_h", None):
             self.lib.sdempc_destroy(self._h)
             self._h = None
+
+    def detach(self):
+        """Forget the handle WITHOUT destroying it: for a handle inherited through fork(), whose HIP objects belong to the parent's
+        context (sdempc_destroy would call hipFree / hipStreamDestroy on it). The few host bytes are leaked on purpose."""
+        self._h = None
+
+    def device_ready(self) -> bool:
+        """Has this handle initialised the GPU (device buffers, stream)? Host-only query."""
+        return bool(getattr(self, "_h", None)) and bool(self.lib.sdempc_device_ready(self._h))
 
     def __del__(self):
         try:

@@ -12,6 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORC_DIR = os.path.join(ROOT, "oracle")
 _LIB = None
+_LIB_FAST = None
 
 
 def build():
@@ -21,6 +22,27 @@ def build():
     if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(["make", "-C", ORC_DIR, "-s"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return so
+
+
+def lib_fast():
+    """-O3 -march=native build of the same source (oracle/Makefile: liborc_fast.so), for bench.py's CPU timing leg only. Rebuilt when
+    missing, stale, or built for another CPU model (the GPU box's host is not the build container's)."""
+    global _LIB_FAST
+    if _LIB_FAST is None:
+        so = os.path.join(ORC_DIR, "liborc_fast.so")
+        src = os.path.join(ORC_DIR, "sde_mpc_oracle.c")
+        tag = os.path.join(ORC_DIR, "liborc_fast.cpu")
+        try:
+            here = next(l for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except Exception:
+            here = ""
+        stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src) or (not os.path.exists(tag)) or open(tag).read() != here
+        if stale:
+            if os.path.exists(so):
+                os.remove(so)
+            subprocess.check_call(["make", "-C", ORC_DIR, "-s", "liborc_fast.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _LIB_FAST = C.CDLL(so)
+    return _LIB_FAST
 
 
 def lib():
@@ -87,16 +109,17 @@ def _f32(a):
 class Oracle:
     """Oracle bound to one (config, model blob). double=True selects the float64 build."""
 
-    def __init__(self, mpc_cfg, model, double=False):
+    def __init__(self, mpc_cfg, model, double=False, fast=False):
         self.cfg_py = mpc_cfg
         self.cfg, self._keep = mpc_cfg.to_cfg()
         self.blob = model.to_blob() if hasattr(model, "to_blob") else bytes(model)
         self._blobbuf = C.create_string_buffer(self.blob, len(self.blob))
         self.pre = "orcd_" if double else "orc_"
+        self._lib = lib_fast() if fast else lib()
         self.H, self.P, self.m = mpc_cfg.horizon, mpc_cfg.num_particles, mpc_cfg.num_motors
 
     def _fn(self, name):
-        return getattr(lib(), self.pre + name)
+        return getattr(self._lib, self.pre + name)
 
     def rollout(self, x0, u, xref, noise, want_traj=False, want_mean=False):
         H, P = self.H, self.P

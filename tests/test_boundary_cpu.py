@@ -6,6 +6,7 @@ import pytest
 
 from cases import CDIR
 from sde4mbrl_px4_amd import jax_shim
+from sde4mbrl_px4_amd import synthetic_iris
 from sde4mbrl_px4_amd.sde_mpc_design import OptState, load_mpc_from_cfgfile
 from sde4mbrl_px4_amd.utils import TrajectoryCSV, enu2ned
 from sde4mbrl_px4_amd.worker import CONTROL_STATE, SharedBlocks, select_command
@@ -74,9 +75,12 @@ def test_jax_facade_matches_call_patterns():
 
 
 def test_prefork_shape_probe_touches_no_device(monkeypatch):
-    """load_single_mpc's warm-up calls (sde_control.py:706,717) under SDEMPC_PREFORK=shape: right shapes, no solver created."""
-    monkeypatch.setenv("SDEMPC_PREFORK", "shape")
-    cfg_dict, (m_reset, m_mpc), _, _ = load_mpc_from_cfgfile(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"))
+    """load_single_mpc's warm-up calls (sde_control.py:706,717): the FIRST call of each compiled callable in the compiling process is a
+    shape probe (right shapes, no solver created) by default; the next call in the same process is a real solve (in-process users), which
+    on this GPU-less machine fails loudly inside the C ABI; SDEMPC_PREFORK=solve makes even the first call real."""
+    from sde4mbrl_px4_amd.solver import SdempcError
+    monkeypatch.delenv("SDEMPC_PREFORK", raising=False)
+    cfg_dict, (m_reset, m_mpc), _, _ = load_mpc_from_cfgfile(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"), model=synthetic_iris())
     prob = cfg_dict["_problem"]
     x0 = HOVER.copy()
     rng = jax_shim.random.PRNGKey(10)
@@ -88,6 +92,122 @@ def test_prefork_shape_probe_touches_no_device(monkeypatch):
     uopt.block_until_ready()
     assert np.array(uopt).shape == (20, 4) and xevol.shape == (21, 13) and st2 is st
     assert prob._solver is None                                           # nothing touched the GPU library
+    if not _has_gpu():
+        with pytest.raises(SdempcError, match="no HIP device|HIP"):      # second call: the real path, no CPU fallback
+            mpc_c(x0, rng, st, curr_t=0.01, xdes=x0)
+        assert prob._solver is not None and not prob._solver.device_ready()
+        monkeypatch.setenv("SDEMPC_PREFORK", "solve")
+        mpc_d = jax_shim.jit(m_mpc).lower(x0, rng, st, curr_t=0.01, xdes=x0).compile()
+        with pytest.raises(SdempcError):
+            mpc_d(x0, rng, st, curr_t=0.01, xdes=x0)
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_inherited_handle_is_detached_not_destroyed_after_fork():
+    """A solver handle created in the parent and never used on the GPU is dropped without sdempc_destroy in a forked child (no HIP call on
+    the parent's context); a fresh one is created there (sde_control.py:69-75,723-728)."""
+    import multiprocessing as mp
+    cfg_dict, _, _, _ = load_mpc_from_cfgfile(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"), model=synthetic_iris())
+    prob = cfg_dict["_problem"]
+    parent = prob.solver()
+    assert not parent.device_ready()
+
+    def child(q):
+        s = prob.solver()
+        q.put((s is not parent, parent._h is None, s.device_ready()))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=child, args=(q,))
+    p.start()
+    fresh, detached, ready = q.get(timeout=60)
+    p.join(30)
+    assert fresh and detached and not ready and p.exitcode == 0
+    assert prob.solver() is parent and parent._h is not None             # the parent keeps its own handle
+
+
+def test_unavailable_model_or_trajectory_is_an_error_not_a_silent_stand_in(tmp_path, monkeypatch):
+    """Every MPC YAML the reference ships points at files of the external sde4mbrl repository (iris_sitl_traj_mpc.yaml:3,6). A configured
+    path that cannot be honoured raises; the synthetic vehicle / analytic lemniscate replace it only on request, with a warning."""
+    import shutil
+    monkeypatch.delenv("SDEMPC_ALLOW_SYNTHETIC", raising=False)
+    ref_yaml = "/root/reference/launch/iris_sitl_traj_mpc.yaml"
+    y = tmp_path / "traj_mpc.yaml"
+    if os.path.exists(ref_yaml):
+        shutil.copy(ref_yaml, y)
+    else:   # GPU box: no reference tree; same two keys on top of this repo's C2 file
+        y.write_text("learned_model_params: ~/nowhere/iris_sitl_sde.pkl\ntrajectory_path: ~/nowhere/fast2_lemn.csv\n"
+                     + open(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).read())
+    with pytest.raises(FileNotFoundError, match="trajectory_path|learned_model_params"):
+        load_mpc_from_cfgfile(str(y))
+    with pytest.raises(FileNotFoundError, match="learned_model_params"):
+        load_mpc_from_cfgfile(str(y), trajectory=lemniscate_state)
+    with pytest.warns(UserWarning, match="SYNTHETIC"):
+        cfg_dict, _, sft, _ = load_mpc_from_cfgfile(str(y), allow_synthetic=True)
+    assert sft is not None and cfg_dict["_problem"].model.num_motors == 4
+    monkeypatch.setenv("SDEMPC_ALLOW_SYNTHETIC", "1")
+    with pytest.warns(UserWarning):
+        load_mpc_from_cfgfile(str(y))
+    cfg_dict, _, _, _ = load_mpc_from_cfgfile(str(y), model=synthetic_iris(), trajectory=lemniscate_state)   # explicit: no warning needed
+    assert cfg_dict["_problem"].convert_to_enu is True
+
+
+def test_frame_contract_hold_target_equals_solver_state():
+    """SPEC.md §1a: x arrives NED, targets are ENU, convert_to_enu=True flips x. In hold mode the node passes xdes = enu2ned(x)
+    (sde_control.py:400): the reference window then starts exactly at the solver's initial state (zero error at t0)."""
+    from sde4mbrl_px4_amd.utils import enu2ned
+    from sde4mbrl_px4_amd.workload import random_initial_states
+    cfg_dict, _, _, _ = load_mpc_from_cfgfile(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"), model=synthetic_iris())
+    prob = cfg_dict["_problem"]
+    x_ned = random_initial_states(1, 7)[0]
+    xdes = enu2ned(x_ned, np)
+    xs = enu2ned(x_ned, np) if prob.convert_to_enu else x_ned
+    xref = prob.xref(0.0, xdes)
+    assert xref.shape == (21, 13) and np.array_equal(xref[0], xs) and np.array_equal(xref[-1], xs)
+    assert not np.array_equal(xs[:3], x_ned[:3])                                       # the flip is not the identity
+    np.testing.assert_allclose(enu2ned(xs, np), x_ned, atol=2e-7)                      # involution up to rounding
+    assert xs[2] == -x_ned[2] and xs[0] == x_ned[1] and xs[11] == -x_ned[11]
+
+
+def test_handle_options_host_side():
+    """sdempc_set_option / sdempc_get_option (include/sdempc.h): defaults, environment defaults read at create, validation; host-only."""
+    from sde4mbrl_px4_amd import load_mpc_config
+    from sde4mbrl_px4_amd.solver import SdeMpcSolver, SdempcError
+    cfg = load_mpc_config(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"))
+    for k in ("SDEMPC_LANE", "SDEMPC_COOP", "SDEMPC_SPEC", "SDEMPC_PK", "SDEMPC_USTG", "SDEMPC_COOP_LAUNCH", "SDEMPC_COOP_FENCE", "SDEMPC_COOP_SPIN_US"):
+        os.environ.pop(k, None)
+    S = SdeMpcSolver(cfg, synthetic_iris(), max_batch=2)
+    assert [S.get_option(k) for k in ("lane", "coop", "spec", "pk", "ustg", "coop_launch", "coop_fence")] == [1, 1, 1, -1, -1, 0, 0]
+    assert S.get_option("coop_spin_us") == 100_000                       # derived budget before the first cooperative solve: 100 ms
+    S.set_option("coop_spin_us", 2500); assert S.get_option("coop_spin_us") == 2500
+    S.set_option("pk", 0); S.set_option("ustg", 1); S.set_option("coop", 0); S.set_option("coop_fence", 1)
+    assert (S.get_option("pk"), S.get_option("ustg"), S.get_option("coop"), S.get_option("coop_fence")) == (0, 1, 0, 1)
+    for key, bad in (("lane", 2), ("pk", 3), ("coop_spin_us", -2), ("spec", -1)):
+        with pytest.raises(SdempcError):
+            S.set_option(key, bad)
+    with pytest.raises(SdempcError):
+        S._check(S.lib.sdempc_set_option(S._h, 99, 0))
+    assert not S.device_ready()
+    S.close()
+    os.environ["SDEMPC_COOP"] = "0"; os.environ["SDEMPC_COOP_SPIN_US"] = "777"
+    try:
+        S = SdeMpcSolver(cfg, synthetic_iris(), max_batch=1)
+        assert S.get_option("coop") == 0 and S.get_option("coop_spin_us") == 777
+        os.environ["SDEMPC_COOP"] = "1"                                  # read once at create: later changes do not reach the handle
+        assert S.get_option("coop") == 0
+        S.close()
+        S = SdeMpcSolver(cfg, synthetic_iris(), max_batch=1, options={"coop": 1})
+        assert S.get_option("coop") == 1
+        S.close()
+    finally:
+        os.environ.pop("SDEMPC_COOP", None); os.environ.pop("SDEMPC_COOP_SPIN_US", None)
 
 
 def test_shared_block_layouts_and_command_selection():

@@ -191,6 +191,10 @@ def test_product_and_tools_never_touch_the_oracle():
                 if pat.search(line) and not line.lstrip().startswith(("#", "//", "*", '"')) and "oracle/prng_oracle.c" not in line:
                     offenders.append(f"{os.path.relpath(f, root)}:{i + 1}: {line.strip()[:100]}")
     assert not offenders, "\n".join(offenders)
-    # bench.py may use it in exactly one function
+    # bench.py may load it in exactly one function, called only by its CPU legs (checker of the timed outputs + cpu_baseline)
     src = open(os.path.join(root, "bench.py")).read()
-    assert src.count("import orc") == 1 and "def cpu_baseline" in src.split("import orc")[0].rsplit("\ndef ", 1)[-1] or "cpu_baseline" in src.split("import orc")[0][-600:]
+    assert src.count("import orc") == 1 and src.split("import orc")[0].rsplit("\ndef ", 1)[-1].startswith("cpu_oracle()")
+    callers = {blk.split("(", 1)[0] for blk in src.split("\ndef ")[1:] if "cpu_oracle()" in blk.split("\n", 1)[1]}
+    assert callers == {"cpu_solve_instances", "cpu_c1_single_solve_ms"}, callers
+    timed = src.split("t0 = time.perf_counter()")[1].split("t1 = time.perf_counter()")[0]
+    assert "cpu_" not in timed and "orc" not in timed

@@ -117,3 +117,27 @@ def test_forked_worker_solves_after_prefork_shape_probe(tmp_path):
     res = json.loads(out.stdout.strip().splitlines()[-1])
     assert res["probe_is_warm_start"] and res["exit"] == 0
     assert res["child"]["shape"] == [20, 4] and res["child"]["num_steps"] == 5 and res["child"]["moved"] and res["child"]["opt"] <= res["child"]["init"]
+
+
+def test_bench_two_ranks_self_started_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: the parent starts both ranks before anything touches the GPU, rank 0's single JSON
+    line comes back, n_gpus == 2. Both ranks share GPU 0 here (SDEMPC_BENCH_DEVICE) and rendezvous over gloo (SDEMPC_BENCH_BACKEND):
+    the one-GPU box has neither a second GPU nor an RCCL peer; the driver's multi-GPU runs use one GPU per rank over RCCL / xGMI."""
+    import json
+    import subprocess
+    import sys
+    from cases import ROOT
+    env = dict(os.environ, SDEMPC_BENCH_DEVICE="0", SDEMPC_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "64",
+                          "--latency-reps", "2", "--latency-warmup", "1", "--no-cpu-baseline", "--verify", "2"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 1 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["instances_per_gpu"] == 64
+    assert rec["verified_instances"] == 2 and rec["verified_bit_exact"] is True
+    assert rec["roofline"]["frac"] > 0 and rec["roofline"]["kernel_ms"] > 0

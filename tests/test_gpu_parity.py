@@ -17,22 +17,24 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4   # north_star tolerance (float32)
 
 
+# execution options every solver of the running test is created with (sdempc_set_option; set by the `layout` fixture)
+LAYOUT_OPTS = {}
+
+
 @pytest.fixture(params=["auto", "coop", "tile"])
 def layout(request, monkeypatch):
     """auto: the library picks (single-particle lanes for P = 1; for small batches the cooperative one-particle-per-wave path, in its
     speculative form when two or more groups of workgroups fit; 32-particle tiles otherwise); coop: the speculative form switched off, which
-    pins the plain cooperative kernel; tile: every alternative off, which pins the tile layout on the same cases. All bit-identical."""
-    if request.param == "coop":
-        monkeypatch.setenv("SDEMPC_SPEC", "0")
-    if request.param == "tile":
-        monkeypatch.setenv("SDEMPC_LANE", "0")
-        monkeypatch.setenv("SDEMPC_COOP", "0")
+    pins the plain cooperative kernel; tile: every alternative off, which pins the tile layout on the same cases. All bit-identical.
+    Selected through the handle's options (include/sdempc.h SDEMPC_OPT_*), not through the environment."""
+    opts = {"auto": {}, "coop": {"spec": 0}, "tile": {"lane": 0, "coop": 0}}[request.param]
+    monkeypatch.setitem(globals(), "LAYOUT_OPTS", opts)
     return request.param
 
 
-def _solver(cfg, model, B):
+def _solver(cfg, model, B, **options):
     from sde4mbrl_px4_amd.solver import SdeMpcSolver
-    return SdeMpcSolver(cfg, model, max_batch=B)
+    return SdeMpcSolver(cfg, model, max_batch=B, options={**LAYOUT_OPTS, **options})
 
 
 def _close(a, b, what):
@@ -507,9 +509,9 @@ def test_single_instance_full_length_solve_bit_exact(cfg_name, iters, layout):
 # ---- cooperative layouts on a GPU they cannot have to themselves: bounded barrier, fallback to the tile layout ----------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("spec", ["1", "0"])
-def test_barrier_timeout_falls_back_to_tile_layout(spec, monkeypatch):
-    """SDEMPC_COOP_SPIN=0 makes every grid barrier give up on its first unsuccessful poll (what happens, after seconds, when the
-    workgroups of a cooperative launch are not all resident). Device API: NaN telemetry + sdempc_solve_status = EDEVICE, and the handle
+def test_barrier_timeout_falls_back_to_tile_layout(spec):
+    """A spin budget of 0 us (SDEMPC_OPT_COOP_SPIN_US) makes every grid barrier give up on its first unsuccessful poll (what happens,
+    after the budget, when the workgroups of a cooperative launch are not all resident). Device API: NaN telemetry + sdempc_solve_status = EDEVICE, and the handle
     leaves the cooperative layouts; host-pointer API: the batch is re-run in the tile layout, results equal the oracle's bit for bit."""
     import torch
     from sde4mbrl_px4_amd.solver import SdempcError
@@ -518,18 +520,18 @@ def test_barrier_timeout_falls_back_to_tile_layout(spec, monkeypatch):
     x0, xref, noise, u = _problem(cfg, B, 5)
     s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
     uo, xo, io = orc.Oracle(cfg, synthetic_iris()).solve_batch(x0, xref, noise, u, s0)
-    monkeypatch.setenv("SDEMPC_SPEC", spec)
-    monkeypatch.setenv("SDEMPC_COOP_SPIN", "0")
+    opts = dict(spec=int(spec), coop_spin_us=0)
     # host-pointer entry point: transparent fallback
-    S = _solver(cfg, synthetic_iris(), B)
+    S = _solver(cfg, synthetic_iris(), B, **opts)
     ug, xg, ig = S.solve(x0, xref, noise, u, s0)
     assert S.layout_fallbacks() == 1
     assert bits_differ(ug, uo) == 0 and bits_differ(xg, xo) == 0 and bits_differ(ig, io) == 0
     ug, xg, ig = S.solve(x0, xref, noise, u, s0)                  # the handle stays on the tile layout: no second timeout
     assert S.layout_fallbacks() == 1 and bits_differ(ug, uo) == 0
+    assert S.get_option("coop") == 0                               # reported as off after the fallback
     S.close()
     # device entry point: the caller asks for the status
-    S = _solver(cfg, synthetic_iris(), B)
+    S = _solver(cfg, synthetic_iris(), B, **opts)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     d = dict(x0=t(x0), xref=t(xref), nd=t(S.noise_to_device_layout(noise)), u=t(u), s=t(s0))
     uopt, xev, info = torch.zeros((B, 12, 4), device="cuda"), torch.zeros((B, 13, 13), device="cuda"), torch.zeros((B, 8), device="cuda")
@@ -549,16 +551,16 @@ def test_barrier_timeout_falls_back_to_tile_layout(spec, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("spec", ["1", "0"])
-def test_runtime_cooperative_launch_bit_exact(spec, monkeypatch):
-    """SDEMPC_COOP_LAUNCH=1: the cooperative layouts launched through hipLaunchCooperativeKernel give the oracle's bits too."""
+@pytest.mark.parametrize("opt", ["coop_launch", "coop_fence"])
+def test_runtime_cooperative_launch_and_fenced_barrier_bit_exact(spec, opt):
+    """SDEMPC_OPT_COOP_LAUNCH: the cooperative layouts launched through hipLaunchCooperativeKernel; SDEMPC_OPT_COOP_FENCE: agent-scope
+    release / acquire fences around every grid barrier. Both give the oracle's bits too."""
     cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(horizon=12, num_short_dt=12, num_particles=72, max_iter=6, max_no_improvement_iter=6)
     B = 2
     x0, xref, noise, u = _problem(cfg, B, 6)
     s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
     uo, xo, io = orc.Oracle(cfg, synthetic_iris()).solve_batch(x0, xref, noise, u, s0)
-    monkeypatch.setenv("SDEMPC_SPEC", spec)
-    monkeypatch.setenv("SDEMPC_COOP_LAUNCH", "1")
-    S = _solver(cfg, synthetic_iris(), B)
+    S = _solver(cfg, synthetic_iris(), B, spec=int(spec), **{opt: 1})
     ug, xg, ig = S.solve(x0, xref, noise, u, s0)
     assert S.layout_fallbacks() == 0
     assert bits_differ(ug, uo) == 0 and bits_differ(xg, xo) == 0 and bits_differ(ig, io) == 0
@@ -568,8 +570,8 @@ def test_runtime_cooperative_launch_bit_exact(spec, monkeypatch):
 # ---- long horizons: the per-step control table of the throughput solve kernel moves from LDS to global memory -------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("H,P,m", [(200, 40, 4), (50, 70, 4), (64, 33, 6), (300, 8, 4)])
-def test_global_control_table_instantiation_bit_exact(H, P, m, monkeypatch):
-    """SDEMPC_USTG=1 + SDEMPC_PK=0 force the instantiation that long-horizon throughput launches pick by themselves (three workgroups per
+def test_global_control_table_instantiation_bit_exact(H, P, m):
+    """SDEMPC_OPT_USTG = 1 + SDEMPC_OPT_PK = 0 force the instantiation that long-horizon throughput launches pick by themselves (three workgroups per
     CU instead of two at C5): same bits as the oracle, and as the LDS-table instantiation."""
     kw = dict(horizon=H, num_short_dt=H, num_particles=P, u_slew_coeff=1.0, max_iter=4, max_no_improvement_iter=4)
     if m == 6:
@@ -580,15 +582,9 @@ def test_global_control_table_instantiation_bit_exact(H, P, m, monkeypatch):
     x0, xref, noise, u = _problem(cfg, B, 9)
     s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
     O = orc.Oracle(cfg, model)
-    monkeypatch.setenv("SDEMPC_COOP", "0")
-    monkeypatch.setenv("SDEMPC_PK", "0")
     res = {}
     for flag in ("1", "0", "auto"):          # auto: H = 200 / 300 choose the global table by themselves (3 instead of 2 / 2 instead of 1 per CU)
-        if flag == "auto":
-            monkeypatch.delenv("SDEMPC_USTG", raising=False)
-        else:
-            monkeypatch.setenv("SDEMPC_USTG", flag)
-        S = _solver(cfg, model, B)
+        S = _solver(cfg, model, B, coop=0, pk=0, ustg={"1": 1, "0": 0, "auto": -1}[flag])
         res[flag] = S.solve(x0, xref, noise, u, s0)
         S.close()
     for b in range(B):

@@ -21,10 +21,8 @@ for name in sys.argv[1:]:
     xref = np.stack([W.reference_window(0.35, cfg.time_steps)])
     key = prng.split(prng.PRNGKey(10), 4)[3:4]
     got = {}
-    for layout, env in (("auto", {}), ("coop", {"SDEMPC_SPEC": "0"}), ("tile", {"SDEMPC_COOP": "0", "SDEMPC_SPEC": "0"})):
-        for k in ("SDEMPC_SPEC", "SDEMPC_COOP"): os.environ.pop(k, None)
-        os.environ.update(env)
-        S = SdeMpcSolver(cfg, model, max_batch=1)
+    for layout, opts in (("auto", {}), ("coop", {"spec": 0}), ("tile", {"coop": 0})):
+        S = SdeMpcSolver(cfg, model, max_batch=1, options=opts)
         yk, i0 = S.reset()
         s0 = np.array([i0["stepsize"]], np.float32)
         t = time.time(); got[layout] = S.solve_keys(x0, xref, key, yk[None], s0); dt = time.time() - t

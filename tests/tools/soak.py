@@ -1,5 +1,5 @@
 """Randomised soak: GPU (C ABI) vs CPU oracle, bit for bit, over many random configurations. Every configuration also draws one of the
-execution layouts / kernel instantiations (environment switches of INTEGRATION.md, read per launch): all must give the same bits."""
+execution layouts / kernel instantiations (handle options of include/sdempc.h, SDEMPC_OPT_*): all must give the same bits."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,9 +11,9 @@ from cases import bits_differ
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0; nonfinite = 0; t0 = time.time()
-LAYOUTS = [("auto", {}), ("coop", {"SDEMPC_SPEC": "0"}), ("coop-rt", {"SDEMPC_COOP_LAUNCH": "1"}), ("tile-pk", {"SDEMPC_COOP": "0", "SDEMPC_PK": "1"}),
-           ("tile", {"SDEMPC_COOP": "0", "SDEMPC_PK": "0"}), ("tile-gtab", {"SDEMPC_COOP": "0", "SDEMPC_PK": "0", "SDEMPC_USTG": "1"}),
-           ("tile-nolane", {"SDEMPC_COOP": "0", "SDEMPC_LANE": "0", "SDEMPC_PK": "0"})]
+LAYOUTS = [("auto", {}), ("coop", {"spec": 0}), ("coop-rt", {"coop_launch": 1}), ("auto-fence", {"coop_fence": 1}), ("coop-fence", {"spec": 0, "coop_fence": 1}),
+           ("tile-pk", {"coop": 0, "pk": 1}), ("tile", {"coop": 0, "pk": 0}), ("tile-gtab", {"coop": 0, "pk": 0, "ustg": 1}),
+           ("tile-nolane", {"coop": 0, "lane": 0, "pk": 0})]
 used = {}
 for it in range(n):
     rng = np.random.default_rng(seed0 + it)
@@ -29,13 +29,12 @@ for it in range(n):
     if rng.random() < 0.4: kw.update(u_slew_constr=[[-float(rng.uniform(0.01, 0.1)), float(rng.uniform(0.01, 0.1))]] * m, u_slew_constr_coeff=float(rng.uniform(1, 20)))
     if rng.random() < 0.3: kw.update(moment_scale=float(rng.uniform(0.1, 1.0)))
     cfg = MPCConfig(**kw); model = synthetic_multirotor(m, seed=it)
-    lname, lenv = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
-    for k in ("SDEMPC_SPEC", "SDEMPC_COOP", "SDEMPC_COOP_LAUNCH", "SDEMPC_PK", "SDEMPC_USTG", "SDEMPC_LANE"): os.environ.pop(k, None)
-    os.environ.update(lenv); used[lname] = used.get(lname, 0) + 1
+    lname, lopts = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
+    used[lname] = used.get(lname, 0) + 1
     B = int(rng.integers(1, 6))
     x0 = W.random_initial_states(B, 1000 + it); xref = np.stack([W.reference_window(0.2 * b, cfg.time_steps) for b in range(B)]); noise = W.make_noise(B, P, H, it)
     u = np.clip(np.asarray(cfg.uref, np.float32) + 0.15 * rng.standard_normal((B, H, m)), 1e-4, 1).astype(np.float32)
-    S = SdeMpcSolver(cfg, model, max_batch=B); O = orc.Oracle(cfg, model)
+    S = SdeMpcSolver(cfg, model, max_batch=B, options=lopts); O = orc.Oracle(cfg, model)
     cost, traj, xm = S.rollout(x0, u, xref, noise, True, True); gc, g = S.grad(x0, u, xref, noise)
     uopt, xe, info = S.solve(x0, xref, noise, u, np.full(B, cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize, np.float32))
     keys = rng.integers(0, 2 ** 32, size=(B, 2), dtype=np.uint32)

@@ -1,5 +1,6 @@
 """Single-instance solve latency (what one control tick of the reference's mpc_process sees), per config.
-usage: python tools/latency.py [--reps 7]; SDEMPC_PK=0/1 forces the scalar / packed tanh instantiation."""
+usage: python tools/latency.py [--reps 7]; environment defaults of the handle options apply (include/sdempc.h: SDEMPC_PK=0/1 forces the
+scalar / packed tanh instantiation, SDEMPC_COOP=0 the one-workgroup-per-instance layout, SDEMPC_COOP_FENCE=1 the fenced grid barrier)."""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -265,13 +265,20 @@ def main():
     elapsed = max_over_ranks(elapsed, device=dev)
     # per-launch kernel duration from HIP events, measured live on the launch stream (separate launches)
     ev_ms = []
+    torch.cuda.synchronize()
+    solver.work_counters(reset=True)
     for _ in range(min(args.steps, 3)):
         step()
         ev_ms.append(solver.last_kernel_ms())
     torch.cuda.synchronize()
+    w_solves, w_grads, w_fwd = solver.work_counters()
     info_h = info.cpu().numpy()
     n_it = float(info_h[:, 2].mean())
     n_ls = float(info_h[:, 7].mean())
+    # work actually performed per solve (sdempc_work_counters): an iteration whose extrapolation point did not move re-uses its
+    # gradient, so fewer gradients are evaluated than iterations are counted; the roofline counts only what was evaluated
+    n_grad = w_grads / max(w_solves, 1)
+    n_fwd = w_fwd / max(w_solves, 1)            # line-search trials + initial-cost + final mean-trajectory rollouts
 
     # outputs of the timed configuration (last launch: same inputs, deterministic kernel), kept for the verification below
     uopt_h, xevol_h = uopt.cpu().numpy(), xevol.cpu().numpy()
@@ -279,7 +286,7 @@ def main():
     if rank == 0:
         solves = world * B * args.steps
         value = solves / elapsed
-        bytes_solve, flops_solve, b_grad, b_ls = algorithmic_counts(cfg, n_it, n_ls)
+        bytes_solve, flops_solve, b_grad, b_ls = algorithmic_counts(cfg, n_grad, n_fwd - 2)
         k_ms = float(np.mean(ev_ms))
         ach_gbs = bytes_solve * B / (k_ms * 1e-3) / 1e9
         ach_tf = flops_solve * B / (k_ms * 1e-3) / 1e12
@@ -313,7 +320,7 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.mlp_dtype == "f32" else "f16 MLP operands / f32 accumulate and state", "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.config)}: H={H} P={P} m={m}, {B} independent MPC instances per GPU per step, "
                                    f"cold-start solves from the hover guess, max_iter={cfg.max_iter} maxls={cfg.ls_maxls}",
-                       "instances_per_gpu": B, "noise": "threefry2x32 keys (seed 10 split per instance), normal draws generated on the device", "N_it_mean": n_it, "N_ls_mean": n_ls, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+                       "instances_per_gpu": B, "noise": "threefry2x32 keys (seed 10 split per instance), normal draws generated on the device", "N_it_mean": n_it, "N_ls_mean": n_ls, "N_grad_evaluated_mean": n_grad, "N_forward_rollouts_mean": n_fwd, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "p50_solve_latency_ms": float(np.median(lat)),
             "p95_solve_latency_ms": float(np.percentile(lat, 95)),
             "latency_reps": len(lat), "latency_layout_fallbacks": solver.layout_fallbacks(),
@@ -323,10 +330,11 @@ def main():
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
                          "traffic": traffic, "kernel": "sdempc::exact::sdempc_solve_kernel<sdempc::exact::%s, %d, %s, false, 0, false>" % ("TeamBlock" if P > 32 else "TeamWave", m if m in (4, 6) else 8, "true" if args.mlp_dtype == "f16" else "false"), "kernel_ms": k_ms,
                          "note": "f32-exact path: MLP contractions on v_mfma_f32_32x32x2_f32 (157.3 TF dense peak = f32 vector peak); "
-                                 "algorithmic flops = SURVEY §8d MLP formula x P*H*(2*N_it+N_ls+2)"},
+                                 "algorithmic flops = SURVEY §8d MLP formula x P*H*(2*N_grad+N_ls+2), N_grad = gradient evaluations actually performed "
+                                 "(sdempc_work_counters; identical re-evaluations at an unchanged point are skipped and not counted)"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "traffic": traffic, "bytes_per_solve": bytes_solve, "B_grad": b_grad, "B_ls": b_ls,
-                             "checkpoint_bytes_per_solve": checkpoint_bytes(cfg, n_it),
+                             "checkpoint_bytes_per_solve": checkpoint_bytes(cfg, n_grad),
                              "note": "achieved = SURVEY 8d algorithmic bytes / kernel time; measured traffic additionally contains the activation-checkpoint stream"},
         }
         # ---- CPU legs (rank 0): verification of the timed launch + the reported CPU baseline ------------------------------------

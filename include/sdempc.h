@@ -137,6 +137,7 @@ int sdempc_device_ready(const sdempc_handle* h);
  *   SDEMPC_OPT_SPEC           0 / 1                          1        SDEMPC_SPEC          speculative variant of the cooperative layout (smallest batches)
  *   SDEMPC_OPT_PK             -1 auto / 0 / 1                -1       SDEMPC_PK            packed-f32 tanh instantiation of the tile layout (auto: grid <= CUs)
  *   SDEMPC_OPT_USTG           -1 auto / 0 / 1                -1       SDEMPC_USTG          per-step control table in global memory instead of LDS (auto: long horizons)
+ *   SDEMPC_OPT_DUO            -1 auto / 0 / 1                -1       SDEMPC_DUO           throughput launches: 64 particles per wave (two 32-particle groups; auto = on)
  *   SDEMPC_OPT_COOP_LAUNCH    0 / 1                          0        SDEMPC_COOP_LAUNCH   hipLaunchCooperativeKernel for the cooperative layouts
  *   SDEMPC_OPT_COOP_FENCE     0 / 1                          0        SDEMPC_COOP_FENCE    agent-scope release / acquire fences around the grid barrier
  *   SDEMPC_OPT_COOP_SPIN_US   -1 derived / >= 0 microseconds -1       SDEMPC_COOP_SPIN_US  how long one grid barrier of a cooperative layout may wait
@@ -153,6 +154,7 @@ int sdempc_device_ready(const sdempc_handle* h);
 #define SDEMPC_OPT_COOP_FENCE 7
 #define SDEMPC_OPT_COOP_SPIN_US 8
 #define SDEMPC_OPT_DEVICE_CUS 9
+#define SDEMPC_OPT_DUO 10
 int sdempc_set_option(sdempc_handle* h, int32_t key, int32_t value);
 int sdempc_get_option(const sdempc_handle* h, int32_t key, int32_t* value);
 
@@ -232,6 +234,14 @@ int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const 
 int sdempc_solve_status(sdempc_handle* h);
 /* Number of times this handle left the cooperative layouts because a grid barrier gave up (0 in normal operation). */
 int32_t sdempc_layout_fallbacks(const sdempc_handle* h);
+
+/* Work the solve launches of this handle have actually done since creation (or the last reset), summed over instances:
+ * out[0] solves, out[1] gradient evaluations (forward + adjoint sweep), out[2] forward-only rollouts (line-search trials, the
+ * initial-cost and the final mean-trajectory rollout), out[3] reserved. An iteration whose extrapolation point did not move re-uses
+ * its gradient instead of evaluating it again, so out[1] can be below the sum of the iteration counts. Counted by the
+ * one-team-per-instance and plain cooperative layouts (the speculative latency layout evaluates extra, discarded rollouts and is
+ * not counted). Call after the stream of the last solve has been synchronised. Roofline accounting of bench.py. */
+int sdempc_work_counters(sdempc_handle* h, uint64_t out[4], int32_t reset);
 
 /* Times the last *_dev launch on its own stream with HIP events (ms); <0 if unavailable. */
 float sdempc_last_kernel_ms(const sdempc_handle* h);

@@ -1,0 +1,468 @@
+"""sde_mpc_numpy.py — SECOND, independent CPU restatement of SPEC.md (NumPy, particle-vectorised). TEST INFRASTRUCTURE ONLY.
+
+Only tests/ may import this file (the same rule as for oracle/sde_mpc_oracle.c). PARITY UNPINNED against the reference for the
+same reason as the C oracle: the arithmetic of the path is not in /root/reference (sde_control.py:12-13 imports it from the
+un-vendored package sde4mbrl). What this file adds is a cross-check of the oracle itself: it is written from SPEC.md in another
+language and another loop order (all particles at once instead of one particle at a time), and the tests require
+
+  * forward rollout, particle x horizon tensor, mean trajectory, expected cost, control cost: BIT-IDENTICAL to the C oracle
+    (SPEC.md §3-§6; float32 with an exact software fma, see `fma`);
+  * the accelerated proximal gradient loop of SPEC.md §8, driven by the C oracle's cost / gradient callbacks but with its own
+    reductions (§6.2) and decision logic: BIT-IDENTICAL controls and telemetry;
+  * the adjoint (§5.4-§5.5): the C oracle's float32 gradient against reverse-mode automatic differentiation (torch.autograd,
+    float64, libm activations) of the same model written here a third time (`torch_cost`) — a check that does not share the
+    hand-derived vector-Jacobian product with anything.
+
+Follows (reference): call shapes sde_control.py:702-719,400-416; YAML keys launch/iris_sitl_traj_mpc.yaml:8-85.
+"""
+import numpy as np
+
+F = np.float32
+U32 = np.uint32
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# exact float32 fma on arrays: the product of two float32 is exact in float64; the float64 sum is corrected to round-to-odd
+# with the TwoSum error term, and a round-to-odd value with >= 2 spare bits rounds to float32 exactly like the infinitely
+# precise result (no double rounding).
+# ------------------------------------------------------------------------------------------------------------------------------
+def fma(a, b, c):
+    a, b, c = np.asarray(a, F), np.asarray(b, F), np.asarray(c, F)
+    p = a.astype(np.float64) * b.astype(np.float64)
+    c64 = c.astype(np.float64)
+    with np.errstate(invalid="ignore", over="ignore"):
+        s = p + c64
+        t = s - p
+        e = (p - (s - t)) + (c64 - t)
+    s = np.asarray(s)
+    fix = np.isfinite(s) & np.isfinite(e) & (e != 0.0) & ((s.view(np.uint64) & np.uint64(1)) == 0)
+    s = np.where(fix, np.nextafter(s, np.where(e > 0, np.inf, -np.inf)), s)
+    with np.errstate(over="ignore", invalid="ignore"):
+        return s.astype(F)
+
+
+def bits(x):
+    return np.asarray(x, F).view(U32)
+
+
+def from_bits(u):
+    return np.asarray(u, U32).view(F)
+
+
+def clamp(x, lo, hi):
+    """SPEC.md §3.6: !(x > lo) ? lo : (x > hi ? hi : x) — a NaN maps to lo."""
+    x = np.asarray(x, F)
+    with np.errstate(invalid="ignore"):
+        return np.where(~(x > F(lo)), F(lo), np.where(x > F(hi), F(hi), x)).astype(F)
+
+
+def rcp(d):
+    d = np.asarray(d, F)
+    y = from_bits(U32(0x7EF311C7) - bits(d))
+    for _ in range(3):
+        e = fma(-d, y, F(1.0))
+        y = fma(y, e, y)
+    return y
+
+
+def rsqrt(a):
+    a = np.asarray(a, F)
+    y = from_bits(U32(0x5F3759DF) - (bits(a) >> U32(1)))
+    h = F(0.5) * a
+    for _ in range(3):
+        t = y * y
+        t = fma(-h, t, F(1.5))
+        y = y * t
+    return y
+
+
+_EXP2 = [F(0.001327647129073739), F(0.009675540961325169), F(0.05550713092088699), F(0.24022120237350464), F(0.6931469440460205),
+         F(1.0000001192092896)]
+
+
+def exp2c(x, c):
+    x = np.asarray(x, F)
+    t2 = fma(x, F(c), F(12582912.0))
+    n = t2 - F(12582912.0)
+    f = fma(x, F(c), -n)
+    p = np.full_like(f, _EXP2[0])
+    for k in _EXP2[1:]:
+        p = fma(p, f, k)
+    with np.errstate(over="ignore"):
+        return from_bits(bits(p) + (bits(t2) << U32(23)))
+
+
+def tanh4(a):
+    """a: [..., 4] — four values share one reciprocal (SPEC.md §3.4)."""
+    d = [F(1.0) + exp2c(clamp(a[..., i], -9.0, 9.0), 2.885390043258667) for i in range(4)]
+    p2 = d[0] * d[1]
+    p3 = p2 * d[2]
+    p4 = p3 * d[3]
+    r = rcp(p4)
+    r3 = r * p3
+    r = r * d[3]
+    r2 = r * p2
+    r = r * d[2]
+    r1 = r * d[0]
+    r0 = r * d[1]
+    return np.stack([fma(F(-2.0), ri, F(1.0)) for ri in (r0, r1, r2, r3)], axis=-1)
+
+
+def tanh_units(a):
+    """a: [..., 32] hidden pre-activations; groups of 4 consecutive units."""
+    return tanh4(a.reshape(a.shape[:-1] + (8, 4))).reshape(a.shape)
+
+
+def sigmoid(x):
+    return rcp(F(1.0) + exp2c(clamp(x, -30.0, 30.0), -1.4426950216293335))
+
+
+def korder():
+    """SPEC.md §4: k(r, h) = (r & 3) + 8 (r >> 2) + 4 h, r = 0..15, inner h = 0, 1."""
+    return [(r & 3) + 8 * (r >> 2) + 4 * h for r in range(16) for h in (0, 1)]
+
+
+def half_sums(w, a):
+    """(P_0 + P_1) of SPEC.md §4: w [32], a [..., 32] -> [...]"""
+    P = []
+    for h in (0, 1):
+        acc = np.zeros(a.shape[:-1], F)
+        for r in range(16):
+            k = (r & 3) + 8 * (r >> 2) + 4 * h
+            acc = fma(w[k], a[..., k], acc)
+        P.append(acc)
+    return P[0] + P[1]
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+class Model:
+    """SPEC.md §2 blob."""
+
+    def __init__(self, blob: bytes):
+        hd = np.frombuffer(blob, np.int32, 16)
+        assert hd[0] == 0x31454453 and hd[1] == 1
+        self.m = int(hd[2])
+        f = np.frombuffer(blob, F, 2120, 64).copy()
+        self.inv_mass, self.grav = f[0], f[1]
+        self.J, self.iJ = f[2:5], f[5:8]
+        self.ct2, self.ct1, self.ct0, self.cm2, self.cm1 = f[8:13]
+        self.rx, self.ry, self.dir = f[16:24], f[24:32], f[32:40]
+        self.sF, self.sT = f[40:43], f[43:46]
+        self.sigma = f[48:54]
+        self.W1z = f[56:440].reshape(64, 6)
+        self.b1 = f[440:504]
+        self.W1u = f[504:760].reshape(32, 8)
+        self.W2 = f[760:1784].reshape(32, 32)
+        self.b2 = f[1784:1816]
+        self.W3 = f[1816:2072].reshape(8, 32)
+        self.b3 = f[2072:2080]
+        self.w3n = f[2080:2112]
+        self.b3n = f[2112]
+
+
+class Restatement:
+    """One (config, model): rollout / cost in float32, bit for bit as SPEC.md writes them; APG loop of §8."""
+
+    def __init__(self, cfg, model):
+        self.cfg = cfg
+        self.M = Model(model.to_blob() if hasattr(model, "to_blob") else bytes(model))
+        self.H, self.P, self.m = cfg.horizon, cfg.num_particles, cfg.num_motors
+        assert cfg.mlp_dtype == "f32"
+        self.dt = np.asarray(cfg.time_steps, F)
+        self.sdt = np.stack([self.M.sigma * F(np.sqrt(F(d))) for d in self.dt]).astype(F)       # sigma_i * sqrtf(dt_t), host float32
+        disc = []
+        d = F(1.0) / F(self.H)
+        for _ in range(self.H + 1):
+            disc.append(d)
+            d = F(d * F(cfg.discount))
+        self.disc = np.asarray(disc, F)
+        self.invP = F(1.0) / F(self.P)
+
+    # ---- §5.1 ----
+    def ustep(self, u):
+        M, m = self.M, self.m
+        c = M.b1[:32].copy()
+        for j in range(m):
+            c = fma(M.W1u[:, j], u[j], c)
+        Tz = t0 = t1 = t2 = F(0.0)
+        for j in range(m):
+            T = fma(fma(M.ct2, u[j], M.ct1), u[j], M.ct0)
+            Mq = M.dir[j] * (fma(M.cm2, u[j], M.cm1) * u[j])
+            Tz = F(Tz + T)
+            t0 = fma(M.ry[j], T, t0)
+            t1 = fma(-M.rx[j], T, t1)
+            t2 = F(t2 + Mq)
+        return c, F(Tz), (F(t0), F(t1), F(t2))
+
+    # ---- §5.2: all particles at once; x [P,13], xi [P,6] ----
+    def step(self, x, xi, u_terms, t):
+        M = self.M
+        c, Tz, tau = u_terms
+        dt = self.dt[t]
+        p, v, q, om = x[:, 0:3], x[:, 3:6], x[:, 6:10], x[:, 10:13]
+        qw, qx, qy, qz = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        xx, yy, zz = qx * qx, qy * qy, qz * qz
+        xy, xz, yz, wx, wy, wz = qx * qy, qx * qz, qy * qz, qw * qx, qw * qy, qw * qz
+        R = [fma(F(-2), yy + zz, F(1)), F(2) * (xy - wz), F(2) * (xz + wy),
+             F(2) * (xy + wz), fma(F(-2), xx + zz, F(1)), F(2) * (yz - wx),
+             F(2) * (xz - wy), F(2) * (yz + wx), fma(F(-2), xx + yy, F(1))]
+        vb = [fma(R[6 + j], v[:, 2], fma(R[3 + j], v[:, 1], R[j] * v[:, 0])) for j in range(3)]
+        z = vb + [om[:, 0], om[:, 1], om[:, 2]]
+        a_d = np.broadcast_to(c, (x.shape[0], 32)).astype(F).copy()
+        a_n = np.broadcast_to(M.b1[32:], (x.shape[0], 32)).astype(F).copy()
+        for k in range(6):
+            a_d = fma(M.W1z[:32, k][None, :], z[k][:, None], a_d)
+            a_n = fma(M.W1z[32:, k][None, :], z[k][:, None], a_n)
+        h1d, h1n = tanh_units(a_d), tanh_units(a_n)
+        a2 = np.broadcast_to(M.b2, (x.shape[0], 32)).astype(F).copy()
+        for k in korder():
+            a2 = fma(M.W2[:, k][None, :], h1d[:, k][:, None], a2)
+        h2 = tanh_units(a2)
+        o = [half_sums(M.W3[i], h2) + M.b3[i] for i in range(6)]
+        eta = sigmoid(half_sums(M.w3n, h1n) + M.b3n)
+        Fb = [M.sF[0] * o[0], M.sF[1] * o[1], fma(M.sF[2], o[2], Tz)]
+        acc = [fma(R[3 * i + 2], Fb[2], fma(R[3 * i + 1], Fb[1], R[3 * i] * Fb[0])) * M.inv_mass for i in range(3)]
+        acc[2] = acc[2] - M.grav
+        taub = [fma(M.sT[i], o[3 + i], tau[i]) for i in range(3)]
+        Jom = [M.J[i] * om[:, i] for i in range(3)]
+        cr = [fma(om[:, 1], Jom[2], -(om[:, 2] * Jom[1])), fma(om[:, 2], Jom[0], -(om[:, 0] * Jom[2])), fma(om[:, 0], Jom[1], -(om[:, 1] * Jom[0]))]
+        dom = [(taub[i] - cr[i]) * M.iJ[i] for i in range(3)]
+        dq = [F(-0.5) * fma(qz, om[:, 2], fma(qy, om[:, 1], qx * om[:, 0])),
+              F(0.5) * fma(-qz, om[:, 1], fma(qy, om[:, 2], qw * om[:, 0])),
+              F(0.5) * fma(-qx, om[:, 2], fma(qz, om[:, 0], qw * om[:, 1])),
+              F(0.5) * fma(-qy, om[:, 0], fma(qx, om[:, 1], qw * om[:, 2]))]
+        xn = np.empty_like(x)
+        for i in range(3):
+            xn[:, i] = fma(v[:, i], dt, p[:, i])
+            xn[:, 3 + i] = fma((self.sdt[t, i] * eta), xi[:, i], fma(acc[i], dt, v[:, i]))
+            xn[:, 10 + i] = fma((self.sdt[t, 3 + i] * eta), xi[:, 3 + i], fma(dom[i], dt, om[:, i]))
+        qt = [fma(dq[i], dt, q[:, i]) for i in range(4)]
+        n2 = fma(qt[3], qt[3], fma(qt[2], qt[2], fma(qt[1], qt[1], qt[0] * qt[0])))
+        rn = rsqrt(n2)
+        for i in range(4):
+            xn[:, 6 + i] = qt[i] * rn
+        return xn, eta
+
+    # ---- §5.3 ----
+    def stage_cost(self, x, xr):
+        C = self.cfg
+        l = np.zeros(x.shape[0], F)
+        for w_, off in ((C.perr, 0), (C.verr, 3), (C.werr, 10)):
+            for i in range(3):
+                e = x[:, off + i] - xr[off + i]
+                l = fma(F(w_[i]) * e, e, l)
+        qw, qx, qy, qz = x[:, 6], x[:, 7], x[:, 8], x[:, 9]
+        rw, rx, ry, rz = xr[6], xr[7], xr[8], xr[9]
+        ex = fma(rz, qy, fma(-ry, qz, fma(-rx, qw, rw * qx)))
+        ey = fma(-rz, qx, fma(-ry, qw, fma(rx, qz, rw * qy)))
+        ez = fma(-rz, qw, fma(ry, qx, fma(-rx, qy, rw * qz)))
+        for w_, e in ((C.qerr[0], ex), (C.qerr[1], ey), (C.qerr[2], ez)):
+            l = fma(F(w_) * e, e, l)
+        return l
+
+    def particle_sum(self, vals):
+        """SPEC.md §6.1; vals [P, ...] -> [...]"""
+        P = vals.shape[0]
+        G = (P + 31) // 32
+        S = [np.zeros(vals.shape[1:], F) for _ in range(4)]
+        for g in range(G):
+            v = np.zeros((32,) + vals.shape[1:], F)
+            n = min(32, P - 32 * g)
+            v[:n] = vals[32 * g:32 * g + n]
+            for s in (16, 8, 4, 2, 1):
+                v = v + v[np.arange(32) ^ s]
+            S[g % 4] = S[g % 4] + v[0]
+        return ((S[0] + S[1]) + S[2]) + S[3]
+
+    @staticmethod
+    def dot256(a, b=None):
+        """SPEC.md §6.2 over flat arrays."""
+        a = np.asarray(a, F).reshape(-1)
+        b = np.ones_like(a) if b is None else np.asarray(b, F).reshape(-1)
+        N = a.size
+        v = np.zeros(256, F)
+        for e0 in range(0, N, 256):
+            n = min(256, N - e0)
+            v[:n] = fma(a[e0:e0 + n], b[e0:e0 + n], v[:n])
+        w = []
+        for k in range(4):
+            x = v[64 * k:64 * k + 64]
+            for s in (32, 16, 8, 4, 2, 1):
+                x = x + x[np.arange(64) ^ s]
+            w.append(x[0])
+        return F(((w[0] + w[1]) + w[2]) + w[3])
+
+    def control_cost(self, u):
+        C, H, m = self.cfg, self.H, self.m
+        u = np.asarray(u, F)
+        el = np.zeros((H, m), F)
+        for t in range(H):
+            for j in range(m):
+                du = F(u[t, j] - F(C.uref[j]))
+                c = F(F(F(C.uerr) * du) * du)
+                if t >= 1:
+                    ds = F(u[t, j] - u[t - 1, j])
+                    c = fma(F(F(C.u_slew_coeff) * ds), ds, c)
+                    if C.u_slew_constr is not None:
+                        lo_b, hi_b = C.u_slew_constr[j]
+                        hi = max(F(0.0), F(ds - F(hi_b)))
+                        lo = max(F(0.0), F(F(lo_b) - ds))
+                        c = fma(F(F(C.u_slew_constr_coeff) * hi), hi, c)
+                        c = fma(F(F(C.u_slew_constr_coeff) * lo), lo, c)
+                el[t, j] = F(self.disc[t] * F(c))
+        return self.dot256(el)
+
+    def rollout(self, x0, u, xref, noise):
+        """-> (expected cost, traj [P,H+1,13], mean trajectory [H+1,13])"""
+        H, P = self.H, self.P
+        x0, u, xref, noise = (np.asarray(a, F) for a in (x0, u, xref, noise))
+        x = np.broadcast_to(x0, (P, 13)).astype(F).copy()
+        traj = np.empty((P, H + 1, 13), F)
+        traj[:, 0] = x
+        J = np.zeros(P, F)
+        for t in range(H):
+            xn, eta = self.step(x, noise[:, t], self.ustep(u[t]), t)
+            l = self.stage_cost(xn, xref[t + 1])
+            l = fma(F(self.cfg.res_mult) * eta, eta, l)
+            J = fma(self.disc[t], l, J)
+            x = xn
+            traj[:, t + 1] = x
+        tot = self.particle_sum(J)
+        xmean = (self.particle_sum(traj) * self.invP).astype(F)
+        return F(fma(tot, self.invP, self.control_cost(u))), traj, xmean
+
+    # ---- §8: the optimiser, with cost / gradient supplied by callables (the tests pass the C oracle's) ----
+    def solve(self, cost_fn, grad_fn, u_init, stepsize_in):
+        C, H, m = self.cfg, self.H, self.m
+        lo, hi = np.asarray([b[0] for b in C.input_bound], F), np.asarray([b[1] for b in C.input_bound], F)
+        if not C.enforce_ubound:
+            lo, hi = np.full(m, -np.inf, F), np.full(m, np.inf, F)
+        proj = lambda v: np.stack([clamp(v[:, j], lo[j], hi[j]) for j in range(m)], axis=1)
+        beta = [F(C.beta_init)] + [F(F(i + 1) / F(i + 4)) for i in range(1, C.max_iter + 2)]
+        if C.moment_scale is not None:
+            beta = [beta[0]] + [F(F(C.moment_scale) * b) for b in beta[1:]]
+        xk = proj(np.asarray(u_init, F))
+        yk = xk.copy()
+        c_init = c_x = F(cost_fn(xk))
+        s = F(stepsize_in)
+        gsq, sum_ls, sum_s = F(0), F(0), F(0)
+        kr = noimp = nit = nls_tot = 0
+        plain = True
+        for k in range(C.max_iter):
+            c_y, g = grad_fn(yk)
+            c_y, g = F(c_y), np.asarray(g, F)
+            gsq = self.dot256(g, g)
+            if not (gsq < np.inf):
+                break
+            c_n, nls = F(0), 0
+            if C.ls_maxls > 0:
+                if k > 0 and C.ls_reset_option == "increase":
+                    s = F(s * F(C.ls_increase_factor))
+                if s > F(C.ls_max_stepsize):
+                    s = F(C.ls_max_stepsize)
+                for jl in range(C.ls_maxls):
+                    xn = proj(fma(-s, g, yk))
+                    d1 = xn - yk
+                    c_n = F(cost_fn(xn))
+                    gd = self.dot256(g, d1)
+                    nls = jl + 1
+                    if c_n <= fma(F(C.ls_coef), gd, c_y):
+                        break
+                    if jl < C.ls_maxls - 1:
+                        s = F(s * F(C.ls_decrease_factor))
+            else:
+                s = F(C.stepsize)
+                xn = proj(fma(-s, g, yk))
+                c_n, nls = F(cost_fn(xn)), 1
+            sum_ls, sum_s, nit, nls_tot = F(sum_ls + F(nls)), F(sum_s + s), k + 1, nls_tot + nls
+            stop = abs(F(c_n - c_x)) <= fma(F(C.rtol), abs(c_x), F(C.atol))
+            if c_n < c_x:
+                if self.dot256(yk - xn, xn - xk) > 0:
+                    yk, kr, plain = xn.copy(), 0, True
+                else:
+                    yk, kr, plain = proj(fma(beta[kr], xn - xk, xn)), kr + 1, False
+                xk, c_x, noimp = xn.copy(), c_n, 0
+            else:
+                if not plain:
+                    stop = False
+                yk, kr, plain, noimp = xk.copy(), 0, True, noimp + 1
+            if noimp >= C.max_no_improvement_iter:
+                stop = True
+            if stop:
+                break
+        fn = F(nit)
+        info = np.array([sum_ls / fn if nit else 0, s, fn, gsq, sum_s / fn if nit else 0, c_init, c_x, nls_tot], F)
+        return xk, info
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Third writing of the model, in torch float64 with libm activations, for reverse-mode differentiation of the expected cost
+# ------------------------------------------------------------------------------------------------------------------------------
+def torch_cost(cfg, model, x0, u, xref, noise):
+    """Expected cost J(u) in float64 (true tanh / sigmoid / 1/sqrt) as a differentiable torch scalar; u: torch [H, m] float64."""
+    import torch
+    M = Model(model.to_blob() if hasattr(model, "to_blob") else bytes(model))
+    T = lambda a: torch.as_tensor(np.asarray(a, np.float64))
+    H, P, m = cfg.horizon, cfg.num_particles, cfg.num_motors
+    dt = np.asarray(cfg.time_steps, F).astype(np.float64)
+    sdt = np.stack([M.sigma * F(np.sqrt(F(d))) for d in np.asarray(cfg.time_steps, F)]).astype(np.float64)
+    disc = [float(F(1.0) / F(H))]
+    for _ in range(H):
+        disc.append(float(F(F(disc[-1]) * F(cfg.discount))))
+    W1z, W1u, W2, W3 = T(M.W1z), T(M.W1u[:, :m]), T(M.W2), T(M.W3[:6])
+    b1, b2, b3, w3n = T(M.b1), T(M.b2), T(M.b3[:6]), T(M.w3n)
+    x = T(x0).repeat(P, 1)
+    xr, nz = T(xref), T(noise)
+    rx, ry, dr = T(M.rx[:m]), T(M.ry[:m]), T(M.dir[:m])
+    J = torch.zeros(P, dtype=torch.float64)
+    for t in range(H):
+        ut = u[t]
+        Tj = (float(M.ct2) * ut + float(M.ct1)) * ut + float(M.ct0)
+        Mq = dr * ((float(M.cm2) * ut + float(M.cm1)) * ut)
+        Tz, tau = Tj.sum(), torch.stack([(ry * Tj).sum(), (-rx * Tj).sum(), Mq.sum()])
+        p, v, q, om = x[:, 0:3], x[:, 3:6], x[:, 6:10], x[:, 10:13]
+        qw, qx, qy, qz = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([torch.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)], -1),
+                         torch.stack([2 * (qx * qy + qw * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qw * qx)], -1),
+                         torch.stack([2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 1 - 2 * (qx * qx + qy * qy)], -1)], 1)   # [P,3,3]
+        vb = torch.einsum("pij,pi->pj", R, v)
+        z = torch.cat([vb, om], 1)
+        h1d = torch.tanh(z @ W1z[:32].T + (W1u @ ut + b1[:32]))
+        h1n = torch.tanh(z @ W1z[32:].T + b1[32:])
+        h2 = torch.tanh(h1d @ W2.T + b2)
+        o = h2 @ W3.T + b3
+        eta = torch.sigmoid(h1n @ w3n + float(M.b3n))
+        Fb = torch.stack([float(M.sF[0]) * o[:, 0], float(M.sF[1]) * o[:, 1], float(M.sF[2]) * o[:, 2] + Tz], 1)
+        acc = torch.einsum("pij,pj->pi", R, Fb) * float(M.inv_mass)
+        acc = acc - torch.tensor([0.0, 0.0, float(M.grav)], dtype=torch.float64)
+        taub = T(M.sT) * o[:, 3:6] + tau
+        Jm = T(M.J)
+        dom = (taub - torch.cross(om, Jm * om, dim=1)) * T(M.iJ)
+        dq = 0.5 * torch.stack([-(qx * om[:, 0] + qy * om[:, 1] + qz * om[:, 2]),
+                                qw * om[:, 0] + qy * om[:, 2] - qz * om[:, 1],
+                                qw * om[:, 1] + qz * om[:, 0] - qx * om[:, 2],
+                                qw * om[:, 2] + qx * om[:, 1] - qy * om[:, 0]], 1)
+        s = T(sdt[t])
+        pn = p + v * dt[t]
+        vn = v + acc * dt[t] + (s[:3] * eta[:, None]) * nz[:, t, :3]
+        on = om + dom * dt[t] + (s[3:] * eta[:, None]) * nz[:, t, 3:]
+        qt = q + dq * dt[t]
+        qn = qt / qt.norm(dim=1, keepdim=True)
+        x = torch.cat([pn, vn, qn, on], 1)
+        r = xr[t + 1]
+        l = (T(cfg.perr) * (pn - r[0:3]) ** 2).sum(1) + (T(cfg.verr) * (vn - r[3:6]) ** 2).sum(1) + (T(cfg.werr) * (on - r[10:13]) ** 2).sum(1)
+        rw, rxq, ryq, rzq = r[6], r[7], r[8], r[9]
+        ex = rw * qn[:, 1] - rxq * qn[:, 0] - ryq * qn[:, 3] + rzq * qn[:, 2]
+        ey = rw * qn[:, 2] + rxq * qn[:, 3] - ryq * qn[:, 0] - rzq * qn[:, 1]
+        ez = rw * qn[:, 3] - rxq * qn[:, 2] + ryq * qn[:, 1] - rzq * qn[:, 0]
+        l = l + float(cfg.qerr[0]) * ex ** 2 + float(cfg.qerr[1]) * ey ** 2 + float(cfg.qerr[2]) * ez ** 2 + float(cfg.res_mult) * eta ** 2
+        J = J + disc[t] * l
+    du = u - T(np.asarray(cfg.uref[:m], np.float64))
+    cu = float(cfg.uerr) * du ** 2
+    ds = u[1:] - u[:-1]
+    sl = float(cfg.u_slew_coeff) * ds ** 2
+    if cfg.u_slew_constr is not None:
+        lo_b, hi_b = T([b[0] for b in cfg.u_slew_constr]), T([b[1] for b in cfg.u_slew_constr])
+        sl = sl + float(cfg.u_slew_constr_coeff) * (torch.clamp(ds - hi_b, min=0) ** 2 + torch.clamp(lo_b - ds, min=0) ** 2)
+    cu = torch.cat([cu[:1], cu[1:] + sl], 0)
+    return J.mean() + (T(disc[:H])[:, None] * cu).sum()

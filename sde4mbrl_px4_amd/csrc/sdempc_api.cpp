@@ -63,6 +63,7 @@ struct sdempc_handle {
     DevBuf d_part, d_act, d_traj, d_x0, d_u, d_xref, d_noise, d_step, d_cost, d_grad, d_xmean, d_uopt, d_info;
     // canonical-layout staging of the host-pointer entry points (allocated on their first use)
     DevBuf d_noise_canon, d_traj_canon, d_keys;
+    DevBuf d_work;            // u64[4] work counters (KArgs::work)
     // cooperative latency path of the solve (allocated on its first use, sized for coop_cap instances)
     DevBuf d_coop_bar, d_coop_pp, d_coop_ck;
     int coop_cap = 0;
@@ -114,6 +115,7 @@ void default_options(sdempc_handle* h) {
     o.spec = env_int("SDEMPC_SPEC", 1, 0, 1);
     o.pk = env_int("SDEMPC_PK", -1, -1, 1);
     o.ustg = env_int("SDEMPC_USTG", -1, -1, 1);
+    o.duo = env_int("SDEMPC_DUO", -1, -1, 1);
     o.coop_launch = env_int("SDEMPC_COOP_LAUNCH", 0, 0, 1);
     o.coop_fence = env_int("SDEMPC_COOP_FENCE", 0, 0, 1);
     h->spin_us = env_int("SDEMPC_COOP_SPIN_US", -1, -1, 10 * 1000 * 1000);
@@ -190,6 +192,9 @@ int ensure_device_impl(sdempc_handle* h) {
     if ((rc = dev_alloc(h, h->d_xmean, sizeof(float) * B * (H + 1) * SDEMPC_NX))) return rc;
     if ((rc = dev_alloc(h, h->d_uopt, sizeof(float) * B * H * m))) return rc;
     if ((rc = dev_alloc(h, h->d_info, sizeof(float) * B * 8))) return rc;
+    if ((rc = dev_alloc(h, h->d_work, sizeof(unsigned long long) * 4))) return rc;
+    HIPCHK(h, hipMemset(h->d_work.p, 0, h->d_work.bytes));
+    h->base.work = (unsigned long long*)h->d_work.p;
     h->base.dt = (const float*)h->d_dt.p;
     h->base.sdt = (const float*)h->d_sdt.p;
     h->base.disc = (const float*)h->d_disc.p;
@@ -384,7 +389,7 @@ namespace {
 void release_device(sdempc_handle* h) {
     if (h->dev_ready || h->stream || h->d_dt.p) {
         (void)hipSetDevice(h->device);
-        for (DevBuf* b : {&h->d_ustg, &h->d_part, &h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys, &h->d_coop_bar, &h->d_coop_pp, &h->d_coop_ck,
+        for (DevBuf* b : {&h->d_ustg, &h->d_part, &h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys, &h->d_work, &h->d_coop_bar, &h->d_coop_pp, &h->d_coop_ck,
                           &h->d_step, &h->d_cost, &h->d_grad, &h->d_xmean, &h->d_uopt, &h->d_info})
             dev_free(*b);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -419,6 +424,7 @@ int sdempc_set_option(sdempc_handle* h, int32_t key, int32_t value) {
         case SDEMPC_OPT_SPEC: return flag(o.spec);
         case SDEMPC_OPT_PK: return tri(o.pk);
         case SDEMPC_OPT_USTG: return tri(o.ustg);
+        case SDEMPC_OPT_DUO: return tri(o.duo);
         case SDEMPC_OPT_COOP_LAUNCH: return flag(o.coop_launch);
         case SDEMPC_OPT_COOP_FENCE: return flag(o.coop_fence);
         case SDEMPC_OPT_COOP_SPIN_US:
@@ -438,6 +444,7 @@ int sdempc_get_option(const sdempc_handle* h, int32_t key, int32_t* value) {
         case SDEMPC_OPT_SPEC: *value = o.spec; break;
         case SDEMPC_OPT_PK: *value = o.pk; break;
         case SDEMPC_OPT_USTG: *value = o.ustg; break;
+        case SDEMPC_OPT_DUO: *value = o.duo; break;
         case SDEMPC_OPT_COOP_LAUNCH: *value = o.coop_launch; break;
         case SDEMPC_OPT_COOP_FENCE: *value = o.coop_fence; break;
         case SDEMPC_OPT_COOP_SPIN_US: *value = h->spin_us >= 0 ? h->spin_us : (int32_t)(coop_spin_ticks(h) / 100u); break;
@@ -653,6 +660,18 @@ int sdempc_solve_status(sdempc_handle* h) {
 }
 
 int32_t sdempc_layout_fallbacks(const sdempc_handle* h) { return h ? h->layout_fallbacks : 0; }
+
+int sdempc_work_counters(sdempc_handle* h, uint64_t out[4], int32_t reset) {
+    if (!h || !out) return SDEMPC_EINVAL;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!h->dev_ready) return SDEMPC_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long v[4];
+    HIPCHK(h, hipMemcpy(v, h->d_work.p, sizeof v, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out[i] = v[i];
+    if (reset) HIPCHK(h, hipMemset(h->d_work.p, 0, h->d_work.bytes));
+    return SDEMPC_OK;
+}
 
 }  // extern "C"
 

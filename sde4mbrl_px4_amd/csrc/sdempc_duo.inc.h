@@ -1,0 +1,325 @@
+// sdempc_duo.inc.h — tile layout with 64 particles per wave ("duo": two 32-particle groups per wave)
+// Fragment of sdempc_kernels.hip: included inside namespace sdempc::{exact|fastm}; not a stand-alone header.
+// ================================================================================================
+// In the plain tile layout (block_rollout / block_cost_grad) a wave owns ONE 32-particle group: lane l holds particle l & 31 and half
+// h = l >> 5 of the hidden units, so everything that is per particle rather than per hidden unit — rotation matrix, rigid body, Euler-
+// Maruyama update, quaternion normalisation, stage cost and the head / tail of the vector-Jacobian product, ≈15 % of the forward and
+// ≈22 % of the adjoint step's vector instructions — is computed twice, identically, by both lane halves.
+// Here a wave owns a PAIR of groups: lanes 0..31 carry the particles of group gA = 2 gp, lanes 32..63 those of gB = 2 gp + 1. The per-
+// particle work runs once on 64 distinct particles; the MLPs run as two passes in the unchanged MFMA accumulator layout (pass A on group
+// A's inputs broadcast to both halves, then pass B), and v_permlane32_swap both broadcasts the six inputs of a pass and, in one swap +
+// one add per value, folds the per-half partial sums of both passes so that every lane ends up with ITS particle's total:
+//     swap(PA, PB) = {PA.lo, PB.lo}, {PA.hi, PB.hi};  sum: lanes < 32 -> PA.lo + PA.hi, lanes >= 32 -> PB.lo + PB.hi   ( = (P0 + P1), SPEC.md §4 )
+// Every value is produced by the same operations in the same order as in the plain layout: results are bit-identical (same tests).
+// Teams: two waves own an instance of up to four groups (C2: P = 128 -> 128-thread workgroups, six per CU), four waves otherwise.
+// ================================================================================================
+
+// {v.lo, v.lo} and {v.hi, v.hi}: a group's per-particle value made visible to both lane halves
+DI void half_split(float v, float& a_both, float& b_both) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b;
+    asm("v_mov_b32 %0, %1" : "=v"(b) : "v"(a));      // the swap needs two registers (given one register twice it aliases, see xor32_sum)
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a_both = __builtin_bit_cast(float, r0); b_both = __builtin_bit_cast(float, r1);
+}
+// per-half partial sums of pass A (pa) and pass B (pb) -> this lane's particle total: lanes < 32: pa.lo + pa.hi, lanes >= 32: pb.lo + pb.hi
+DI float half_join_sum(float pa, float pb) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa), __builtin_bit_cast(unsigned, pb), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+
+// Which groups a wave's halves own in pair gp of an instance with G groups. Odd G: the last pair has no group B; its upper half then
+// shadows group A (same inputs, so it stays finite) and neither stores nor contributes to a sum, and pass B is skipped.
+struct DuoPair {
+    int g;          // this lane's group
+    bool hasB;      // wave-uniform: the pair has a real group B
+    bool own;       // this lane half owns a real group
+};
+DI DuoPair duo_pair(int gp, int G, int h) {
+    DuoPair p;
+    p.hasB = (2 * gp + 1) < G;
+    p.own = (h == 0) || p.hasB;
+    p.g = 2 * gp + ((h && p.hasB) ? 1 : 0);
+    return p;
+}
+
+// One Euler-Maruyama step for the wave's 64 particles. CKPT: stream the second hidden layer of both passes to the groups' checkpoint
+// rows (acA / acB: this step's rows of group A / group B).
+template <bool F16, bool CKPT>
+DI void duo_step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, bool hasB, const float* x, const float* xi, float* xn,
+                     StepAux& A, float* acA, float* acB) {
+    const float* ust = sm.ust + t * UST;
+    float z[NN], zA[NN], zB[NN];
+    fwd_head(x, A.Rm, z);
+#pragma unroll
+    for (int k = 0; k < NN; ++k) half_split(z[k], zA[k], zB[k]);
+    SCHED_PHASE();
+    float PA[7], PB[7];
+    fwd_mlp_partials<F16, false>(a, sm, ww, ust, h, lane, zA, A, PA);
+    if constexpr (CKPT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(acA + (q * 64 + lane) * 4) = make_float4(A.h2[4 * q], A.h2[4 * q + 1], A.h2[4 * q + 2], A.h2[4 * q + 3]);
+    }
+    SCHED_PHASE();
+    if (hasB) {
+        fwd_mlp_partials<F16, false>(a, sm, ww, ust, h, lane, zB, A, PB);
+        if constexpr (CKPT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(acB + (q * 64 + lane) * 4) = make_float4(A.h2[4 * q], A.h2[4 * q + 1], A.h2[4 * q + 2], A.h2[4 * q + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) PB[i] = PA[i];
+    }
+    SCHED_PHASE();
+    float o[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = half_join_sum(PA[i], PB[i]) + a.M.b3[i];
+    const float eta = sigmoid_spec(half_join_sum(PA[6], PB[6]) + a.M.b3n);
+    SCHED_PHASE();
+    fwd_tail(a, sm, ust, t, x, xi, A.Rm, o, eta, xn, A);
+}
+
+// ------------------------------------------------------------------------------------------------
+// team-level rollout: expected cost of control sequence u (LDS). Same contract as block_rollout.
+// ------------------------------------------------------------------------------------------------
+template <class Team, bool F16>
+DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
+    b = opaque_s(b); tid = opaque_v(tid);
+    const int H = a.H, G = a.G, P = a.P;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const bool want_mean = xmean_out != nullptr;
+    Team::sync();
+    block_prepass<Team>(a, sm, u, tid);
+    const int PS = part_stride(H);
+    float* prows = a.part + (size_t)b * G * PS;
+    float cu = block_ucost<Team>(a, sm, u, tid);
+    Team::sync();                                      // prepass table visible to every wave of the team
+    float x0r[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x0r[i] = a.x0[b * NX + i];
+    const int NPAIR = (G + 1) >> 1;
+    for (int gp = wave; gp < NPAIR; gp += Team::NWAVES) {
+        const DuoPair pr = duo_pair(gp, G, h);
+        const bool valid = pr.own && (pr.g * 32 + j) < P;
+        const float* nz = a.noise + ((size_t)(b * G + pr.g) * H) * NN * 32 + j;
+        float* tj = a.traj + ((size_t)(b * G + pr.g) * (H + 1)) * NX * 32 + j;
+        float* xm = prows + (size_t)pr.g * PS;          // this group's row of per-step particle sums (SPEC.md §6.1/§6.3)
+        float x[NX], xn[NX], xi[NN];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = x0r[i];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) xi[i] = nz[i * 32];
+        if (store_traj && pr.own) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) tj[i * 32] = x[i];
+        }
+        if (want_mean) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { float s = group_bfly32(valid ? x[i] : 0.0f); if (j == 0 && pr.own) xm[i] = s; }
+        }
+        float J = 0.0f;
+        StepAux A;
+        for (int t = 0; t < H; ++t) {
+            float xin[NN];
+            if (t + 1 < H) {
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
+            }
+            duo_step_fwd<F16, false>(a, sm, ww, t, h, lane, pr.hasB, x, xi, xn, A, nullptr, nullptr);
+            float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
+            l = FMA(a.C.res_mult * A.eta, A.eta, l);
+            J = FMA(sm.disc[t], l, J);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xn[i];
+            if (t + 1 < H) {
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xi[i] = xin[i];
+            }
+            if (store_traj && pr.own) {
+                float* tp = tj + (size_t)(t + 1) * NX * 32;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) tp[i * 32] = x[i];
+            }
+            if (want_mean) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { float s = group_bfly32(valid ? x[i] : 0.0f); if (j == 0 && pr.own) xm[(t + 1) * NX + i] = s; }
+            }
+        }
+        const float T = group_bfly32(valid ? J : 0.0f);
+        if (j == 0 && pr.own) xm[PS - 1] = T;          // group total of the particle costs (last element of the group's row)
+    }
+    Team::sync();
+    const float tot = group_ordered_sum(prows, G, PS, PS - 1);
+    if (want_mean) {
+        for (int i = tid; i < (H + 1) * NX; i += Team::NT) xmean_out[i] = group_ordered_sum(prows, G, PS, i) * a.invP;
+    }
+    return FMA(tot, a.invP, cu);
+}
+
+// ------------------------------------------------------------------------------------------------
+// team-level cost + gradient (forward sweep with trajectory / checkpoint store, adjoint sweep). Same contract as block_cost_grad;
+// no register prefetch buffer: built for three waves per SIMD, which hide the latency of the adjoint's loads.
+// ------------------------------------------------------------------------------------------------
+template <class Team, int M, bool F16>
+DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const float* y, float* gout, int b, int tid) {
+    b = opaque_s(b); tid = opaque_v(tid);
+    const int H = a.H, G = a.G, P = a.P;
+    constexpr int nq = M + 4;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    Team::sync();
+    block_prepass<Team>(a, sm, y, tid);
+    const int PS = part_stride(H);
+    float* prows = a.part + (size_t)b * G * PS;
+    float cu = block_ucost<Team>(a, sm, y, tid);
+    Team::sync();
+    float x0r[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x0r[i] = a.x0[b * NX + i];
+    const int NPAIR = (G + 1) >> 1;
+    for (int gp = wave; gp < NPAIR; gp += Team::NWAVES) {
+        const DuoPair pr = duo_pair(gp, G, h);
+        const bool valid = pr.own && (pr.g * 32 + j) < P;
+        const int gA = 2 * gp, gB = pr.hasB ? 2 * gp + 1 : gA;
+        const float* nz = a.noise + ((size_t)(b * G + pr.g) * H) * NN * 32 + j;
+        float* tj = a.traj + ((size_t)(b * G + pr.g) * (H + 1)) * NX * 32 + j;
+        float* acA = a.act + ((size_t)(b * G + gA) * H) * ACT_STRIDE;       // checkpoint rows of the two groups (tiles: whole wave)
+        float* acB = a.act + ((size_t)(b * G + gB) * H) * ACT_STRIDE;
+        float* acS = (h ? acB : acA) + 1024 + j * 8;                         // this lane's particle: step scalars
+        float* Sq = prows + (size_t)pr.g * PS;                               // this group's row of per-step adjoint sums (SPEC.md §6.1)
+        float x[NX], xn[NX], xi[NN];
+        StepAux A;
+        // ---- forward sweep, x_t and the second hidden layer streamed to HBM ----
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = x0r[i];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) xi[i] = nz[i * 32];
+        if (pr.own) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) tj[i * 32] = x[i];
+        }
+        float J = 0.0f;
+        for (int t = 0; t < H; ++t) {
+            float xin[NN];
+            if (t + 1 < H) {
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
+            }
+            duo_step_fwd<F16, true>(a, sm, ww, t, h, lane, pr.hasB, x, xi, xn, A, acA + (size_t)t * ACT_STRIDE, acB + (size_t)t * ACT_STRIDE);
+            if (pr.own) {
+                float* sp = acS + (size_t)t * ACT_STRIDE;
+                *reinterpret_cast<float4*>(sp) = make_float4(A.eta, A.Fb[0], A.Fb[1], A.Fb[2]);
+                sp[4] = A.rn;
+            }
+            float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
+            l = FMA(a.C.res_mult * A.eta, A.eta, l);
+            J = FMA(sm.disc[t], l, J);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xn[i];
+            if (t + 1 < H) {
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xi[i] = xin[i];
+            }
+            if (pr.own) {
+                float* tp = tj + (size_t)(t + 1) * NX * 32;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) tp[i * 32] = x[i];
+            }
+        }
+        { const float T = group_bfly32(valid ? J : 0.0f); if (j == 0 && pr.own) Sq[PS - 1] = T; }
+        // ---- adjoint sweep: x (registers) currently holds x_H ----
+        float lam[NX], xt[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) lam[i] = 0.0f;
+        // this wave's own stores of x_t / activations must be visible to its loads (same CU: workgroup scope)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int t = H - 1; t >= 0; --t) {
+            const float* apA = acA + (size_t)t * ACT_STRIDE;
+            const float* apB = acB + (size_t)t * ACT_STRIDE;
+            float4 hA[4], hB[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hA[q] = *reinterpret_cast<const float4*>(apA + (q * 64 + lane) * 4);
+            const float* sp = acS + (size_t)t * ACT_STRIDE;
+            const float4 ns4 = *reinterpret_cast<const float4*>(sp);
+            const float nrn = sp[4];
+            {
+                const float* tp = tj + (size_t)t * NX * 32;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xt[i] = tp[i * 32];
+#pragma unroll
+                for (int i = 0; i < NN; ++i) xi[i] = nz[(t * NN + i) * 32];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hB[q] = *reinterpret_cast<const float4*>(apB + (q * 64 + lane) * 4);
+            // x = x_{t+1}: fold the stage-cost gradient into the incoming adjoint
+            const float dsc = sm.disc[t];
+            {
+                float gx[NX];
+                stage_cost<true>(a, x, sm.xref + (t + 1) * NX, gx);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) lam[i] = FMA(dsc, gx[i], lam[i]);
+            }
+            SCHED_PHASE();
+            const float* ust = sm.ust + t * UST;
+            float z[NN], zA[NN], zB[NN];
+            fwd_head(xt, A.Rm, z);
+#pragma unroll
+            for (int k = 0; k < NN; ++k) half_split(z[k], zA[k], zB[k]);
+            A.eta = ns4.x; A.Fb[0] = ns4.y; A.Fb[1] = ns4.z; A.Fb[2] = ns4.w; A.rn = nrn;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) A.Jom[i] = a.M.J[i] * xt[10 + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A.qn[i] = x[6 + i];   // q_{t+1}
+            const float ebc = dsc * ((2.0f * a.C.res_mult) * A.eta);
+            VjpTmp T;
+            float gq[12], lamn[NX];
+            vjp_head<M>(a, sm, t, xt, xi, A, lam, ebc, T, gq);
+            float eA, eB, obA[6], obB[6];
+            half_split(T.ebraw, eA, eB);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) half_split(T.ob[i], obA[i], obB[i]);
+            SCHED_PHASE();
+            float PzA[NN], PuA[M], PzB[NN], PuB[M], Pdead[7];
+            // pass A: recompute layer 1 only (6 MFMAs, 32 tanh; the rest of fwd_mlp_partials is dead code), layer 2 from the checkpoint
+            fwd_mlp_partials<F16, false>(a, sm, ww, ust, h, lane, zA, A, Pdead);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { A.h2[4 * q] = hA[q].x; A.h2[4 * q + 1] = hA[q].y; A.h2[4 * q + 2] = hA[q].z; A.h2[4 * q + 3] = hA[q].w; }
+            vjp_mlp_partials<M>(sm, h, lane, A, eA, obA, PzA, PuA);
+            SCHED_PHASE();
+            if (pr.hasB) {
+                fwd_mlp_partials<F16, false>(a, sm, ww, ust, h, lane, zB, A, Pdead);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { A.h2[4 * q] = hB[q].x; A.h2[4 * q + 1] = hB[q].y; A.h2[4 * q + 2] = hB[q].z; A.h2[4 * q + 3] = hB[q].w; }
+                vjp_mlp_partials<M>(sm, h, lane, A, eB, obB, PzB, PuB);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NN; ++k) PzB[k] = PzA[k];
+#pragma unroll
+                for (int jj = 0; jj < M; ++jj) PuB[jj] = PuA[jj];
+            }
+            SCHED_PHASE();
+            float zb[NN];
+#pragma unroll
+            for (int k = 0; k < NN; ++k) zb[k] = half_join_sum(PzA[k], PzB[k]);
+#pragma unroll
+            for (int jj = 0; jj < M; ++jj) gq[jj] = half_join_sum(PuA[jj], PuB[jj]);
+            vjp_tail(sm, t, xt, A, lam, T, zb, lamn);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { lam[i] = lamn[i]; x[i] = xt[i]; }
+            // particle sums of the nq per-step adjoint outputs: each lane half reduces its own group (halves never mix below xor 32)
+#pragma unroll
+            for (int k = 0; k < nq; ++k) {
+                const float s = group_bfly32(valid ? gq[k] : 0.0f);
+                if (j == 0 && pr.own) Sq[t * 12 + k] = s;
+            }
+        }
+    }
+    Team::sync();
+    const float tot = group_ordered_sum(prows, G, PS, PS - 1);
+    assemble_gradient<Team, M>(a, sm, y, gout, tid, [&](int q) { return group_ordered_sum(prows, G, PS, q); });
+    Team::sync();
+    return FMA(tot, a.invP, cu);
+}

@@ -32,6 +32,7 @@ struct LaunchOpts {
     int pk;            // -1: packed-f32 tanh instantiation when the grid leaves one wave per SIMD (default), 0 / 1: forced
     int ustg;          // -1: per-step control table in global memory when that raises occupancy (default), 0 / 1: forced
     int coop_launch;   // 1: hipLaunchCooperativeKernel for the cooperative layouts, 0: plain launch of a grid sized to be resident (default)
+    int duo;           // 1 / -1: throughput launches of multi-group instances in the duo tile layout (64 particles per wave; default), 0: one group per wave
     int coop_fence;    // 1: agent-scope release / acquire fences around the grid barrier, 0: sc1 write-through hand-off only (default)
 };
 struct KArgs {
@@ -71,6 +72,7 @@ struct KArgs {
     unsigned coop_spin;        // time one grid barrier may wait before it gives up, in ticks of the 100 MHz s_memrealtime clock (10 ns)
     float* coop_pp;            // [B][2][part_stride(H)][G*32]
     float* coop_ck;            // [B][P][H+1][160]
+    unsigned long long* work;  // [4] cumulative work of sdempc_solve_kernel launches: solves, gradient evaluations, forward-only rollouts, spare
     int fast;                  // SPEC.md §10: hardware transcendentals (selects the fastm translation unit; host-side switch)
     LaunchOpts opt;
 };

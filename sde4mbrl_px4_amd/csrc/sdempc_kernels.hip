@@ -83,6 +83,14 @@ struct TeamBlock8 {
     DI static int team() { return 0; }
     DI static void sync() { __syncthreads(); }
 };
+// Two waves on one instance: the duo tile layout (64 particles per wave, sdempc_duo.inc.h) of instances with up to four particle groups
+// (C2: P = 128). 128-thread workgroups, six per CU at three waves per SIMD.
+struct TeamBlock2 {
+    static constexpr int NT = 128, NWAVES = 2, IPB = 1, BNT = 128;
+    DI static int tid() { return threadIdx.x; }
+    DI static int team() { return 0; }
+    DI static void sync() { __syncthreads(); }
+};
 struct TeamWave {
     static constexpr int NT = 64, NWAVES = 1, IPB = 4, BNT = 256;
     DI static int tid() { return threadIdx.x & 63; }
@@ -247,12 +255,13 @@ DI float team_reduce256(const Smem& sm, int N, int tid, F&& elem) {
         if ((tid & 63) == 0 && tid < 256) sm.red[tid >> 6] = acc;
         Team::sync();
         return ((sm.red[0] + sm.red[1]) + sm.red[2]) + sm.red[3];
-    } else {
+    } else {                              // every wave of the team walks all four virtual waves itself: no LDS exchange, no barrier
+        const int ln = tid & 63;
         float w[4];
 #pragma unroll
         for (int vw = 0; vw < 4; ++vw) {
             float acc = 0.0f;
-            for (int e = vw * 64 + tid; e < N; e += 256) acc = elem(e, acc);
+            for (int e = vw * 64 + ln; e < N; e += 256) acc = elem(e, acc);
             w[vw] = wave_bfly64(acc);
         }
         return ((w[0] + w[1]) + w[2]) + w[3];
@@ -345,6 +354,8 @@ DI float group_ordered_sum(const float* rows, int G, int PS, int i) {
 #include "sdempc_lane.inc.h"
 
 #include "sdempc_coop.inc.h"
+
+#include "sdempc_duo.inc.h"
 
 // ------------------------------------------------------------------------------------------------
 // block-level rollout: expected cost of control sequence u (LDS). SPEC.md §5.3/§6/§7
@@ -633,16 +644,18 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 }
 
 // MODE 0: tile layout (32 particles per wave); 1: single-particle lane layout (P == 1); 2: cooperative lane layout (one particle per
-// wave, one instance over several workgroups)
+// wave, one instance over several workgroups); 3: duo tile layout (64 particles per wave, throughput launches)
 template <class Team, bool F16, bool PK, int MODE>
 DI float team_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, CoopCtx& CC, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
-    if constexpr (MODE == 2) return coop_rollout<Team>(a, sm, LW, CC, u, b, tid, xmean_out);
+    if constexpr (MODE == 3) return duo_rollout<Team, F16>(a, sm, ww, u, b, tid, store_traj, xmean_out);
+    else if constexpr (MODE == 2) return coop_rollout<Team>(a, sm, LW, CC, u, b, tid, xmean_out);
     else if constexpr (MODE == 1) return lane_rollout<Team>(a, sm, LW, u, b, tid, store_traj, xmean_out);
     else return block_rollout<Team, F16, PK>(a, sm, ww, u, b, tid, store_traj, xmean_out);
 }
 template <class Team, int M, bool F16, bool PK, bool PREF, int MODE>
 DI float team_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, CoopCtx& CC, const float* y, float* gout, int b, int tid) {
-    if constexpr (MODE == 2) return coop_cost_grad<Team, M>(a, sm, LW, CC, y, gout, b, tid);
+    if constexpr (MODE == 3) return duo_cost_grad<Team, M, F16>(a, sm, ww, y, gout, b, tid);
+    else if constexpr (MODE == 2) return coop_cost_grad<Team, M>(a, sm, LW, CC, y, gout, b, tid);
     else if constexpr (MODE == 1) return lane_cost_grad<Team, M>(a, sm, LW, y, gout, b, tid);
     else return block_cost_grad<Team, M, F16, PK, PREF>(a, sm, ww, y, gout, b, tid);
 }
@@ -678,7 +691,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     load_weights(a, sm, ww, threadIdx.x, Team::BNT);                                 \
     __syncthreads();                                                                 \
     if (b >= a.B) return; /* no workgroup-wide barrier below this line in TeamWave */ \
-    if constexpr (MODE != 0) load_lane_weights(a, LW, threadIdx.x & 63);             \
+    if constexpr (MODE == 1 || MODE == 2) load_lane_weights(a, LW, threadIdx.x & 63); \
     load_common<Team>(a, sm, b, tid);
 
 template <class Team, bool F16, int MODE = 0>
@@ -710,7 +723,7 @@ template <class Team, bool PK> constexpr int solve_waves_per_simd() { return PK 
 // USTG: the per-step control table [H][36] lives in global memory (KArgs::ustg, L1/L2-resident) instead of LDS: long horizons keep three
 // workgroups per CU (C5: 79 KB -> 50 KB per instance)
 template <class Team, int M, bool F16, bool PK = false, int MODE = 0, bool USTG = false>
-__global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : MODE ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
+__global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 || MODE == 2) ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE(USTG);
     const int m = a.m, N = a.H * m;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
@@ -724,10 +737,18 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : MODE ? 2 : s
     const float c_init = uni_f(team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xk, b, tid, false, nullptr));
     float c_x = c_init, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f;
     int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1;
+    // (c_y, g, |g|^2) are a pure function of yk: when an iteration leaves yk where it was (a plain gradient step from yk == xk that did not
+    // lower the cost — every iteration of a cold start until the line search has shrunk the step far enough) the next iteration would
+    // recompute the same bits, so they are kept instead. g lives in LDS and is written by the gradient evaluation only.
+    int yk_unchanged = 0, ngrad = 0;
+    float c_y = 0.0f;
     for (int k = 0; k < a.A.max_iter; ++k) {
-        c_x = uni_f(c_x); s = uni_f(s); sum_ls = uni_f(sum_ls); sum_s = uni_f(sum_s);
-        const float c_y = uni_f(team_cost_grad<Team, M, F16, PK, solve_waves_per_simd<Team, PK>() == 2, MODE>(a, sm, ww, LW, CC, yk, g, b, tid));
-        gsq = uni_f(block_dot<Team>(sm, g, g, N, tid));
+        c_x = uni_f(c_x); s = uni_f(s); sum_ls = uni_f(sum_ls); sum_s = uni_f(sum_s); c_y = uni_f(c_y); gsq = uni_f(gsq);
+        if (!yk_unchanged) {
+            c_y = uni_f(team_cost_grad<Team, M, F16, PK, solve_waves_per_simd<Team, PK>() == 2, MODE>(a, sm, ww, LW, CC, yk, g, b, tid));
+            gsq = uni_f(block_dot<Team>(sm, g, g, N, tid));
+            ngrad += 1;
+        }
         if (!(gsq < __builtin_inff())) break;   // SPEC.md §8 non-finite guard (team-uniform): keep xk, report gsq
         float c_n = 0.0f;
         int nls = 0;
@@ -757,6 +778,7 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : MODE ? 2 : s
         sum_ls = sum_ls + (float)nls; sum_s = sum_s + s; nit = k + 1; nls_tot += nls;
         int stop = (__builtin_fabsf(c_n - c_x) <= FMA(a.A.rtol, __builtin_fabsf(c_x), a.A.atol));
         Team::sync();
+        yk_unchanged = plain && !(c_n < c_x);       // yk == xk already and it stays there
         if (c_n < c_x) {
             for (int e = tid; e < N; e += Team::NT) { d1[e] = yk[e] - xn[e]; d2[e] = xn[e] - xk[e]; }
             float rs = uni_f(block_dot<Team>(sm, d1, d2, N, tid));
@@ -787,6 +809,11 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : MODE ? 2 : s
         const float fn = (float)nit;
         inf[0] = nit ? sum_ls / fn : 0.0f; inf[1] = s; inf[2] = fn; inf[3] = gsq; inf[4] = nit ? sum_s / fn : 0.0f;
         inf[5] = c_init; inf[6] = c_x; inf[7] = (float)nls_tot;
+        if (a.work) {   // work actually done (roofline accounting, sdempc_work_counters): solves, gradient evaluations, forward-only rollouts
+            __hip_atomic_fetch_add(a.work + 0, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.work + 1, (unsigned long long)ngrad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.work + 2, (unsigned long long)(nls_tot + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if constexpr (MODE == 2) {   // a grid barrier gave up (never seen in testing; bounded so that a fault cannot hang the GPU): poison the telemetry
             if (__hip_atomic_load(CC.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
                 for (int i = 0; i < 8; ++i) inf[i] = __builtin_nanf("");
@@ -830,12 +857,31 @@ static hipError_t launch_grad_team(const KArgs& a, hipStream_t st) {
 // workgroups leaves one wave per SIMD. Every dispatch decision below comes from the handle's LaunchOpts (sdempc_set_option); no
 // environment variable is read on the launch path.
 // Throughput launches of the workgroup-wide team: is the per-step control table better kept in global memory? (SDEMPC_OPT_USTG forces)
-bool use_global_ust(int H, int m, const LaunchOpts& o) {
+bool use_global_ust(int H, int m, const LaunchOpts& o, int nwaves = 4) {
     if (o.ustg >= 0) return o.ustg == 1;
-    // workgroups per CU: at most three by registers (launch bounds), otherwise what the 160 KB of LDS hold
-    const size_t cap = 160 * 1024;
-    auto per_cu = [&](size_t bytes) { const size_t n = bytes ? cap / bytes : 3; return n > 3 ? (size_t)3 : n; };
+    // workgroups per CU: by registers (launch bounds: three waves per SIMD = twelve per CU) at most 12 / nwaves, otherwise what the
+    // 160 KB of LDS hold
+    const size_t cap = 160 * 1024, by_regs = 12 / (size_t)nwaves;
+    auto per_cu = [&](size_t bytes) { const size_t n = bytes ? cap / bytes : by_regs; return n > by_regs ? by_regs : n; };
     return per_cu(smem_bytes(H, m, 1, false, false)) > per_cu(smem_bytes(H, m, 1));
+}
+// Duo tile layout (sdempc_duo.inc.h) for throughput launches of multi-group instances: two waves per instance up to four groups, four
+// waves beyond (SDEMPC_OPT_DUO = 0 keeps the one-group-per-wave layout: A/B, tests)
+template <class TeamD, int M, bool F16>
+static hipError_t launch_duo_m(const KArgs& a, hipStream_t st) {
+    if (use_global_ust(a.H, a.m, a.opt, TeamD::NWAVES) && a.ustg) return launch_k(sdempc_solve_kernel<TeamD, M, F16, false, 3, true>, a, st, 1, TeamD::BNT, false);
+    return launch_k(sdempc_solve_kernel<TeamD, M, F16, false, 3, false>, a, st, 1, TeamD::BNT);
+}
+template <bool F16>
+static hipError_t launch_duo(const KArgs& a, hipStream_t st) {
+    if (a.G <= 4) {
+        if (a.m == 4) return launch_duo_m<TeamBlock2, 4, F16>(a, st);
+        if (a.m == 6) return launch_duo_m<TeamBlock2, 6, F16>(a, st);
+        return launch_duo_m<TeamBlock2, 8, F16>(a, st);
+    }
+    if (a.m == 4) return launch_duo_m<TeamBlock, 4, F16>(a, st);
+    if (a.m == 6) return launch_duo_m<TeamBlock, 6, F16>(a, st);
+    return launch_duo_m<TeamBlock, 8, F16>(a, st);
 }
 template <class Team, bool F16>
 static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
@@ -857,6 +903,7 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
         }
     }
     if constexpr (Team::IPB == 1 && !FAST) {
+        if (a.G >= 2 && a.opt.duo != 0) return launch_duo<F16>(a, st);
         // long horizons: with the control table in LDS only two workgroups fit a CU; without it three do (the kernel is built for three)
         if (use_global_ust(a.H, a.m, a.opt) && a.ustg) {
             if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16, false, 0, true>, a, st, 1, Team::BNT, false);

@@ -24,9 +24,11 @@ DI void fwd_head(const float* x, float* Rm, float* z) {
     z[3] = x[10]; z[4] = x[11]; z[5] = x[12];
 }
 
-// ---- MLPs of a step in the MFMA tile layout (32 particles per wave): outputs o[6] and eta per particle ----
+// ---- MLPs of a step in the MFMA tile layout (32 particles per wave) ----
+// fwd_mlp_partials: the hidden tiles (A.h1d, A.h1n, A.h2) and the per-half partial chains of the seven output-layer dot products
+// (Po[0..5]: residual force / torque, Po[6]: density pre-activation); fwd_mlp_tiles adds the halves: (P0 + P1) + bias (SPEC.md §5.2).
 template <bool F16, bool PK>
-DI void fwd_mlp_tiles(const KArgs& a, const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, StepAux& A, float* o, float& eta_out) {
+DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, StepAux& A, float* Po) {
     // layer 1: C operand = per-step offsets (drift) / bias (density); K = 6 -> 3 MFMAs per tile
     f32x16 accD, accN;
 #pragma unroll
@@ -100,9 +102,8 @@ DI void fwd_mlp_tiles(const KArgs& a, const Smem& sm, const WaveW& ww, const flo
     A.h2 = acc2;
     SCHED_PHASE();
 
-    // output layers on the VALU: per-half partial chains, then (P0 + P1) + bias
+    // output layers on the VALU: per-half partial chains
     {
-        float Po[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Po[i] = 0.0f;
 #pragma unroll
@@ -114,10 +115,7 @@ DI void fwd_mlp_tiles(const KArgs& a, const Smem& sm, const WaveW& ww, const flo
             }
             SCHED_PHASE();
         }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) o[i] = xor32_sum(Po[i]) + a.M.b3[i];
     }
-    float eta;
     {
         float P = 0.0f;
 #pragma unroll
@@ -125,9 +123,16 @@ DI void fwd_mlp_tiles(const KArgs& a, const Smem& sm, const WaveW& ww, const flo
             float4 w4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
             P = FMA(w4.x, accN[4 * q], P); P = FMA(w4.y, accN[4 * q + 1], P); P = FMA(w4.z, accN[4 * q + 2], P); P = FMA(w4.w, accN[4 * q + 3], P);
         }
-        eta = sigmoid_spec(xor32_sum(P) + a.M.b3n);
+        Po[6] = P;
     }
-    eta_out = eta;
+}
+template <bool F16, bool PK>
+DI void fwd_mlp_tiles(const KArgs& a, const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, StepAux& A, float* o, float& eta_out) {
+    float Po[7];
+    fwd_mlp_partials<F16, PK>(a, sm, ww, ust, h, lane, z, A, Po);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = xor32_sum(Po[i]) + a.M.b3[i];
+    eta_out = sigmoid_spec(xor32_sum(Po[6]) + a.M.b3n);
     SCHED_PHASE();
 }
 
@@ -274,14 +279,12 @@ DI void vjp_head(const KArgs& a, const Smem& sm, int t, const float* x, const fl
 }
 
 // ---- MLP part in the MFMA tile layout: zb[6] = adjoint of z, gq[0..M-1] = W1u^T abar1 (per particle) ----
+// vjp_mlp_partials leaves the per-half partial chains Pz[6], Pu[M]; vjp_mlp_tiles adds the halves.
 template <int M>
-DI void vjp_mlp_tiles(const Smem& sm, int h, int lane, const StepAux& A, const VjpTmp& T, float* zb, float* gq) {
-    const float ebraw = T.ebraw;
-    const float* ob = T.ob;
+DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, float ebraw, const float* ob, float* Pz, float* Pu) {
     // MLP VJP. Order chosen to keep few tiles live: density tile first (frees h1n), then the drift
     // tile: abar2 on the VALU, W2^T abar2 by MFMA in the accumulator layout.
     {
-        float Pz[NN], Pu[M];
 #pragma unroll
         for (int k = 0; k < NN; ++k) Pz[k] = 0.0f;
 #pragma unroll
@@ -347,11 +350,16 @@ DI void vjp_mlp_tiles(const Smem& sm, int h, int lane, const StepAux& A, const V
             }
             SCHED_PHASE();
         }
-#pragma unroll
-        for (int k = 0; k < NN; ++k) zb[k] = xor32_sum(Pz[k]);
-#pragma unroll
-        for (int jj = 0; jj < M; ++jj) gq[jj] = xor32_sum(Pu[jj]);
     }
+}
+template <int M>
+DI void vjp_mlp_tiles(const Smem& sm, int h, int lane, const StepAux& A, const VjpTmp& T, float* zb, float* gq) {
+    float Pz[NN], Pu[M];
+    vjp_mlp_partials<M>(sm, h, lane, A, T.ebraw, T.ob, Pz, Pu);
+#pragma unroll
+    for (int k = 0; k < NN; ++k) zb[k] = xor32_sum(Pz[k]);
+#pragma unroll
+    for (int jj = 0; jj < M; ++jj) gq[jj] = xor32_sum(Pu[jj]);
     SCHED_PHASE();
 }
 

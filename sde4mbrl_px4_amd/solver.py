@@ -200,5 +200,11 @@ class SdeMpcSolver:
     def layout_fallbacks(self) -> int:
         return int(self.lib.sdempc_layout_fallbacks(self._h))
 
+    def work_counters(self, reset: bool = False):
+        """(solves, gradient evaluations, forward-only rollouts) done by this handle's solve launches so far (sdempc_work_counters)."""
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.sdempc_work_counters(self._h, out, int(reset)))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def last_kernel_ms(self) -> float:
         return float(self.lib.sdempc_last_kernel_ms(self._h))

@@ -9,6 +9,7 @@ from cases import CDIR, bits_differ
 from sde4mbrl_px4_amd import jax_shim
 from sde4mbrl_px4_amd import workload as W
 from sde4mbrl_px4_amd.sde_mpc_design import _next_key, load_mpc_problem
+from sde4mbrl_px4_amd.utils import enu2ned
 from sde4mbrl_px4_amd.worker import CONTROL_STATE, KEY2INDEX_INFO, MpcWorker, select_command
 
 pytestmark = pytest.mark.gpu
@@ -29,9 +30,13 @@ def test_m_mpc_matches_oracle_on_identical_seed():
     assert np.array_equal(np.stack([new_rng, sub]), orc.split(rng, 2)) and np.array_equal(rng2, new_rng)   # threefry split (SPEC.md §7.3)
     noise = orc.noise_from_key(sub, 32, 20)
     O = orc.Oracle(prob.cfg, prob.model)
-    uo, xe, info, _ = O.solve(x, W.constant_reference(xdes, 20), noise, np.asarray(st.yk), float(st.stepsize))
+    # frame contract (SPEC.md §1a): x arrives NED and is flipped into the solver's ENU frame, xdes is ENU, xevol comes back in x's frame
+    assert prob.convert_to_enu
+    uo, xe, info, _ = O.solve(enu2ned(x, np), W.constant_reference(xdes, 20), noise, np.asarray(st.yk), float(st.stepsize))
+    xe = np.stack([enu2ned(r, np) for r in xe])
     np.testing.assert_allclose(uopt, uo, rtol=1e-4, atol=1e-6)
     assert bits_differ(uopt, uo) == 0 and bits_differ(xevol, xe) == 0
+    np.testing.assert_allclose(xevol[0], x, atol=2e-7)                    # the predicted trajectory starts at the reported state
     assert float(st2.num_steps) == info[2] and float(st2.opt_cost) == info[6] and float(st2.init_cost) == info[5]
     assert not np.array_equal(rng, rng2)
     # same key -> same solution (identical seeds), new key -> different noise
@@ -141,3 +146,53 @@ def test_bench_two_ranks_self_started_on_one_gpu():
     assert rec["config"]["instances_per_gpu"] == 64
     assert rec["verified_instances"] == 2 and rec["verified_bit_exact"] is True
     assert rec["roofline"]["frac"] > 0 and rec["roofline"]["kernel_ms"] > 0
+
+
+def test_hold_mode_tracks_the_current_state_in_the_right_frame():
+    """Mode 'none' of the worker loop: xdes = enu2ned(curr_state) (sde_control.py:400) with the state reported in NED. The solver's
+    reference then equals its own initial state: the initial cost is the pure control / uncertainty cost of hovering there, far below the
+    cost of the same call with the target left in the wrong frame (what a solver that compared x and xdes frame-blind would track)."""
+    prob = load_mpc_problem(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"), overrides=SMALL)
+    x = W.random_initial_states(1, 9)[0]
+    x[0:3] = [1.5, -0.7, -2.0]                                           # NED: 2 m above the ground
+    rng = jax_shim.random.PRNGKey(3)
+    st = prob.m_reset(x=x, rng=rng, xdes=x)
+    _, st_hold, _, xevol = prob.m_mpc(x, rng, st, curr_t=0.0, xdes=enu2ned(x, np))
+    _, st_wrong, _, _ = prob.m_mpc(x, rng, st, curr_t=0.0, xdes=x)
+    assert float(st_hold.init_cost) < 0.05 * float(st_wrong.init_cost)
+    np.testing.assert_allclose(xevol[0], x, atol=2e-7)
+    assert abs(float(xevol[1, 2]) - float(x[2])) < 0.05                  # stays near its altitude over the first step (NED z)
+
+
+def test_worker_replay_matches_the_oracle_driven_fixture():
+    """the scripted 34-tick mode sequence (none -> pos -> idle -> traj -> pos -> none -> idle -> traj) through the HIP
+    path, compared per tick with the committed fixture an oracle-backed worker produced (tests/golden/make_worker_replay.py): u_opt (f32),
+    w_opt (f64), opt_info[1:8] and the rows `select_command` picks at four lags — bit for bit."""
+    import replay
+    fx = dict(np.load(replay.FIXTURE))
+    got = replay.run(oracle=False)
+    assert np.array_equal(got["states"], fx["states"]) and np.array_equal(got["modes"], fx["modes"])
+    for k in range(len(replay.MODES)):
+        assert bits_differ(got["u_opt"][k], fx["u_opt"][k]) == 0, (k, replay.MODES[k])
+        assert np.array_equal(got["w_opt"][k].view(np.uint64), fx["w_opt"][k].view(np.uint64)), (k, replay.MODES[k])
+        assert bits_differ(got["opt_info"][k], fx["opt_info"][k]) == 0, (k, replay.MODES[k], got["opt_info"][k], fx["opt_info"][k])
+    assert np.array_equal(got["sel_idx"], fx["sel_idx"]) and np.array_equal(got["sel_u"], fx["sel_u"]) and np.array_equal(got["sel_w"], fx["sel_w"])
+
+
+def test_in_process_worker_solves_with_prefork_variable_set(monkeypatch):
+    """SDEMPC_PREFORK=shape in the environment of a process that never forks (notebook, in-process MpcWorker): only the first call of a
+    jax_shim-compiled callable is a shape probe; the worker and every later call solve for real."""
+    monkeypatch.setenv("SDEMPC_PREFORK", "shape")
+    traj = load_mpc_problem(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml"), horizon=12, num_particles=32, trajectory=W.lemniscate_state, overrides=SMALL)
+    pos = load_mpc_problem(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"), horizon=10, overrides=SMALL)
+    wk = MpcWorker(traj, pos, seed=10)
+    x = W.random_initial_states(1, 5)[0]
+    uopt, wopt, st = wk.step(x, CONTROL_STATE["pos"], 0.0, W.HOVER, 1e6)
+    assert float(st.num_steps) > 0 and np.abs(uopt - 0.71).max() > 1e-6
+    x0 = W.HOVER.copy(); rng = jax_shim.random.PRNGKey(1)
+    st0 = pos.m_reset(x=x0, rng=rng, xdes=x0)
+    mpc_c = jax_shim.jit(pos.m_mpc).lower(x0, rng, st0, curr_t=0.0, xdes=x0).compile()
+    u1, s1, _, _ = mpc_c(x, rng, st0, curr_t=0.0, xdes=W.HOVER)          # first call: probe (warm start returned, no iterations)
+    u2, s2, _, _ = mpc_c(x, rng, st0, curr_t=0.0, xdes=W.HOVER)          # second call: a real solve
+    assert s1 is st0 and np.all(np.array(u1) == np.float32(0.71))
+    assert float(s2.num_steps) > 0 and np.abs(np.array(u2) - 0.71).max() > 1e-6

@@ -592,3 +592,111 @@ def test_global_control_table_instantiation_bit_exact(H, P, m):
         for flag in ("1", "0", "auto"):
             ug, xg, ig = res[flag]
             assert bits_differ(ug[b], uo) == 0 and bits_differ(xg[b], xe) == 0 and bits_differ(ig[b], io) == 0, (flag, b)
+
+
+# ---- every single-GPU BASELINE config at FULL size, in the kernel instantiation the bench times ---------------------------------------
+# A batch larger than the number of CUs makes launch_solve_team pick the throughput instantiation by itself (three waves per SIMD, scalar
+# tanh: sdempc_solve_kernel<TeamBlock, m, F16, false, 0, USTG> — the kernel `bench.py` names in roofline.kernel), with no option forced.
+def _full_size_case(cfg_name, B, iters, mlp="f32", sample=(0, 1), seed=0, stepsize=None):
+    from sde4mbrl_px4_amd import prng
+    cfg = load_mpc_config(os.path.join(CDIR, cfg_name)).replace(max_iter=iters, max_no_improvement_iter=iters, mlp_dtype=mlp)
+    model = synthetic_iris() if cfg.num_motors == 4 else synthetic_hexa()
+    pos = "posctrl" in cfg_name
+    H, P = cfg.horizon, cfg.num_particles
+    x0 = W.random_initial_states(B, seed)
+    xref = np.stack([W.constant_reference(W.HOVER, H) if pos else W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(B)])
+    keys = prng.split(prng.PRNGKey(10), B)                                # launch seed 10 (iris_sdectrl.launch:8), one key per instance
+    S = _solver(cfg, model, B)
+    assert S.get_option("pk") == -1 and S.get_option("coop") == 1 and S.get_option("ustg") == -1     # nothing forced
+    yk, i0 = S.reset()
+    u0 = np.tile(yk[None], (B, 1, 1))
+    s0 = np.full(B, i0["stepsize"] if stepsize is None else stepsize, np.float32)
+    uopt, xevol, info = S.solve_keys(x0, xref, keys, u0, s0)
+    assert S.get_option("device_cus") < B                                 # grid > CUs: the throughput instantiation ran
+    assert np.all(info[:, 2] == iters) and np.all(info[:, 6] <= info[:, 5]) and uopt.min() >= 1e-4 and uopt.max() <= 1.0
+    O = orc.Oracle(cfg, model)
+    res = []
+    for b in sample:
+        noise = orc.noise_from_key(keys[b], P, H)
+        res.append((b, O.solve(x0[b], xref[b], noise, u0[b], float(s0[b]))[:3]))
+    S.close()
+    return uopt, xevol, info, res
+
+
+@pytest.mark.parametrize("cfg_name,B,iters,sample", [
+    ("c2_iris_traj_h50_p128.yaml", 512, 10, (0, 100, 255, 256, 300, 511)),      # C2: the bench workload (four particle groups = four waves)
+    ("c3_hexa_traj_h50_p256.yaml", 320, 6, (0, 257, 319)),                      # C3: six rotors, eight particle groups on four waves
+    ("c1_iris_posctrl_h20_p32.yaml", 1280, 20, (0, 1025, 1279)),                # C1 geometry: one wave per instance, four instances per workgroup
+])
+def test_baseline_configs_full_size_throughput_kernel_bit_exact(cfg_name, B, iters, sample):
+    uopt, xevol, info, res = _full_size_case(cfg_name, B, iters, sample=sample)
+    for b, (uo, xe, io) in res:
+        _close(uopt[b], uo, "uopt")
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0, b
+
+
+def test_c5_full_size_solve_f32_bit_exact_and_f16_within_tolerance():
+    """BASELINE config C5 (H=200, P=1024: 32 particle groups per instance, control table in global memory) as a SOLVE at full size, B > CUs:
+    f32 bit for bit against the oracle; fp16-operand MLP mode (the mode C5 names) against the oracle's emulation within the north star's
+    1e-4 on the controls (few iterations: the decisions coincide; drift over full-length solves: DESIGN.md §2, tools/mode_drift.py).
+    The 10 s open-loop horizon from a random initial state is violently ill-conditioned (|g|^2 ~ 1e16): the solve starts from a step size of
+    1e-11 so that its three iterations all take steps (from the YAML's 0.01 the line search only shrinks the step for the first dozens)."""
+    kw = dict(sample=(259,), stepsize=1e-11)
+    uopt, xevol, info, res = _full_size_case("c5_iris_traj_h200_p1024.yaml", 260, 3, **kw)
+    for b, (uo, xe, io) in res:
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0
+    assert info[259, 6] < 0.7 * info[259, 5] and np.abs(uopt[259] - 0.71).max() > 1e-4      # the iterations moved the controls
+    uh, xh, ih, resh = _full_size_case("c5_iris_traj_h200_p1024.yaml", 260, 3, mlp="f16", **kw)
+    for b, (uo, xe, io) in resh:
+        np.testing.assert_allclose(uh[b], uo, rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(ih[b, 5:7], io[5:7], rtol=2e-5)
+        assert ih[b, 7] == io[7]                                          # same line-search decisions
+    assert bits_differ(uh[259], uopt[259]) > 0                            # and genuinely another arithmetic than f32
+
+
+# ---- duo tile layout (64 particles per wave) against the one-group-per-wave layout and the oracle -------------------------------------
+@pytest.mark.parametrize("H,P,m", [(9, 33, 4), (12, 64, 4), (7, 65, 6), (10, 128, 4), (6, 160, 4), (5, 257, 8), (200, 40, 4), (50, 300, 6)])
+def test_duo_tile_layout_bit_exact(H, P, m):
+    """SDEMPC_OPT_PK = 0 pins the throughput instantiation on a small batch; SDEMPC_OPT_DUO picks 64 particles per wave (default) or one
+    32-particle group per wave. Odd group counts (a pair without a group B), ragged last groups, two- and four-wave teams, the control
+    table in LDS and in global memory: all give the oracle's bits."""
+    kw = dict(horizon=H, num_short_dt=max(1, H // 2), long_step_dt=0.1, num_particles=P, u_slew_coeff=1.0, max_iter=5, max_no_improvement_iter=5)
+    if m != 4:
+        kw.update(input_id=list(range(m)), input_bound=[[1e-4, 1.0]] * m, uref=[0.42] * m)
+    cfg = MPCConfig(**kw)
+    model = synthetic_multirotor(m, seed=3) if m == 8 else (synthetic_iris() if m == 4 else synthetic_hexa())
+    B = 3
+    x0, xref, noise, u = _problem(cfg, B, 13)
+    s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
+    O = orc.Oracle(cfg, model)
+    ref = [O.solve(x0[b], xref[b], noise[b], u[b], float(s0[b]))[:3] for b in range(B)]
+    for opts in (dict(duo=1), dict(duo=0), dict(duo=1, ustg=1), dict(duo=1, ustg=0)):
+        S = _solver(cfg, model, B, coop=0, pk=0, **opts)
+        ug, xg, ig = S.solve(x0, xref, noise, u, s0)
+        S.close()
+        for b in range(B):
+            assert bits_differ(ug[b], ref[b][0]) == 0 and bits_differ(xg[b], ref[b][1]) == 0 and bits_differ(ig[b], ref[b][2]) == 0, (opts, b)
+
+
+def test_work_counters_and_gradient_reuse():
+    """sdempc_work_counters: a cold start whose first iterations fail at the same point (the line search only shrinks the step) re-uses the
+    gradient instead of re-evaluating it: fewer gradient evaluations than iterations, identical results (the oracle evaluates every one)."""
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(max_iter=14, max_no_improvement_iter=14)
+    model = synthetic_iris()
+    B = 2
+    x0, xref, noise, _ = _problem(cfg, B, 31)
+    S = _solver(cfg, model, B, coop=0)
+    yk, i0 = S.reset()
+    u0 = np.tile(yk[None], (B, 1, 1))
+    s0 = np.full(B, i0["stepsize"], np.float32)
+    ug, xg, ig = S.solve(x0, xref, noise, u0, s0)
+    solves, grads, fwd = S.work_counters()
+    assert solves == B and fwd == int(ig[:, 7].sum()) + 2 * B
+    assert grads < int(ig[:, 2].sum()) and grads >= B                    # some iterations re-used their gradient
+    S.work_counters(reset=True)
+    assert S.work_counters() == (0, 0, 0)
+    O = orc.Oracle(cfg, model)
+    for b in range(B):
+        uo, xe, io, _ = O.solve(x0[b], xref[b], noise[b], u0[b], float(s0[b]))
+        assert bits_differ(ug[b], uo) == 0 and bits_differ(xg[b], xe) == 0 and bits_differ(ig[b], io) == 0
+    S.close()

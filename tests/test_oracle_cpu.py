@@ -183,3 +183,16 @@ def test_f16_mode_is_close_to_f32_mode():
     assert c16 != c32                                       # the quantisation is really applied
     assert abs(c16 - c32) <= 1e-3 * abs(c32)
     assert np.abs(g16 - g32).max() <= 2e-2 * np.abs(g32).max()
+
+
+def test_worker_replay_fixture_is_reproduced_by_the_oracle_backed_worker():
+    """tests/golden/worker_replay.npz (SURVEY.md §8c last row, §8f N1): the committed fixture is what the worker loop (worker.py =
+    sde_control.py:365-450) produces today when its solver is the CPU oracle — guards the fixture against drift of either."""
+    import replay
+    fx = dict(np.load(replay.FIXTURE))
+    got = replay.run(oracle=True)
+    assert set(got) == set(fx)
+    for k in fx:
+        a, b = np.ascontiguousarray(got[k]), np.ascontiguousarray(fx[k])
+        assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes(), k
+    assert len(replay.MODES) >= 30 and fx["sel_idx"].max() == 11 and fx["sel_idx"].min() == 0

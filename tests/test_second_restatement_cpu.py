@@ -1,0 +1,110 @@
+"""The second, independent restatement of SPEC.md (oracle/sde_mpc_numpy.py: NumPy float32 with an exact software fma, all particles at
+once; torch float64 autograd for the gradient) against the C oracle. Pins the oracle against a shared-mistake-free second writing of the
+same specification; both remain unpinned against the reference's JAX path, which cannot run here."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import orc
+from cases import ROOT, bits_differ
+from sde4mbrl_px4_amd import MPCConfig, synthetic_hexa, synthetic_iris, synthetic_multirotor
+from sde4mbrl_px4_amd import workload as W
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import sde_mpc_numpy as R2  # noqa: E402
+
+
+def _case(name):
+    if name == "iris":
+        cfg = MPCConfig(horizon=8, num_short_dt=5, long_step_dt=0.1, num_particles=40, u_slew_coeff=1.0, max_iter=7, max_no_improvement_iter=7)
+        model = synthetic_iris()
+    elif name == "hexa_slew_constr":
+        cfg = MPCConfig(horizon=6, num_short_dt=6, num_particles=33, discount=0.95, input_id=list(range(6)), input_bound=[[1e-4, 1.0]] * 6, uref=[0.42] * 6,
+                        u_slew_coeff=0.5, u_slew_constr=[[-0.05, 0.04]] * 6, u_slew_constr_coeff=7.0, res_mult=0.5, max_iter=6, max_no_improvement_iter=3,
+                        moment_scale=0.8, ls_maxls=3)
+        model = synthetic_hexa()
+    else:   # one particle, three rotors, fixed step size, no bounds
+        cfg = MPCConfig(horizon=9, num_short_dt=9, num_particles=1, input_id=[0, 1, 2], input_bound=[[1e-4, 1.0]] * 3, uref=[0.6] * 3, enforce_ubound=False,
+                        ls_maxls=0, stepsize=2e-4, max_iter=5, max_no_improvement_iter=5)
+        model = synthetic_multirotor(3, seed=4)
+    H, P, m = cfg.horizon, cfg.num_particles, cfg.num_motors
+    x0 = W.random_initial_states(1, 17)[0]
+    xref = W.reference_window(0.3, cfg.time_steps)
+    noise = W.make_noise(1, P, H, 5)[0]
+    u = np.clip(np.asarray(cfg.uref, np.float32) + 0.1 * np.random.default_rng(2).standard_normal((H, m)), 1e-4, 1).astype(np.float32)
+    return cfg, model, x0, xref, noise, u
+
+
+def test_software_fma_is_exact():
+    rng = np.random.default_rng(0)
+    a, b, c = (rng.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, 20000).astype(np.float32) for _ in range(3))
+    c = np.where(rng.random(20000) < 0.5, -(a * b), c).astype(np.float32)          # heavy cancellation: the case double rounding gets wrong
+    got = R2.fma(a, b, c)
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.fmaf.restype = ctypes.c_float
+    libm.fmaf.argtypes = [ctypes.c_float] * 3
+    want = np.array([libm.fmaf(float(x), float(y), float(z)) for x, y, z in zip(a, b, c)], np.float32)
+    assert bits_differ(got, want) == 0
+
+
+def test_elementary_functions_match_the_c_oracle_bit_for_bit():
+    x = np.concatenate([np.linspace(-12, 12, 4001), np.random.default_rng(1).standard_normal(2000) * 3]).astype(np.float32)
+    x = x[: (x.size // 4) * 4]
+    t = R2.tanh4(x.reshape(-1, 4)).reshape(-1)
+    want = np.zeros_like(x)
+    L = orc.lib()
+    import ctypes as C
+    for i in range(0, x.size, 4):
+        L.orc_tanh4(x[i:i + 4].ctypes.data_as(C.POINTER(C.c_float)), want[i:i + 4].ctypes.data_as(C.POINTER(C.c_float)))
+    assert bits_differ(t, want) == 0
+    pos = np.abs(x) + np.float32(1e-3)
+    assert bits_differ(R2.rcp(pos), np.array([L.orc_rcp(float(v)) for v in pos], np.float32)) == 0
+    assert bits_differ(R2.rsqrt(pos), np.array([L.orc_rsqrt(float(v)) for v in pos], np.float32)) == 0
+    assert bits_differ(R2.sigmoid(x * 4), np.array([L.orc_sigmoid(float(v)) for v in x * 4], np.float32)) == 0
+
+
+@pytest.mark.parametrize("name", ["iris", "hexa_slew_constr", "single_particle"])
+def test_forward_rollout_bit_identical_to_the_c_oracle(name):
+    cfg, model, x0, xref, noise, u = _case(name)
+    O, N = orc.Oracle(cfg, model), R2.Restatement(cfg, model)
+    c_o, traj_o, mean_o = O.rollout(x0, u, xref, noise, want_traj=True, want_mean=True)
+    c_n, traj_n, mean_n = N.rollout(x0, u, xref, noise)
+    assert np.float32(c_o) == c_n and bits_differ(traj_n, traj_o) == 0 and bits_differ(mean_n, mean_o) == 0
+
+
+@pytest.mark.parametrize("name", ["iris", "hexa_slew_constr", "single_particle"])
+def test_optimiser_loop_bit_identical_to_the_c_oracle(name):
+    """SPEC.md §8 written a second time (Python control flow, NumPy reductions), fed by the C oracle's cost / gradient: same iterates,
+    same line-search decisions, same telemetry."""
+    cfg, model, x0, xref, noise, u = _case(name)
+    O, N = orc.Oracle(cfg, model), R2.Restatement(cfg, model)
+    s0 = cfg.ls_init_stepsize if cfg.ls_maxls > 0 else cfg.stepsize
+    uo, _, info_o, _ = O.solve(x0, xref, noise, u, s0)
+    cost = lambda uu: np.float32(O.rollout(x0, uu, xref, noise)[0])
+    grad = lambda uu: (lambda c, g: (np.float32(c), g.astype(np.float32)))(*O.grad(x0, uu, xref, noise))
+    un, info_n = N.solve(cost, grad, u, s0)
+    assert info_o[2] >= 3 and bits_differ(un, uo) == 0 and bits_differ(info_n, info_o) == 0
+
+
+@pytest.mark.parametrize("name", ["iris", "hexa_slew_constr", "single_particle"])
+def test_adjoint_against_reverse_mode_autodiff(name):
+    """The hand-derived vector-Jacobian product of the oracle (SPEC.md §5.4-§5.5) against torch.autograd on a float64 writing of the model
+    that shares no code with it: float64 oracle build to 1e-6 (its tables — discount powers, sigma sqrt(dt) — are computed in float64, here
+    in float32 as SPEC.md says), float32 oracle (software tanh, f32 accumulation) to 2e-4 of the largest entry."""
+    import torch
+    cfg, model, x0, xref, noise, u = _case(name)
+    ut = torch.tensor(u.astype(np.float64), requires_grad=True)
+    J = R2.torch_cost(cfg, model, x0, ut, xref, noise)
+    J.backward()
+    g_ad = ut.grad.numpy()
+    c64, g64 = orc.Oracle(cfg, model, double=True).grad(x0, u, xref, noise)
+    c32, g32 = orc.Oracle(cfg, model).grad(x0, u, xref, noise)
+    scale = np.abs(g_ad).max()
+    Jv = float(J.detach())
+    assert abs(c64 - Jv) <= 1e-6 * abs(Jv)
+    np.testing.assert_allclose(g64, g_ad, rtol=0, atol=1e-6 * scale)
+    np.testing.assert_allclose(g32, g_ad, rtol=0, atol=2e-4 * scale)
+    assert abs(c32 - Jv) <= 2e-5 * abs(Jv)

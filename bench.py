@@ -79,10 +79,11 @@ def cpu_solve_instances(cfg, model, n_threads, x0, xref, keys, u0, s0, fast=Fals
     """CPU leg, kind 'port': the C oracle (CPU restatement of SPEC.md) solves the given instances — the first ones of the GPU
     batch, noise derived from the same threefry keys — one solve at a time per thread, all usable host cores. fast=False: the
     bit-exact -O2 build the parity tests use (its outputs are what the GPU results are compared with); fast=True: the same source
-    built -O3 -march=native (oracle/Makefile: liborc_fast.so), the credible CPU timing. Returns (solves/s, wall s, outputs)."""
+    built as the particle-vectorised timing build (oracle/Makefile: liborc_vec.so, 16 particles per call through GCC vector
+    extensions, -O3 -march=native, contraction allowed: tolerance parity), the credible CPU timing. Returns (solves/s, wall s, outputs)."""
     orc = cpu_oracle()
     n = len(x0)
-    O = [orc.Oracle(cfg, model, fast=fast) for _ in range(n_threads)]
+    O = [orc.Oracle(cfg, model, vec=fast) for _ in range(n_threads)]
     P, H = cfg.num_particles, cfg.horizon
     noise = [None] * n
     out = [None] * n
@@ -124,25 +125,27 @@ def words_differ(a, b):
 
 
 def cpu_c1_single_solve_ms(model_blob, reps=3):
-    """BASELINE config 1 (Iris posctrl YAML, H=20, 32 particles, CPU path, single solve, no GPU): one thread, -O3 -march=native
-    build of the oracle, median wall time of a full cold-start solve."""
+    """BASELINE config 1 (Iris posctrl YAML, H=20, 32 particles, CPU path, single solve, no GPU): one thread, median wall time of a full
+    cold-start solve, by the particle-vectorised timing build and by the bit-exact scalar build."""
     orc = cpu_oracle()
     from sde4mbrl_px4_amd import load_mpc_config, prng
     from sde4mbrl_px4_amd import workload as W
     cfg = load_mpc_config(os.path.join(ROOT, "configs", "c1_iris_posctrl_h20_p32.yaml"))
-    O = orc.Oracle(cfg, model_blob, fast=True)
     x0 = W.random_initial_states(reps, 0)
     keys = prng.split(prng.PRNGKey(10), reps)
     u0 = np.tile(np.asarray(cfg.uref, np.float32)[None], (cfg.horizon, 1))
-    ms, nit = [], []
-    for r in range(reps):
-        noise = orc.noise_from_key(keys[r], cfg.num_particles, cfg.horizon)
-        xref = W.constant_reference(W.HOVER, cfg.horizon)
-        t = time.perf_counter()
-        _, _, info, _ = O.solve(x0[r], xref, noise, u0, cfg.ls_init_stepsize)
-        ms.append((time.perf_counter() - t) * 1e3)
-        nit.append(float(info[2]))
-    return float(np.median(ms)), float(np.mean(nit)), cfg
+    out = {}
+    for kind, O in (("vec", orc.Oracle(cfg, model_blob, vec=True)), ("scalar", orc.Oracle(cfg, model_blob))):
+        ms, nit = [], []
+        for r in range(reps):
+            noise = orc.noise_from_key(keys[r], cfg.num_particles, cfg.horizon)
+            xref = W.constant_reference(W.HOVER, cfg.horizon)
+            t = time.perf_counter()
+            _, _, info, _ = O.solve(x0[r], xref, noise, u0, cfg.ls_init_stepsize)
+            ms.append((time.perf_counter() - t) * 1e3)
+            nit.append(float(info[2]))
+        out[kind] = (float(np.median(ms)), float(np.mean(nit)))
+    return out, cfg
 
 
 def spawn_ranks(n, argv):
@@ -364,17 +367,18 @@ def main():
             n_cpu = min(2 * nthr, B)
             v, dt, outs_f = cpu_solve_instances(cfg, blob, nthr, x0_h[:n_cpu], xref_h[:n_cpu], keys[:n_cpu], u0_h[:n_cpu], s0, fast=True)
             md = max(float(np.max(np.abs(outs_f[i][0] - uopt_h[i]))) for i in range(n_cpu))
-            c1_ms, c1_nit, c1cfg = cpu_c1_single_solve_ms(blob)
+            c1, c1cfg = cpu_c1_single_solve_ms(blob)
             out["cpu_baseline"] = {"value": v, "unit": "solves/s", "cores": nthr, "kind": "port",
                                    "threads_used": nthr, "os_cpu_count": os.cpu_count(), "usable_cores": effective_cores(),
                                    "sample": f"{n_cpu} solves of the same workload (the first {n_cpu} instances of the GPU batch, one solve at a time per thread, "
                                              f"{nthr} threads = usable host cores: os.cpu_count {os.cpu_count()}, cgroup/affinity limit {effective_cores()}; {dt:.1f} s wall) "
-                                             "by the C oracle built -O3 -march=native (CPU restatement of SPEC.md, not the reference JAX path: that cannot run here); "
+                                             "by the particle-vectorised build of the C oracle (oracle/sde_mpc_oracle.c -DORC_VEC: 16 particles per call, -O3 -march=native, "
+                                             "contraction allowed; CPU restatement of SPEC.md, not the reference JAX path: that cannot run here); "
                                              f"max |uopt - GPU uopt| over the sample {md:.1e}",
                                    "value_bit_exact_build": (n_ver / dt_exact) if n_ver > 0 and args.mlp_dtype == "f32" else None,
-                                   "cpu_c1_single_solve_ms": c1_ms,
-                                   "cpu_c1_note": f"BASELINE config 1: {os.path.basename('c1_iris_posctrl_h20_p32.yaml')} H={c1cfg.horizon} P={c1cfg.num_particles}, one cold-start solve "
-                                                  f"(N_it {c1_nit:.0f}) on ONE thread, -O3 -march=native oracle build, median of 3"}
+                                   "cpu_c1_single_solve_ms": c1["vec"][0], "cpu_c1_single_solve_ms_scalar_build": c1["scalar"][0],
+                                   "cpu_c1_note": f"BASELINE config 1: c1_iris_posctrl_h20_p32.yaml H={c1cfg.horizon} P={c1cfg.num_particles}, one cold-start solve "
+                                                  f"(N_it {c1['vec'][1]:.0f}) on ONE thread, median of 3: particle-vectorised build / bit-exact scalar -O2 build"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -43,6 +43,40 @@ typedef float real;
 #endif
 #define R(x) ((real)(x))
 
+/* Lane blocks. The per-particle functions below (elementary functions, step_fwd, stage_cost, step_vjp) are written on the type `preal`:
+ * one particle per call in the two checker builds (preal = real, VL = 1: the bit-exact float32 oracle and the float64 build), and
+ * VL = 16 particles per call in the TIMING build (-DORC_VEC: GCC vector extensions, AVX-512 / AVX2 code under -O3 -march=native,
+ * exported as orcv_*; bench.py's cpu_baseline leg). The vector build lets the compiler contract a*b+c and is therefore compared with
+ * the checker build within a tolerance only (tests/test_oracle_cpu.py); it is never used as the checker. */
+#ifdef ORC_VEC
+#undef NAME
+#define NAME(x) orcv_##x
+#define VL 16
+typedef float preal __attribute__((vector_size(4 * VL)));
+typedef uint32_t puint __attribute__((vector_size(4 * VL)));
+typedef int32_t pint __attribute__((vector_size(4 * VL)));
+#define PFMA(a, b, c) ((a) * (b) + (c))                 /* contracted to vfmadd by -ffp-contract=fast */
+#define PUB static inline                               /* the elementary functions are internal in this build */
+static inline preal psel(pint m, preal a, preal b) { return (preal)(((puint)m & (puint)a) | (~(puint)m & (puint)b)); }
+static inline preal pclamp(preal x, float lo, float hi) {
+    preal l = lo - (preal){0}, h = hi - (preal){0};
+    x = psel(x > l, x, l);                              /* NaN -> lo, as in the checker build */
+    return psel(x > h, h, x);
+}
+static inline preal pbroadcast(real v) { return v - (preal){0}; }
+#define PLANE(v, l) ((v)[l])
+#define F16Q(on, v) (v)                                 /* fp16-operand mode is not built for the timing build (ctx_init refuses it) */
+#else
+#define VL 1
+typedef real preal;
+typedef uint32_t puint;
+#define PFMA(a, b, c) FMA(a, b, c)
+#define PUB
+#define pbroadcast(v) (v)
+#define PLANE(v, l) (v)
+#define F16Q(on, v) ((on) ? f16_rtz(v) : (v))
+#endif
+
 #define NX 13
 #define NN 6
 #define HID 32
@@ -53,56 +87,59 @@ typedef float real;
 /* SPEC.md §3: elementary functions                                                            */
 /* ------------------------------------------------------------------------------------------- */
 #ifndef ORC_DOUBLE
-static inline float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-static inline uint32_t as_u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline preal as_f(puint u) { preal f; memcpy(&f, &u, sizeof f); return f; }
+static inline puint as_u(preal f) { puint u; memcpy(&u, &f, sizeof u); return u; }
+#ifndef ORC_VEC
+#define pclamp(x, lo, hi) fminf(fmaxf((x), (lo)), (hi))
+#endif
 
 /* reciprocal of d > 0: magic-constant seed + 3 Newton steps, every step an fma */
-float NAME(rcp)(float d) {
-    float y = as_f(0x7EF311C7u - as_u(d));
-    for (int i = 0; i < 3; ++i) { float e = fmaf(-d, y, 1.0f); y = fmaf(y, e, y); }
+PUB preal NAME(rcp)(preal d) {
+    preal y = as_f(0x7EF311C7u - as_u(d));
+    for (int i = 0; i < 3; ++i) { preal e = PFMA(-d, y, 1.0f); y = PFMA(y, e, y); }
     return y;
 }
 /* 1/sqrt(a), a > 0: magic seed + 3 Newton steps */
-float NAME(rsqrt)(float a) {
-    float y = as_f(0x5F3759DFu - (as_u(a) >> 1));
-    float h = 0.5f * a;
-    for (int i = 0; i < 3; ++i) { float t = y * y; t = fmaf(-h, t, 1.5f); y = y * t; }
+PUB preal NAME(rsqrt)(preal a) {
+    preal y = as_f(0x5F3759DFu - (as_u(a) >> 1));
+    preal h = 0.5f * a;
+    for (int i = 0; i < 3; ++i) { preal t = y * y; t = PFMA(-h, t, 1.5f); y = y * t; }
     return y;
 }
 /* 2^(x*c) for |x*c| <= 64 (SPEC.md §3.3): t2 = fma(x,c,1.5*2^23) holds n = rne(x*c) in its low
  * mantissa bits; f = fma(x,c,-n) in [-0.5,0.5]; degree-5 polynomial; exponent add by integer shift */
-static inline float exp2_spec(float x, float c) {
-    float t2 = fmaf(x, c, 12582912.0f);
-    float n = t2 - 12582912.0f;
-    float f = fmaf(x, c, -n);
-    float p = 0.001327647129073739f;
-    p = fmaf(p, f, 0.009675540961325169f);
-    p = fmaf(p, f, 0.05550713092088699f);
-    p = fmaf(p, f, 0.24022120237350464f);
-    p = fmaf(p, f, 0.6931469440460205f);
-    p = fmaf(p, f, 1.0000001192092896f);
+static inline preal exp2_spec(preal x, float c) {
+    preal t2 = PFMA(x, c, 12582912.0f);
+    preal n = t2 - 12582912.0f;
+    preal f = PFMA(x, c, -n);
+    preal p = pbroadcast(0.001327647129073739f);
+    p = PFMA(p, f, 0.009675540961325169f);
+    p = PFMA(p, f, 0.05550713092088699f);
+    p = PFMA(p, f, 0.24022120237350464f);
+    p = PFMA(p, f, 0.6931469440460205f);
+    p = PFMA(p, f, 1.0000001192092896f);
     return as_f(as_u(p) + (as_u(t2) << 23));
 }
 /* tanh of 4 values sharing ONE reciprocal (batched inversion, SPEC.md §3.4):
  * d_i = 1 + exp(2 x_i); r = 1/(d0 d1 d2 d3); 1/d_i recovered by multiplications; tanh = 1 - 2/d_i */
-void NAME(tanh4)(const float* x, float* y) {
-    float d[4];
+PUB void NAME(tanh4)(const preal* x, preal* y) {
+    preal d[4];
     for (int i = 0; i < 4; ++i) {
-        float xc = fminf(fmaxf(x[i], -9.0f), 9.0f);
+        preal xc = pclamp(x[i], -9.0f, 9.0f);
         d[i] = 1.0f + exp2_spec(xc, 2.885390043258667f); /* 2*log2(e) */
     }
-    float p2 = d[0] * d[1], p3 = p2 * d[2], p4 = p3 * d[3];
-    float r = NAME(rcp)(p4);
-    float r3 = r * p3; r = r * d[3];
-    float r2 = r * p2; r = r * d[2];
-    float r1 = r * d[0];
-    float r0 = r * d[1];
-    y[0] = fmaf(-2.0f, r0, 1.0f); y[1] = fmaf(-2.0f, r1, 1.0f); y[2] = fmaf(-2.0f, r2, 1.0f); y[3] = fmaf(-2.0f, r3, 1.0f);
+    preal p2 = d[0] * d[1], p3 = p2 * d[2], p4 = p3 * d[3];
+    preal r = NAME(rcp)(p4);
+    preal r3 = r * p3; r = r * d[3];
+    preal r2 = r * p2; r = r * d[2];
+    preal r1 = r * d[0];
+    preal r0 = r * d[1];
+    y[0] = PFMA(-2.0f, r0, 1.0f); y[1] = PFMA(-2.0f, r1, 1.0f); y[2] = PFMA(-2.0f, r2, 1.0f); y[3] = PFMA(-2.0f, r3, 1.0f);
 }
-float NAME(tanh)(float x) { float a[4] = {x, x, x, x}, y[4]; NAME(tanh4)(a, y); return y[0]; }
-float NAME(sigmoid)(float x) {
-    float xc = fminf(fmaxf(x, -30.0f), 30.0f);
-    float E = exp2_spec(xc, -1.4426950216293335f); /* -log2(e) */
+PUB preal NAME(tanh)(preal x) { preal a[4] = {x, x, x, x}, y[4]; NAME(tanh4)(a, y); return y[0]; }
+PUB preal NAME(sigmoid)(preal x) {
+    preal xc = pclamp(x, -30.0f, 30.0f);
+    preal E = exp2_spec(xc, -1.4426950216293335f); /* -log2(e) */
     return NAME(rcp)(1.0f + E);
 }
 #else
@@ -226,213 +263,215 @@ static void ustep_eval(const model_t* M, const real* u, ustep_t* U) {
 /* SURVEY.md §8a A4/A6; knobs launch/iris_sitl_traj_mpc.yaml:44-52; body NOT IN REFERENCE      */
 /* ------------------------------------------------------------------------------------------- */
 typedef struct { /* values the VJP re-uses; recomputed from x_t in the backward sweep */
-    real Rm[9], vb[3], h1d[HID], h1n[HID], h2[HID], o[6], eta, Fb[3], Jom[3], qt[4], rn, qn[4];
+    preal Rm[9], vb[3], h1d[HID], h1n[HID], h2[HID], o[6], eta, Fb[3], Jom[3], qt[4], rn, qn[4];
 } stepaux_t;
 
-static void step_fwd(const model_t* M, const ustep_t* U, const real* x, const real* xi, real dt,
-                     const real* sdt, real* xn, stepaux_t* A) {
-    const real *p = x, *v = x + 3, *q = x + 6, *om = x + 10;
-    real qw = q[0], qx = q[1], qy = q[2], qz = q[3];
-    real xx = qx * qx, yy = qy * qy, zz = qz * qz;
-    real xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
-    real* Rm = A->Rm;
-    Rm[0] = FMA(R(-2), yy + zz, R(1)); Rm[1] = R(2) * (xy - wz);          Rm[2] = R(2) * (xz + wy);
-    Rm[3] = R(2) * (xy + wz);          Rm[4] = FMA(R(-2), xx + zz, R(1)); Rm[5] = R(2) * (yz - wx);
-    Rm[6] = R(2) * (xz - wy);          Rm[7] = R(2) * (yz + wx);          Rm[8] = FMA(R(-2), xx + yy, R(1));
+static void step_fwd(const model_t* M, const ustep_t* U, const preal* x, const preal* xi, real dt,
+                     const real* sdt, preal* xn, stepaux_t* A) {
+    const preal *p = x, *v = x + 3, *q = x + 6, *om = x + 10;
+    preal qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    preal xx = qx * qx, yy = qy * qy, zz = qz * qz;
+    preal xy = qx * qy, xz = qx * qz, yz = qy * qz, wx = qw * qx, wy = qw * qy, wz = qw * qz;
+    preal* Rm = A->Rm;
+    Rm[0] = PFMA(R(-2), yy + zz, R(1)); Rm[1] = R(2) * (xy - wz);          Rm[2] = R(2) * (xz + wy);
+    Rm[3] = R(2) * (xy + wz);          Rm[4] = PFMA(R(-2), xx + zz, R(1)); Rm[5] = R(2) * (yz - wx);
+    Rm[6] = R(2) * (xz - wy);          Rm[7] = R(2) * (yz + wx);          Rm[8] = PFMA(R(-2), xx + yy, R(1));
     /* body-frame velocity vb = R^T v */
-    for (int j = 0; j < 3; ++j) A->vb[j] = FMA(Rm[6 + j], v[2], FMA(Rm[3 + j], v[1], Rm[j] * v[0]));
-    real z[NN] = {A->vb[0], A->vb[1], A->vb[2], om[0], om[1], om[2]};
+    for (int j = 0; j < 3; ++j) A->vb[j] = PFMA(Rm[6 + j], v[2], PFMA(Rm[3 + j], v[1], Rm[j] * v[0]));
+    preal z[NN] = {A->vb[0], A->vb[1], A->vb[2], om[0], om[1], om[2]};
+#ifndef ORC_VEC
     if (M->f16) for (int k = 0; k < NN; ++k) z[k] = f16_rtz(z[k]);   /* activations enter the contraction in fp16 */
+#endif
     /* layer 1: drift rows 0..31 start from U->c, density rows 32..63 from b1 */
-    real pre_d[HID], pre_n[HID], pre_2[HID];
+    preal pre_d[HID], pre_n[HID], pre_2[HID];
     for (int r = 0; r < HID; ++r) {
-        real a = U->c[r], b = M->b1[HID + r];
-        for (int k = 0; k < NN; ++k) { a = FMA(M->W1z[r][k], z[k], a); b = FMA(M->W1z[HID + r][k], z[k], b); }
+        preal a = pbroadcast(U->c[r]), b = pbroadcast(M->b1[HID + r]);
+        for (int k = 0; k < NN; ++k) { a = PFMA(M->W1z[r][k], z[k], a); b = PFMA(M->W1z[HID + r][k], z[k], b); }
         pre_d[r] = a; pre_n[r] = b;
     }
     for (int r = 0; r < HID; r += 4) { NAME(tanh4)(pre_d + r, A->h1d + r); NAME(tanh4)(pre_n + r, A->h1n + r); }
     /* layer 2 (drift): k visited in rowmap order */
     for (int i = 0; i < HID; ++i) {
-        real a = M->b2[i];
-        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int k = rowmap(r, h); a = FMA(M->W2[i][k], M->f16 ? f16_rtz(A->h1d[k]) : A->h1d[k], a); }
+        preal a = pbroadcast(M->b2[i]);
+        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int k = rowmap(r, h); a = PFMA(M->W2[i][k], F16Q(M->f16, A->h1d[k]), a); }
         pre_2[i] = a;
     }
     for (int r = 0; r < HID; r += 4) NAME(tanh4)(pre_2 + r, A->h2 + r);
     /* output layers: two half-sums (h = 0, 1) over r, then (P0 + P1) + bias */
     for (int i = 0; i < 6; ++i) {
-        real P0 = 0, P1 = 0;
-        for (int r = 0; r < 16; ++r) { P0 = FMA(M->W3[i][rowmap(r, 0)], A->h2[rowmap(r, 0)], P0); P1 = FMA(M->W3[i][rowmap(r, 1)], A->h2[rowmap(r, 1)], P1); }
+        preal P0 = pbroadcast(R(0)), P1 = pbroadcast(R(0));
+        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->W3[i][rowmap(r, 0)], A->h2[rowmap(r, 0)], P0); P1 = PFMA(M->W3[i][rowmap(r, 1)], A->h2[rowmap(r, 1)], P1); }
         A->o[i] = (P0 + P1) + M->b3[i];
     }
     {
-        real P0 = 0, P1 = 0;
-        for (int r = 0; r < 16; ++r) { P0 = FMA(M->w3n[rowmap(r, 0)], A->h1n[rowmap(r, 0)], P0); P1 = FMA(M->w3n[rowmap(r, 1)], A->h1n[rowmap(r, 1)], P1); }
+        preal P0 = pbroadcast(R(0)), P1 = pbroadcast(R(0));
+        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->w3n[rowmap(r, 0)], A->h1n[rowmap(r, 0)], P0); P1 = PFMA(M->w3n[rowmap(r, 1)], A->h1n[rowmap(r, 1)], P1); }
         A->eta = NAME(sigmoid)((P0 + P1) + M->b3n);
     }
     /* rigid body */
-    A->Fb[0] = M->sF[0] * A->o[0]; A->Fb[1] = M->sF[1] * A->o[1]; A->Fb[2] = FMA(M->sF[2], A->o[2], U->Tz);
-    real acc[3];
+    A->Fb[0] = M->sF[0] * A->o[0]; A->Fb[1] = M->sF[1] * A->o[1]; A->Fb[2] = PFMA(M->sF[2], A->o[2], U->Tz);
+    preal acc[3];
     for (int i = 0; i < 3; ++i) {
-        real Fw = FMA(Rm[3 * i + 2], A->Fb[2], FMA(Rm[3 * i + 1], A->Fb[1], Rm[3 * i] * A->Fb[0]));
+        preal Fw = PFMA(Rm[3 * i + 2], A->Fb[2], PFMA(Rm[3 * i + 1], A->Fb[1], Rm[3 * i] * A->Fb[0]));
         acc[i] = Fw * M->inv_mass;
     }
     acc[2] = acc[2] - M->grav;
-    real taub[3];
-    for (int i = 0; i < 3; ++i) { taub[i] = FMA(M->sT[i], A->o[3 + i], U->tau[i]); A->Jom[i] = M->J[i] * om[i]; }
-    real cr[3];
-    cr[0] = FMA(om[1], A->Jom[2], -(om[2] * A->Jom[1]));
-    cr[1] = FMA(om[2], A->Jom[0], -(om[0] * A->Jom[2]));
-    cr[2] = FMA(om[0], A->Jom[1], -(om[1] * A->Jom[0]));
-    real dom[3];
+    preal taub[3];
+    for (int i = 0; i < 3; ++i) { taub[i] = PFMA(M->sT[i], A->o[3 + i], U->tau[i]); A->Jom[i] = M->J[i] * om[i]; }
+    preal cr[3];
+    cr[0] = PFMA(om[1], A->Jom[2], -(om[2] * A->Jom[1]));
+    cr[1] = PFMA(om[2], A->Jom[0], -(om[0] * A->Jom[2]));
+    cr[2] = PFMA(om[0], A->Jom[1], -(om[1] * A->Jom[0]));
+    preal dom[3];
     for (int i = 0; i < 3; ++i) dom[i] = (taub[i] - cr[i]) * M->iJ[i];
-    real dq[4];
-    dq[0] = R(-0.5) * FMA(qz, om[2], FMA(qy, om[1], qx * om[0]));
-    dq[1] = R(0.5) * FMA(-qz, om[1], FMA(qy, om[2], qw * om[0]));
-    dq[2] = R(0.5) * FMA(-qx, om[2], FMA(qz, om[0], qw * om[1]));
-    dq[3] = R(0.5) * FMA(-qy, om[0], FMA(qx, om[1], qw * om[2]));
+    preal dq[4];
+    dq[0] = R(-0.5) * PFMA(qz, om[2], PFMA(qy, om[1], qx * om[0]));
+    dq[1] = R(0.5) * PFMA(-qz, om[1], PFMA(qy, om[2], qw * om[0]));
+    dq[2] = R(0.5) * PFMA(-qx, om[2], PFMA(qz, om[0], qw * om[1]));
+    dq[3] = R(0.5) * PFMA(-qy, om[0], PFMA(qx, om[1], qw * om[2]));
     /* Euler–Maruyama update */
-    real se[NN];
+    preal se[NN];
     for (int i = 0; i < NN; ++i) se[i] = sdt[i] * A->eta;
     for (int i = 0; i < 3; ++i) {
-        xn[i] = FMA(v[i], dt, p[i]);
-        xn[3 + i] = FMA(se[i], xi[i], FMA(acc[i], dt, v[i]));
-        xn[10 + i] = FMA(se[3 + i], xi[3 + i], FMA(dom[i], dt, om[i]));
+        xn[i] = PFMA(v[i], dt, p[i]);
+        xn[3 + i] = PFMA(se[i], xi[i], PFMA(acc[i], dt, v[i]));
+        xn[10 + i] = PFMA(se[3 + i], xi[3 + i], PFMA(dom[i], dt, om[i]));
     }
-    for (int i = 0; i < 4; ++i) A->qt[i] = FMA(dq[i], dt, q[i]);
-    real n2 = FMA(A->qt[3], A->qt[3], FMA(A->qt[2], A->qt[2], FMA(A->qt[1], A->qt[1], A->qt[0] * A->qt[0])));
+    for (int i = 0; i < 4; ++i) A->qt[i] = PFMA(dq[i], dt, q[i]);
+    preal n2 = PFMA(A->qt[3], A->qt[3], PFMA(A->qt[2], A->qt[2], PFMA(A->qt[1], A->qt[1], A->qt[0] * A->qt[0])));
     A->rn = NAME(rsqrt)(n2);
     for (int i = 0; i < 4; ++i) { A->qn[i] = A->qt[i] * A->rn; xn[6 + i] = A->qn[i]; }
 }
 
 /* stage state cost at x_{t+1} (SPEC.md §5.3): returns l, optionally the gradient wrt x_{t+1}.
  * SURVEY.md §8a A5; weights = cost_params of launch/iris_sitl_traj_mpc.yaml:32-41 */
-static real stage_cost(const sdempc_cfg* C, const real* x, const real* xr, real* gx) {
-    real l = 0;
+static preal stage_cost(const sdempc_cfg* C, const preal* x, const real* xr, preal* gx) {
+    preal l = pbroadcast(R(0));
     for (int i = 0; i < 3; ++i) {
-        real e = x[i] - xr[i];
-        real w = (real)C->perr[i] * e;
-        l = FMA(w, e, l);
+        preal e = x[i] - xr[i];
+        preal w = (real)C->perr[i] * e;
+        l = PFMA(w, e, l);
         if (gx) gx[i] = R(2) * w;
     }
     for (int i = 0; i < 3; ++i) {
-        real e = x[3 + i] - xr[3 + i];
-        real w = (real)C->verr[i] * e;
-        l = FMA(w, e, l);
+        preal e = x[3 + i] - xr[3 + i];
+        preal w = (real)C->verr[i] * e;
+        l = PFMA(w, e, l);
         if (gx) gx[3 + i] = R(2) * w;
     }
     for (int i = 0; i < 3; ++i) {
-        real e = x[10 + i] - xr[10 + i];
-        real w = (real)C->werr[i] * e;
-        l = FMA(w, e, l);
+        preal e = x[10 + i] - xr[10 + i];
+        preal w = (real)C->werr[i] * e;
+        l = PFMA(w, e, l);
         if (gx) gx[10 + i] = R(2) * w;
     }
-    real qw = x[6], qx = x[7], qy = x[8], qz = x[9], rw = xr[6], rx = xr[7], ry = xr[8], rz = xr[9];
-    real ex = FMA(rz, qy, FMA(-ry, qz, FMA(-rx, qw, rw * qx)));
-    real ey = FMA(-rz, qx, FMA(-ry, qw, FMA(rx, qz, rw * qy)));
-    real ez = FMA(-rz, qw, FMA(ry, qx, FMA(-rx, qy, rw * qz)));
-    real wxe = (real)C->qerr[0] * ex, wye = (real)C->qerr[1] * ey, wze = (real)C->qerr[2] * ez;
-    l = FMA(wxe, ex, l); l = FMA(wye, ey, l); l = FMA(wze, ez, l);
+    preal qw = x[6], qx = x[7], qy = x[8], qz = x[9], rw = pbroadcast(xr[6]), rx = pbroadcast(xr[7]), ry = pbroadcast(xr[8]), rz = pbroadcast(xr[9]);
+    preal ex = PFMA(rz, qy, PFMA(-ry, qz, PFMA(-rx, qw, rw * qx)));
+    preal ey = PFMA(-rz, qx, PFMA(-ry, qw, PFMA(rx, qz, rw * qy)));
+    preal ez = PFMA(-rz, qw, PFMA(ry, qx, PFMA(-rx, qy, rw * qz)));
+    preal wxe = (real)C->qerr[0] * ex, wye = (real)C->qerr[1] * ey, wze = (real)C->qerr[2] * ez;
+    l = PFMA(wxe, ex, l); l = PFMA(wye, ey, l); l = PFMA(wze, ez, l);
     if (gx) {
-        real a = R(2) * wxe, b = R(2) * wye, c = R(2) * wze;
-        gx[6] = FMA(-rz, c, FMA(-ry, b, -rx * a));
-        gx[7] = FMA(ry, c, FMA(-rz, b, rw * a));
-        gx[8] = FMA(-rx, c, FMA(rw, b, rz * a));
-        gx[9] = FMA(rw, c, FMA(rx, b, -ry * a));
+        preal a = R(2) * wxe, b = R(2) * wye, c = R(2) * wze;
+        gx[6] = PFMA(-rz, c, PFMA(-ry, b, -rx * a));
+        gx[7] = PFMA(ry, c, PFMA(-rz, b, rw * a));
+        gx[8] = PFMA(-rx, c, PFMA(rw, b, rz * a));
+        gx[9] = PFMA(rw, c, PFMA(rx, b, -ry * a));
     }
     return l;
 }
 
 /* VJP of step_fwd. L = adjoint wrt x_{t+1}; etabar_cost = direct d(cost)/d(eta).
  * Outputs: lam = adjoint wrt x_t; gu[m] = W1u^T abar1 (drift tile); gT = adjoint of Tz; gtau[3]. */
-static void step_vjp(const model_t* M, const real* x, const real* xi, real dt, const real* sdt,
-                     const stepaux_t* A, const real* L, real etabar_cost,
-                     real* lam, real* gu, real* gT, real* gtau) {
-    const real *v = x + 3, *q = x + 6, *om = x + 10;
-    const real *Lp = L, *Lv = L + 3, *Lq = L + 6, *Lo = L + 10;
-    const real* Rm = A->Rm;
-    real qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+static void step_vjp(const model_t* M, const preal* x, const preal* xi, real dt, const real* sdt,
+                     const stepaux_t* A, const preal* L, preal etabar_cost,
+                     preal* lam, preal* gu, preal* gT, preal* gtau) {
+    const preal *v = x + 3, *q = x + 6, *om = x + 10;
+    const preal *Lp = L, *Lv = L + 3, *Lq = L + 6, *Lo = L + 10;
+    const preal* Rm = A->Rm;
+    preal qw = q[0], qx = q[1], qy = q[2], qz = q[3];
     /* eta adjoint */
-    real eb = etabar_cost;
-    for (int i = 0; i < 3; ++i) eb = FMA(Lv[i] * sdt[i], xi[i], eb);
-    for (int i = 0; i < 3; ++i) eb = FMA(Lo[i] * sdt[3 + i], xi[3 + i], eb);
-    real ebraw = eb * (A->eta * (R(1) - A->eta));
+    preal eb = etabar_cost;
+    for (int i = 0; i < 3; ++i) eb = PFMA(Lv[i] * sdt[i], xi[i], eb);
+    for (int i = 0; i < 3; ++i) eb = PFMA(Lo[i] * sdt[3 + i], xi[3 + i], eb);
+    preal ebraw = eb * (A->eta * (R(1) - A->eta));
     /* quaternion normalisation */
-    real dotq = FMA(A->qn[3], Lq[3], FMA(A->qn[2], Lq[2], FMA(A->qn[1], Lq[1], A->qn[0] * Lq[0])));
-    real qtb[4], dqb[4];
-    for (int i = 0; i < 4; ++i) { qtb[i] = A->rn * FMA(-A->qn[i], dotq, Lq[i]); dqb[i] = qtb[i] * dt; }
+    preal dotq = PFMA(A->qn[3], Lq[3], PFMA(A->qn[2], Lq[2], PFMA(A->qn[1], Lq[1], A->qn[0] * Lq[0])));
+    preal qtb[4], dqb[4];
+    for (int i = 0; i < 4; ++i) { qtb[i] = A->rn * PFMA(-A->qn[i], dotq, Lq[i]); dqb[i] = qtb[i] * dt; }
     /* angular acceleration */
-    real taub_b[3], crb[3];
+    preal taub_b[3], crb[3];
     for (int i = 0; i < 3; ++i) { taub_b[i] = (Lo[i] * dt) * M->iJ[i]; crb[i] = -taub_b[i]; }
     /* cr = om x Jom : om_bar += Jom x crb ; Jom_bar = crb x om */
-    real omb[3], Jb[3];
-    omb[0] = Lo[0] + FMA(A->Jom[1], crb[2], -(A->Jom[2] * crb[1]));
-    omb[1] = Lo[1] + FMA(A->Jom[2], crb[0], -(A->Jom[0] * crb[2]));
-    omb[2] = Lo[2] + FMA(A->Jom[0], crb[1], -(A->Jom[1] * crb[0]));
-    Jb[0] = FMA(crb[1], om[2], -(crb[2] * om[1]));
-    Jb[1] = FMA(crb[2], om[0], -(crb[0] * om[2]));
-    Jb[2] = FMA(crb[0], om[1], -(crb[1] * om[0]));
-    for (int i = 0; i < 3; ++i) omb[i] = FMA(M->J[i], Jb[i], omb[i]);
+    preal omb[3], Jb[3];
+    omb[0] = Lo[0] + PFMA(A->Jom[1], crb[2], -(A->Jom[2] * crb[1]));
+    omb[1] = Lo[1] + PFMA(A->Jom[2], crb[0], -(A->Jom[0] * crb[2]));
+    omb[2] = Lo[2] + PFMA(A->Jom[0], crb[1], -(A->Jom[1] * crb[0]));
+    Jb[0] = PFMA(crb[1], om[2], -(crb[2] * om[1]));
+    Jb[1] = PFMA(crb[2], om[0], -(crb[0] * om[2]));
+    Jb[2] = PFMA(crb[0], om[1], -(crb[1] * om[0]));
+    for (int i = 0; i < 3; ++i) omb[i] = PFMA(M->J[i], Jb[i], omb[i]);
     /* linear acceleration: acc = R Fb inv_mass - g e3 */
-    real Fwb[3], Fbb[3];
+    preal Fwb[3], Fbb[3];
     for (int i = 0; i < 3; ++i) Fwb[i] = (Lv[i] * dt) * M->inv_mass;
-    for (int j = 0; j < 3; ++j) Fbb[j] = FMA(Rm[6 + j], Fwb[2], FMA(Rm[3 + j], Fwb[1], Rm[j] * Fwb[0]));
+    for (int j = 0; j < 3; ++j) Fbb[j] = PFMA(Rm[6 + j], Fwb[2], PFMA(Rm[3 + j], Fwb[1], Rm[j] * Fwb[0]));
     /* MLP output adjoints */
-    real ob[6];
+    preal ob[6];
     for (int i = 0; i < 3; ++i) { ob[i] = M->sF[i] * Fbb[i]; ob[3 + i] = M->sT[i] * taub_b[i]; }
     *gT = Fbb[2];
     for (int i = 0; i < 3; ++i) gtau[i] = taub_b[i];
     /* MLP VJP (SPEC.md §5.4) */
-    real a2b[HID], a1d[HID], a1n[HID];
+    preal a2b[HID], a1d[HID], a1n[HID];
     for (int k = 0; k < HID; ++k) {
-        real hb = 0;
-        for (int i = 0; i < 6; ++i) hb = FMA(M->W3[i][k], ob[i], hb);
-        a2b[k] = hb * FMA(-A->h2[k], A->h2[k], R(1));
+        preal hb = pbroadcast(R(0));
+        for (int i = 0; i < 6; ++i) hb = PFMA(M->W3[i][k], ob[i], hb);
+        a2b[k] = hb * PFMA(-A->h2[k], A->h2[k], R(1));
     }
     for (int k = 0; k < HID; ++k) {
-        real hb = 0;
-        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int i = rowmap(r, h); hb = FMA(M->W2[i][k], a2b[i], hb); }
-        a1d[k] = hb * FMA(-A->h1d[k], A->h1d[k], R(1));
-        a1n[k] = (M->w3n[k] * ebraw) * FMA(-A->h1n[k], A->h1n[k], R(1));
+        preal hb = pbroadcast(R(0));
+        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int i = rowmap(r, h); hb = PFMA(M->W2[i][k], a2b[i], hb); }
+        a1d[k] = hb * PFMA(-A->h1d[k], A->h1d[k], R(1));
+        a1n[k] = (M->w3n[k] * ebraw) * PFMA(-A->h1n[k], A->h1n[k], R(1));
     }
-    real zb[NN];
+    preal zb[NN];
     for (int k = 0; k < NN; ++k) {
-        real P0 = 0, P1 = 0;
-        for (int r = 0; r < 16; ++r) { P0 = FMA(M->W1z[HID + rowmap(r, 0)][k], a1n[rowmap(r, 0)], P0); P1 = FMA(M->W1z[HID + rowmap(r, 1)][k], a1n[rowmap(r, 1)], P1); }
-        for (int r = 0; r < 16; ++r) { P0 = FMA(M->W1z[rowmap(r, 0)][k], a1d[rowmap(r, 0)], P0); P1 = FMA(M->W1z[rowmap(r, 1)][k], a1d[rowmap(r, 1)], P1); }
+        preal P0 = pbroadcast(R(0)), P1 = pbroadcast(R(0));
+        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->W1z[HID + rowmap(r, 0)][k], a1n[rowmap(r, 0)], P0); P1 = PFMA(M->W1z[HID + rowmap(r, 1)][k], a1n[rowmap(r, 1)], P1); }
+        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->W1z[rowmap(r, 0)][k], a1d[rowmap(r, 0)], P0); P1 = PFMA(M->W1z[rowmap(r, 1)][k], a1d[rowmap(r, 1)], P1); }
         zb[k] = P0 + P1;
     }
     for (int j = 0; j < M->m; ++j) {
-        real P0 = 0, P1 = 0;
-        for (int r = 0; r < 16; ++r) { P0 = FMA(M->W1u[rowmap(r, 0)][j], a1d[rowmap(r, 0)], P0); P1 = FMA(M->W1u[rowmap(r, 1)][j], a1d[rowmap(r, 1)], P1); }
+        preal P0 = pbroadcast(R(0)), P1 = pbroadcast(R(0));
+        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->W1u[rowmap(r, 0)][j], a1d[rowmap(r, 0)], P0); P1 = PFMA(M->W1u[rowmap(r, 1)][j], a1d[rowmap(r, 1)], P1); }
         gu[j] = P0 + P1;
     }
     for (int i = 0; i < 3; ++i) omb[i] = omb[i] + zb[3 + i];
     /* vb = R^T v */
-    real vbar[3];
+    preal vbar[3];
     for (int i = 0; i < 3; ++i) {
-        real Rvb = FMA(Rm[3 * i + 2], zb[2], FMA(Rm[3 * i + 1], zb[1], Rm[3 * i] * zb[0]));
-        vbar[i] = FMA(Lp[i], dt, Lv[i]) + Rvb;
+        preal Rvb = PFMA(Rm[3 * i + 2], zb[2], PFMA(Rm[3 * i + 1], zb[1], Rm[3 * i] * zb[0]));
+        vbar[i] = PFMA(Lp[i], dt, Lv[i]) + Rvb;
     }
     /* Rbar_ij = Fwb_i Fb_j + v_i zb_j */
-    real Rb[9];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rb[3 * i + j] = FMA(v[i], zb[j], Fwb[i] * A->Fb[j]);
+    preal Rb[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rb[3 * i + j] = PFMA(v[i], zb[j], Fwb[i] * A->Fb[j]);
     /* dq = 0.5 q (x) (0, om) */
-    real qb[4];
-    qb[0] = FMA(R(0.5), FMA(dqb[3], om[2], FMA(dqb[2], om[1], dqb[1] * om[0])), qtb[0]);
-    qb[1] = FMA(R(0.5), FMA(dqb[3], om[1], FMA(-dqb[2], om[2], -(dqb[0] * om[0]))), qtb[1]);
-    qb[2] = FMA(R(0.5), FMA(-dqb[3], om[0], FMA(dqb[1], om[2], -(dqb[0] * om[1]))), qtb[2]);
-    qb[3] = FMA(R(0.5), FMA(dqb[2], om[0], FMA(-dqb[1], om[1], -(dqb[0] * om[2]))), qtb[3]);
-    omb[0] = FMA(R(0.5), FMA(-dqb[3], qy, FMA(dqb[2], qz, FMA(dqb[1], qw, -(dqb[0] * qx)))), omb[0]);
-    omb[1] = FMA(R(0.5), FMA(dqb[3], qx, FMA(dqb[2], qw, FMA(-dqb[1], qz, -(dqb[0] * qy)))), omb[1]);
-    omb[2] = FMA(R(0.5), FMA(dqb[3], qw, FMA(-dqb[2], qx, FMA(dqb[1], qy, -(dqb[0] * qz)))), omb[2]);
+    preal qb[4];
+    qb[0] = PFMA(R(0.5), PFMA(dqb[3], om[2], PFMA(dqb[2], om[1], dqb[1] * om[0])), qtb[0]);
+    qb[1] = PFMA(R(0.5), PFMA(dqb[3], om[1], PFMA(-dqb[2], om[2], -(dqb[0] * om[0]))), qtb[1]);
+    qb[2] = PFMA(R(0.5), PFMA(-dqb[3], om[0], PFMA(dqb[1], om[2], -(dqb[0] * om[1]))), qtb[2]);
+    qb[3] = PFMA(R(0.5), PFMA(dqb[2], om[0], PFMA(-dqb[1], om[1], -(dqb[0] * om[2]))), qtb[3]);
+    omb[0] = PFMA(R(0.5), PFMA(-dqb[3], qy, PFMA(dqb[2], qz, PFMA(dqb[1], qw, -(dqb[0] * qx)))), omb[0]);
+    omb[1] = PFMA(R(0.5), PFMA(dqb[3], qx, PFMA(dqb[2], qw, PFMA(-dqb[1], qz, -(dqb[0] * qy)))), omb[1]);
+    omb[2] = PFMA(R(0.5), PFMA(dqb[3], qw, PFMA(-dqb[2], qx, PFMA(dqb[1], qy, -(dqb[0] * qz)))), omb[2]);
     /* R(q) */
-    real s01 = Rb[1] + Rb[3], d10 = Rb[3] - Rb[1];
-    real s02 = Rb[2] + Rb[6], d02 = Rb[2] - Rb[6];
-    real s12 = Rb[5] + Rb[7], d21 = Rb[7] - Rb[5];
-    qb[0] = FMA(R(2), FMA(qx, d21, FMA(qy, d02, qz * d10)), qb[0]);
-    qb[1] = FMA(R(2), FMA(qw, d21, FMA(qz, s02, qy * s01)), FMA(R(-4) * qx, Rb[4] + Rb[8], qb[1]));
-    qb[2] = FMA(R(2), FMA(qz, s12, FMA(qw, d02, qx * s01)), FMA(R(-4) * qy, Rb[0] + Rb[8], qb[2]));
-    qb[3] = FMA(R(2), FMA(qy, s12, FMA(qx, s02, qw * d10)), FMA(R(-4) * qz, Rb[0] + Rb[4], qb[3]));
+    preal s01 = Rb[1] + Rb[3], d10 = Rb[3] - Rb[1];
+    preal s02 = Rb[2] + Rb[6], d02 = Rb[2] - Rb[6];
+    preal s12 = Rb[5] + Rb[7], d21 = Rb[7] - Rb[5];
+    qb[0] = PFMA(R(2), PFMA(qx, d21, PFMA(qy, d02, qz * d10)), qb[0]);
+    qb[1] = PFMA(R(2), PFMA(qw, d21, PFMA(qz, s02, qy * s01)), PFMA(R(-4) * qx, Rb[4] + Rb[8], qb[1]));
+    qb[2] = PFMA(R(2), PFMA(qz, s12, PFMA(qw, d02, qx * s01)), PFMA(R(-4) * qy, Rb[0] + Rb[8], qb[2]));
+    qb[3] = PFMA(R(2), PFMA(qy, s12, PFMA(qx, s02, qw * d10)), PFMA(R(-4) * qz, Rb[0] + Rb[4], qb[3]));
     for (int i = 0; i < 3; ++i) { lam[i] = Lp[i]; lam[3 + i] = vbar[i]; lam[10 + i] = omb[i]; }
     for (int i = 0; i < 4; ++i) lam[6 + i] = qb[i];
 }
@@ -475,6 +514,26 @@ static real dot256(const real* a, const real* b, int N) {
     return ((v[0] + v[64]) + v[128]) + v[192];
 }
 
+/* lanes of one block of VL particles <-> strided scalar storage (n = live lanes of the block; dead lanes load 0) */
+static inline preal pload(const real* base, size_t stride, int n) {
+#ifdef ORC_VEC
+    preal v = pbroadcast(R(0));
+    for (int l = 0; l < VL; ++l) if (l < n) v[l] = base[(size_t)l * stride];
+    return v;
+#else
+    (void)stride; (void)n;
+    return base[0];
+#endif
+}
+static inline void pstore(real* base, size_t stride, int n, preal v) {
+#ifdef ORC_VEC
+    for (int l = 0; l < VL; ++l) if (l < n) base[(size_t)l * stride] = v[l];
+#else
+    (void)stride; (void)n;
+    base[0] = v;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* problem context                                                                             */
 /* ------------------------------------------------------------------------------------------- */
@@ -492,6 +551,9 @@ typedef struct {
 
 static int ctx_init(ctx_t* X, const sdempc_cfg* C, const void* blob) {
     if (!C || C->struct_size != (int32_t)sizeof(sdempc_cfg)) return SDEMPC_EINVAL;
+#ifdef ORC_VEC
+    if (C->mlp_dtype == 1) return SDEMPC_EINVAL;   /* the timing build has the f32 arithmetic only */
+#endif
     if (parse_blob(blob, &X->M, C->mlp_dtype == 1)) return SDEMPC_EBLOB;
     X->C = C; X->H = C->horizon; X->P = C->num_particles; X->m = C->num_motors;
     if (X->H < 1 || X->P < 1 || X->m != X->M.m) return SDEMPC_EINVAL;
@@ -574,24 +636,27 @@ static real rollout(const ctx_t* X, const real* x0, const real* u, const real* x
     real* Jp = X->wsJp;
     real* xs = xmean ? X->wsXs : NULL;
     stepaux_t A;
-    for (int p = 0; p < P; ++p) {
-        real x[NX], xn[NX];
-        memcpy(x, x0, sizeof x);
-        real* tp = traj ? traj + (size_t)p * (H + 1) * NX : NULL;
-        real* sp = xs ? xs + (size_t)p * (H + 1) * NX : NULL;
-        if (tp) memcpy(tp, x, sizeof x);
-        if (sp) memcpy(sp, x, sizeof x);
-        real J = 0;
+    const size_t ps = (size_t)(H + 1) * NX;                 /* particle stride of traj / xs */
+    for (int p = 0; p < P; p += VL) {                        /* one block of VL particles (VL = 1 in the checker builds) */
+        const int n = P - p < VL ? P - p : VL;
+        preal x[NX], xn[NX], xi[NN];
+        for (int i = 0; i < NX; ++i) x[i] = pbroadcast(x0[i]);
+        real* tp = traj ? traj + (size_t)p * ps : NULL;
+        real* sp = xs ? xs + (size_t)p * ps : NULL;
+        if (tp) for (int i = 0; i < NX; ++i) pstore(tp + i, ps, n, x[i]);
+        if (sp) for (int i = 0; i < NX; ++i) pstore(sp + i, ps, n, x[i]);
+        preal J = pbroadcast(R(0));
         for (int t = 0; t < H; ++t) {
-            step_fwd(&X->M, &U[t], x, noise + ((size_t)p * H + t) * NN, X->dt[t], X->sdt + t * NN, xn, &A);
-            real l = stage_cost(X->C, xn, xref + (t + 1) * NX, NULL);
-            l = FMA((real)X->C->res_mult * A.eta, A.eta, l);
-            J = FMA(X->disc[t], l, J);
+            for (int i = 0; i < NN; ++i) xi[i] = pload(noise + ((size_t)p * H + t) * NN + i, (size_t)H * NN, n);
+            step_fwd(&X->M, &U[t], x, xi, X->dt[t], X->sdt + t * NN, xn, &A);
+            preal l = stage_cost(X->C, xn, xref + (t + 1) * NX, NULL);
+            l = PFMA((real)X->C->res_mult * A.eta, A.eta, l);
+            J = PFMA(X->disc[t], l, J);
             memcpy(x, xn, sizeof x);
-            if (tp) memcpy(tp + (t + 1) * NX, x, sizeof x);
-            if (sp) memcpy(sp + (t + 1) * NX, x, sizeof x);
+            if (tp) for (int i = 0; i < NX; ++i) pstore(tp + (t + 1) * NX + i, ps, n, x[i]);
+            if (sp) for (int i = 0; i < NX; ++i) pstore(sp + (t + 1) * NX + i, ps, n, x[i]);
         }
-        Jp[p] = J;
+        pstore(Jp + p, 1, n, J);
     }
     real tot = preduce(Jp, P);
     real cu = ucost(X, u, NULL);
@@ -617,30 +682,38 @@ static real cost_grad(const ctx_t* X, const real* x0, const real* u, const real*
     int nq = m + 4;
     real* Q = X->wsQ;
     stepaux_t A;
-    for (int p = 0; p < P; ++p) {
-        real* tp = traj + (size_t)p * (H + 1) * NX;
-        memcpy(tp, x0, sizeof(real) * NX);
-        real J = 0;
+    const size_t ps = (size_t)(H + 1) * NX;                 /* particle stride of traj */
+    for (int p = 0; p < P; p += VL) {                        /* one block of VL particles (VL = 1 in the checker builds) */
+        const int n = P - p < VL ? P - p : VL;
+        real* tp = traj + (size_t)p * ps;
+        preal x[NX], xn[NX], xi[NN];
+        for (int i = 0; i < NX; ++i) { x[i] = pbroadcast(x0[i]); pstore(tp + i, ps, n, x[i]); }
+        preal J = pbroadcast(R(0));
         for (int t = 0; t < H; ++t) {
-            step_fwd(M, &U[t], tp + t * NX, noise + ((size_t)p * H + t) * NN, X->dt[t], X->sdt + t * NN, tp + (t + 1) * NX, &A);
-            real l = stage_cost(X->C, tp + (t + 1) * NX, xref + (t + 1) * NX, NULL);
-            l = FMA((real)X->C->res_mult * A.eta, A.eta, l);
-            J = FMA(X->disc[t], l, J);
+            for (int i = 0; i < NN; ++i) xi[i] = pload(noise + ((size_t)p * H + t) * NN + i, (size_t)H * NN, n);
+            step_fwd(M, &U[t], x, xi, X->dt[t], X->sdt + t * NN, xn, &A);
+            preal l = stage_cost(X->C, xn, xref + (t + 1) * NX, NULL);
+            l = PFMA((real)X->C->res_mult * A.eta, A.eta, l);
+            J = PFMA(X->disc[t], l, J);
+            memcpy(x, xn, sizeof x);
+            for (int i = 0; i < NX; ++i) pstore(tp + (t + 1) * NX + i, ps, n, x[i]);
         }
-        Jp[p] = J;
-        real lam[NX];
-        for (int i = 0; i < NX; ++i) lam[i] = 0;
+        pstore(Jp + p, 1, n, J);
+        preal lam[NX];
+        for (int i = 0; i < NX; ++i) lam[i] = pbroadcast(R(0));
         for (int t = H - 1; t >= 0; --t) {
-            real xn[NX], gx[NX], L[NX], lamn[NX], gu[MAXM], gT, gtau[3];
-            step_fwd(M, &U[t], tp + t * NX, noise + ((size_t)p * H + t) * NN, X->dt[t], X->sdt + t * NN, xn, &A);
-            stage_cost(X->C, tp + (t + 1) * NX, xref + (t + 1) * NX, gx);
-            for (int i = 0; i < NX; ++i) L[i] = FMA(X->disc[t], gx[i], lam[i]);
-            real ebc = X->disc[t] * ((R(2) * (real)X->C->res_mult) * A.eta);
-            step_vjp(M, tp + t * NX, noise + ((size_t)p * H + t) * NN, X->dt[t], X->sdt + t * NN, &A, L, ebc, lamn, gu, &gT, gtau);
+            preal xt[NX], x1[NX], gx[NX], L[NX], lamn[NX], gu[MAXM], gT, gtau[3];
+            for (int i = 0; i < NX; ++i) { xt[i] = pload(tp + t * NX + i, ps, n); x1[i] = pload(tp + (t + 1) * NX + i, ps, n); }
+            for (int i = 0; i < NN; ++i) xi[i] = pload(noise + ((size_t)p * H + t) * NN + i, (size_t)H * NN, n);
+            step_fwd(M, &U[t], xt, xi, X->dt[t], X->sdt + t * NN, xn, &A);
+            stage_cost(X->C, x1, xref + (t + 1) * NX, gx);
+            for (int i = 0; i < NX; ++i) L[i] = PFMA(X->disc[t], gx[i], lam[i]);
+            preal ebc = X->disc[t] * ((R(2) * (real)X->C->res_mult) * A.eta);
+            step_vjp(M, xt, xi, X->dt[t], X->sdt + t * NN, &A, L, ebc, lamn, gu, &gT, gtau);
             memcpy(lam, lamn, sizeof lam);
-            for (int j = 0; j < m; ++j) Q[((size_t)t * nq + j) * P + p] = gu[j];
-            Q[((size_t)t * nq + m) * P + p] = gT;
-            for (int i = 0; i < 3; ++i) Q[((size_t)t * nq + m + 1 + i) * P + p] = gtau[i];
+            for (int j = 0; j < m; ++j) pstore(Q + ((size_t)t * nq + j) * P + p, 1, n, gu[j]);
+            pstore(Q + ((size_t)t * nq + m) * P + p, 1, n, gT);
+            for (int i = 0; i < 3; ++i) pstore(Q + ((size_t)t * nq + m + 1 + i) * P + p, 1, n, gtau[i]);
         }
     }
     real tot = preduce(Jp, P);
@@ -784,6 +857,7 @@ int NAME(grad)(const sdempc_cfg* C, const void* blob, const float* x0, const flo
     return 0;
 }
 
+#ifndef ORC_VEC
 /* cost as a function of double-precision u (finite-difference tests, ORC_DOUBLE build only keeps the
  * precision; in the float build u is rounded to float) */
 int NAME(cost_du)(const sdempc_cfg* C, const void* blob, const float* x0, const double* u, const float* xref,
@@ -797,6 +871,8 @@ int NAME(cost_du)(const sdempc_cfg* C, const void* blob, const float* x0, const 
     free(ru); free(rx0); free(rxr); free(rn); ctx_free(&X);
     return 0;
 }
+
+#endif /* !ORC_VEC */
 
 int NAME(solve)(const sdempc_cfg* C, const void* blob, const float* x0, const float* xref, const float* noise,
                 const float* u_init, float stepsize_in, float* uopt, float* xevol, float* info8,
@@ -828,6 +904,7 @@ int NAME(solve_batch)(const sdempc_cfg* C, const void* blob, int B, const float*
     return 0;
 }
 
+#ifndef ORC_VEC
 /* fp16 round-toward-zero quantiser, exposed for unit tests */
 double NAME(f16_rtz_value)(double x) { return (double)f16_rtz((real)x); }
 
@@ -843,3 +920,4 @@ int NAME(step)(const sdempc_cfg* C, const void* blob, const float* x, const floa
     free(rx); free(ru); free(rxi); ctx_free(&X);
     return 0;
 }
+#endif /* !ORC_VEC */

@@ -90,7 +90,8 @@ template <class Team, bool F16>
 DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;
-    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: the pair's base addresses stay in SGPRs
     const bool want_mean = xmean_out != nullptr;
     Team::sync();
     block_prepass<Team>(a, sm, u, tid);
@@ -105,8 +106,10 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
     for (int gp = wave; gp < NPAIR; gp += Team::NWAVES) {
         const DuoPair pr = duo_pair(gp, G, h);
         const bool valid = pr.own && (pr.g * 32 + j) < P;
-        const float* nz = a.noise + ((size_t)(b * G + pr.g) * H) * NN * 32 + j;
-        float* tj = a.traj + ((size_t)(b * G + pr.g) * (H + 1)) * NX * 32 + j;
+        // uniform base of the pair (group 2 gp) + a 32-bit per-lane offset (this lane's group and column): scalar-base addressing
+        const int gofs = pr.g - 2 * gp;
+        const float* nz = a.noise + ((size_t)(b * G + 2 * gp) * H) * NN * 32 + (gofs * H * NN * 32 + j);
+        float* tj = a.traj + ((size_t)(b * G + 2 * gp) * (H + 1)) * NX * 32 + (gofs * (H + 1) * NX * 32 + j);
         float* xm = prows + (size_t)pr.g * PS;          // this group's row of per-step particle sums (SPEC.md §6.1/§6.3)
         float x[NX], xn[NX], xi[NN];
 #pragma unroll
@@ -169,7 +172,8 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;
     constexpr int nq = M + 4;
-    const int lane = tid & 63, j = lane & 31, h = lane >> 5, wave = tid >> 6;
+    const int lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: the pair's base addresses stay in SGPRs
     Team::sync();
     block_prepass<Team>(a, sm, y, tid);
     const int PS = part_stride(H);
@@ -184,8 +188,9 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         const DuoPair pr = duo_pair(gp, G, h);
         const bool valid = pr.own && (pr.g * 32 + j) < P;
         const int gA = 2 * gp, gB = pr.hasB ? 2 * gp + 1 : gA;
-        const float* nz = a.noise + ((size_t)(b * G + pr.g) * H) * NN * 32 + j;
-        float* tj = a.traj + ((size_t)(b * G + pr.g) * (H + 1)) * NX * 32 + j;
+        const int gofs = pr.g - gA;
+        const float* nz = a.noise + ((size_t)(b * G + gA) * H) * NN * 32 + (gofs * H * NN * 32 + j);
+        float* tj = a.traj + ((size_t)(b * G + gA) * (H + 1)) * NX * 32 + (gofs * (H + 1) * NX * 32 + j);
         float* acA = a.act + ((size_t)(b * G + gA) * H) * ACT_STRIDE;       // checkpoint rows of the two groups (tiles: whole wave)
         float* acB = a.act + ((size_t)(b * G + gB) * H) * ACT_STRIDE;
         float* acS = (h ? acB : acA) + 1024 + j * 8;                         // this lane's particle: step scalars
@@ -252,8 +257,6 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 #pragma unroll
                 for (int i = 0; i < NN; ++i) xi[i] = nz[(t * NN + i) * 32];
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hB[q] = *reinterpret_cast<const float4*>(apB + (q * 64 + lane) * 4);
             // x = x_{t+1}: fold the stage-cost gradient into the incoming adjoint
             const float dsc = sm.disc[t];
             {
@@ -282,18 +285,17 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 #pragma unroll
             for (int i = 0; i < 6; ++i) half_split(T.ob[i], obA[i], obB[i]);
             SCHED_PHASE();
-            float PzA[NN], PuA[M], PzB[NN], PuB[M], Pdead[7];
-            // pass A: recompute layer 1 only (6 MFMAs, 32 tanh; the rest of fwd_mlp_partials is dead code), layer 2 from the checkpoint
-            fwd_mlp_partials<F16, false>(a, sm, ww, ust, h, lane, zA, A, Pdead);
+            float PzA[NN], PuA[M], PzB[NN], PuB[M];
+            // pass B's second-layer checkpoint is fetched while pass A computes
+            if (pr.hasB) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { A.h2[4 * q] = hA[q].x; A.h2[4 * q + 1] = hA[q].y; A.h2[4 * q + 2] = hA[q].z; A.h2[4 * q + 3] = hA[q].w; }
-            vjp_mlp_partials<M>(sm, h, lane, A, eA, obA, PzA, PuA);
+                for (int q = 0; q < 4; ++q) hB[q] = *reinterpret_cast<const float4*>(apB + (q * 64 + lane) * 4);
+            }
+            // per pass: layer 1 recomputed tile by tile (6 MFMAs, 32 tanh), layer 2 from the checkpoint (adj_mlp_pass)
+            adj_mlp_pass<M, F16>(sm, ww, ust, h, lane, zA, hA, eA, obA, PzA, PuA);
             SCHED_PHASE();
             if (pr.hasB) {
-                fwd_mlp_partials<F16, false>(a, sm, ww, ust, h, lane, zB, A, Pdead);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { A.h2[4 * q] = hB[q].x; A.h2[4 * q + 1] = hB[q].y; A.h2[4 * q + 2] = hB[q].z; A.h2[4 * q + 3] = hB[q].w; }
-                vjp_mlp_partials<M>(sm, h, lane, A, eB, obB, PzB, PuB);
+                adj_mlp_pass<M, F16>(sm, ww, ust, h, lane, zB, hB, eB, obB, PzB, PuB);
             } else {
 #pragma unroll
                 for (int k = 0; k < NN; ++k) PzB[k] = PzA[k];

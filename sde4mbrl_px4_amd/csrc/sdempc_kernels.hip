@@ -246,6 +246,9 @@ DI float wave_bfly64(float v) { return group_bfly32(xor32_sum(v)); }
 // ((w0+w1)+w2)+w3. A team of NT threads walks the 256 virtual lanes in 256/NT passes.
 template <class Team, class F>
 DI float team_reduce256(const Smem& sm, int N, int tid, F&& elem) {
+    // A virtual lane reads the elements e = i, i + 256, ...: with 256 threads (or one wave) those are the elements the same thread wrote
+    // in the caller's preceding `for (e = tid; e < N; e += NT)` loop; any other team size reads elements other waves wrote: barrier first.
+    if constexpr (Team::NT != 256 && Team::NT != 64) Team::sync();
     if constexpr (Team::NT >= 256) {      // the first four waves are the 256 virtual lanes; further waves only take part in the barriers
         float acc = 0.0f;
         if (tid < 256)

@@ -352,6 +352,118 @@ DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, floa
         }
     }
 }
+// One layer-1 tile (3 f32 MFMAs, or one fp16 MFMA) on top of its C operand, then tanh: the drift tile (DRIFT: C = per-step control
+// terms c_t, A = W1z rows 0..31) or the density tile (C = b1 rows 32..63, A = W1z rows 32..63)
+template <bool F16, bool DRIFT>
+DI void layer1_tile(const Smem& sm, const WaveW& ww, const float* ust, int h, const float* z, f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 c4 = *reinterpret_cast<const float4*>((DRIFT ? ust : sm.b1n) + 8 * q + 4 * h);
+        acc[4 * q] = c4.x; acc[4 * q + 1] = c4.y; acc[4 * q + 2] = c4.z; acc[4 * q + 3] = c4.w;
+    }
+    if constexpr (F16) {
+        half8 bv;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            auto pk = __builtin_amdgcn_cvt_pkrtz(h ? 0.0f : z[2 * e], h ? 0.0f : z[2 * e + 1]);
+            bv[2 * e] = (_Float16)pk[0]; bv[2 * e + 1] = (_Float16)pk[1];
+        }
+        bv[6] = (_Float16)0.0f; bv[7] = (_Float16)0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(DRIFT ? ww.h1d : ww.h1n, bv, acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float bb = h ? z[2 * s + 1] : z[2 * s];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(DRIFT ? ww.w1d[s] : ww.w1n[s], bb, acc, 0, 0, 0);
+        }
+    }
+    SCHED_PHASE();
+    tanh_tile<false>(acc);
+}
+
+// The adjoint's MLP work of one 32-particle pass with short live ranges (one hidden tile at a time): density tile recomputed and
+// consumed, then abar2 from the checkpointed second layer (h2c: this lane's four float4 of the tile), W2^T abar2 by MFMA, and only
+// then the drift layer-1 tile recomputed and consumed. Same operations and the same chain order per value as step_fwd's layer 1 +
+// vjp_mlp_partials (density tile first, then the drift tile: SPEC.md §5.4), hence the same bits; peak 32 tile registers instead of 64.
+template <int M, bool F16>
+DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, const float4* h2c,
+                     float ebraw, const float* ob, float* Pz, float* Pu) {
+#pragma unroll
+    for (int k = 0; k < NN; ++k) Pz[k] = 0.0f;
+#pragma unroll
+    for (int jj = 0; jj < M; ++jj) Pu[jj] = 0.0f;
+    {   // density net: abar1n = (w3n * etaraw_bar) * (1 - h1n^2); zbar += W1z[32:64]^T abar1n
+        f32x16 hn;
+        layer1_tile<F16, false>(sm, ww, ust, h, z, hn);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
+            float an0 = (wn4.x * ebraw) * FMA(-hn[4 * q], hn[4 * q], 1.0f);
+            float an1 = (wn4.y * ebraw) * FMA(-hn[4 * q + 1], hn[4 * q + 1], 1.0f);
+            float an2 = (wn4.z * ebraw) * FMA(-hn[4 * q + 2], hn[4 * q + 2], 1.0f);
+            float an3 = (wn4.w * ebraw) * FMA(-hn[4 * q + 3], hn[4 * q + 3], 1.0f);
+#pragma unroll
+            for (int k = 0; k < NN; ++k) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + HID + 8 * q + 4 * h);
+                Pz[k] = FMA(w4.x, an0, Pz[k]); Pz[k] = FMA(w4.y, an1, Pz[k]); Pz[k] = FMA(w4.z, an2, Pz[k]); Pz[k] = FMA(w4.w, an3, Pz[k]);
+            }
+            SCHED_PHASE();
+        }
+    }
+    f32x16 accB;
+    {   // drift net, second layer: abar2 = (W3^T obar) * (1 - h2^2) on the VALU, W2^T abar2 by MFMA in the accumulator layout
+        f32x16 a2b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f, hb3 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
+                hb0 = FMA(w4.x, ob[i], hb0); hb1 = FMA(w4.y, ob[i], hb1); hb2 = FMA(w4.z, ob[i], hb2); hb3 = FMA(w4.w, ob[i], hb3);
+            }
+            const float4 hq = h2c[q];
+            a2b[4 * q] = hb0 * FMA(-hq.x, hq.x, 1.0f);
+            a2b[4 * q + 1] = hb1 * FMA(-hq.y, hq.y, 1.0f);
+            a2b[4 * q + 2] = hb2 * FMA(-hq.z, hq.z, 1.0f);
+            a2b[4 * q + 3] = hb3 * FMA(-hq.w, hq.w, 1.0f);
+            SCHED_PHASE();
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 w4 = *reinterpret_cast<const float4*>(sm.A2T + (q * 64 + lane) * 4);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, a2b[4 * q], accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, a2b[4 * q + 1], accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, a2b[4 * q + 2], accB, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, a2b[4 * q + 3], accB, 0, 0, 0);
+        }
+        SCHED_PHASE();
+    }
+    {   // drift net, first layer: recomputed only now
+        f32x16 hd;
+        layer1_tile<F16, true>(sm, ww, ust, h, z, hd);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float ad0 = accB[4 * q] * FMA(-hd[4 * q], hd[4 * q], 1.0f);
+            float ad1 = accB[4 * q + 1] * FMA(-hd[4 * q + 1], hd[4 * q + 1], 1.0f);
+            float ad2 = accB[4 * q + 2] * FMA(-hd[4 * q + 2], hd[4 * q + 2], 1.0f);
+            float ad3 = accB[4 * q + 3] * FMA(-hd[4 * q + 3], hd[4 * q + 3], 1.0f);
+#pragma unroll
+            for (int k = 0; k < NN; ++k) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + 8 * q + 4 * h);
+                Pz[k] = FMA(w4.x, ad0, Pz[k]); Pz[k] = FMA(w4.y, ad1, Pz[k]); Pz[k] = FMA(w4.z, ad2, Pz[k]); Pz[k] = FMA(w4.w, ad3, Pz[k]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < M; ++jj) {
+                float4 w4 = *reinterpret_cast<const float4*>(sm.W1uT + jj * HID + 8 * q + 4 * h);
+                Pu[jj] = FMA(w4.x, ad0, Pu[jj]); Pu[jj] = FMA(w4.y, ad1, Pu[jj]); Pu[jj] = FMA(w4.z, ad2, Pu[jj]); Pu[jj] = FMA(w4.w, ad3, Pu[jj]);
+            }
+            SCHED_PHASE();
+        }
+    }
+}
+
 template <int M>
 DI void vjp_mlp_tiles(const Smem& sm, int h, int lane, const StepAux& A, const VjpTmp& T, float* zb, float* gq) {
     float Pz[NN], Pu[M];

@@ -24,25 +24,41 @@ def build():
     return so
 
 
+def _native_lib(name):
+    """A -march=native build of oracle/sde_mpc_oracle.c (oracle/Makefile), for bench.py's CPU timing leg only. Rebuilt when missing,
+    stale, or built for another CPU model (the GPU box's host is not the build container's)."""
+    so = os.path.join(ORC_DIR, name + ".so")
+    src = os.path.join(ORC_DIR, "sde_mpc_oracle.c")
+    tag = os.path.join(ORC_DIR, name + ".cpu")
+    try:
+        here = next(l for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        here = ""
+    stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src) or (not os.path.exists(tag)) or open(tag).read() != here
+    if stale:
+        if os.path.exists(so):
+            os.remove(so)
+        subprocess.check_call(["make", "-C", ORC_DIR, "-s", name + ".so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return C.CDLL(so)
+
+
 def lib_fast():
-    """-O3 -march=native build of the same source (oracle/Makefile: liborc_fast.so), for bench.py's CPU timing leg only. Rebuilt when
-    missing, stale, or built for another CPU model (the GPU box's host is not the build container's)."""
+    """liborc_fast.so: the checker's scalar code built -O3 -march=native (same bits, a little faster)."""
     global _LIB_FAST
     if _LIB_FAST is None:
-        so = os.path.join(ORC_DIR, "liborc_fast.so")
-        src = os.path.join(ORC_DIR, "sde_mpc_oracle.c")
-        tag = os.path.join(ORC_DIR, "liborc_fast.cpu")
-        try:
-            here = next(l for l in open("/proc/cpuinfo") if l.startswith("model name"))
-        except Exception:
-            here = ""
-        stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src) or (not os.path.exists(tag)) or open(tag).read() != here
-        if stale:
-            if os.path.exists(so):
-                os.remove(so)
-            subprocess.check_call(["make", "-C", ORC_DIR, "-s", "liborc_fast.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        _LIB_FAST = C.CDLL(so)
+        _LIB_FAST = _native_lib("liborc_fast")
     return _LIB_FAST
+
+
+_LIB_VEC = None
+
+
+def lib_vec():
+    """liborc_vec.so: the particle-vectorised timing build (-DORC_VEC, 16 particles per call, orcv_* symbols; tolerance parity only)."""
+    global _LIB_VEC
+    if _LIB_VEC is None:
+        _LIB_VEC = _native_lib("liborc_vec")
+    return _LIB_VEC
 
 
 def lib():
@@ -109,13 +125,13 @@ def _f32(a):
 class Oracle:
     """Oracle bound to one (config, model blob). double=True selects the float64 build."""
 
-    def __init__(self, mpc_cfg, model, double=False, fast=False):
+    def __init__(self, mpc_cfg, model, double=False, fast=False, vec=False):
         self.cfg_py = mpc_cfg
         self.cfg, self._keep = mpc_cfg.to_cfg()
         self.blob = model.to_blob() if hasattr(model, "to_blob") else bytes(model)
         self._blobbuf = C.create_string_buffer(self.blob, len(self.blob))
-        self.pre = "orcd_" if double else "orc_"
-        self._lib = lib_fast() if fast else lib()
+        self.pre = "orcv_" if vec else ("orcd_" if double else "orc_")
+        self._lib = lib_vec() if vec else (lib_fast() if fast else lib())
         self.H, self.P, self.m = mpc_cfg.horizon, mpc_cfg.num_particles, mpc_cfg.num_motors
 
     def _fn(self, name):

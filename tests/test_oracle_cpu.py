@@ -7,7 +7,7 @@ import pytest
 
 import orc
 from cases import bits_differ, golden_cases, load_golden
-from sde4mbrl_px4_amd import MPCConfig, synthetic_iris
+from sde4mbrl_px4_amd import MPCConfig, synthetic_hexa, synthetic_iris
 from sde4mbrl_px4_amd import workload as W
 
 
@@ -196,3 +196,26 @@ def test_worker_replay_fixture_is_reproduced_by_the_oracle_backed_worker():
         a, b = np.ascontiguousarray(got[k]), np.ascontiguousarray(fx[k])
         assert a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes(), k
     assert len(replay.MODES) >= 30 and fx["sel_idx"].max() == 11 and fx["sel_idx"].min() == 0
+
+
+def test_vectorised_timing_build_agrees_with_the_checker_build():
+    """oracle/liborc_vec.so (-DORC_VEC: the same source, 16 particles per call, contraction allowed) is bench.py's CPU timing leg, never the
+    checker: a full solve must agree with the bit-exact scalar build to well inside the north star's 1e-4 on the controls, ragged particle
+    counts included (dead lanes of the last block)."""
+    from sde4mbrl_px4_amd import MPCConfig
+    for P, m, seed in ((40, 4, 1), (17, 6, 2), (1, 4, 3), (128, 4, 4)):
+        kw = dict(horizon=10, num_short_dt=6, long_step_dt=0.1, num_particles=P, u_slew_coeff=1.0, max_iter=8, max_no_improvement_iter=8)
+        if m == 6:
+            kw.update(input_id=list(range(6)), input_bound=[[1e-4, 1.0]] * 6, uref=[0.42] * 6)
+        cfg = MPCConfig(**kw)
+        model = synthetic_iris() if m == 4 else synthetic_hexa()
+        x0 = W.random_initial_states(1, seed)[0]
+        xref = W.reference_window(0.2, cfg.time_steps)
+        noise = W.make_noise(1, P, 10, seed)[0]
+        u = np.tile(np.asarray(cfg.uref, np.float32), (10, 1))
+        a = orc.Oracle(cfg, model).solve(x0, xref, noise, u, 0.01)
+        b = orc.Oracle(cfg, model, vec=True).solve(x0, xref, noise, u, 0.01)
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-4, atol=1e-4)
+        assert b[2][2] == a[2][2] and b[2][7] == a[2][7]                  # same iteration and line-search counts
+        np.testing.assert_allclose(b[2][5:7], a[2][5:7], rtol=1e-5)

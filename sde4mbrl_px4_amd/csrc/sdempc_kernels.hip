@@ -725,9 +725,9 @@ template <class Team, bool PK> constexpr int solve_waves_per_simd() { return PK 
 // MODE 1 / 2: lane layouts (weights in VGPRs, two waves per SIMD; MODE 2 with PK: one workgroup per CU, spills go to AGPRs)
 // USTG: the per-step control table [H][36] lives in global memory (KArgs::ustg, L1/L2-resident) instead of LDS: long horizons keep three
 // workgroups per CU (C5: 79 KB -> 50 KB per instance)
-template <class Team, int M, bool F16, bool PK = false, int MODE = 0, bool USTG = false>
-__global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 || MODE == 2) ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
-    SDEMPC_KERNEL_PROLOGUE(USTG);
+// One instance's solve (SPEC.md §8) on its team: everything after the LDS staging of the kernel prologue.
+template <class Team, int M, bool F16, bool PK, int MODE>
+DI void solve_instance(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, CoopCtx& CC, const int b, const int tid) {
     const int m = a.m, N = a.H * m;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
     for (int e = tid; e < N; e += Team::NT) {
@@ -824,6 +824,33 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
     }
 }
 
+template <class Team, int M, bool F16, bool PK = false, int MODE = 0, bool USTG = false>
+__global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 || MODE == 2) ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
+    if constexpr (MODE == 3) {
+        // Duo throughput launches are PERSISTENT: the grid holds as many workgroups as are resident at once (launch_duo_m) and every
+        // workgroup walks the instances b = blockIdx.x, + gridDim.x, ... With only two rounds of six small workgroups per CU the
+        // hardware dispatcher's placement of a plain one-workgroup-per-instance grid leaves CUs idle for a sixth of the launch
+        // (tools/occ_probe.hip; measured with SQ_BUSY_CYCLES / SQ_CYCLES); no workgroup depends on another, so nothing needs co-residency.
+        extern __shared__ __attribute__((aligned(16))) float smem[];
+        LaneW LW;
+        CoopCtx CC;
+        const int tid = Team::tid();
+        Smem sm = carve(smem, a.H, a.m, 0, false, !USTG);
+        WaveW ww;
+        load_weights(a, sm, ww, threadIdx.x, Team::BNT);
+        for (int bb = blockIdx.x; bb < a.B; bb += gridDim.x) {
+            const int b = __builtin_amdgcn_readfirstlane(bb);
+            if constexpr (USTG) sm.ust = a.ustg + (size_t)b * a.H * UST;
+            __syncthreads();                       // weights staged / the previous instance's last LDS reads are done
+            load_common<Team>(a, sm, b, tid);
+            solve_instance<Team, M, F16, PK, MODE>(a, sm, ww, LW, CC, b, tid);
+        }
+        return;
+    }
+    SDEMPC_KERNEL_PROLOGUE(USTG);
+    solve_instance<Team, M, F16, PK, MODE>(a, sm, ww, LW, CC, b, tid);
+}
+
 #include "sdempc_spec.inc.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -864,16 +891,32 @@ bool use_global_ust(int H, int m, const LaunchOpts& o, int nwaves = 4) {
     if (o.ustg >= 0) return o.ustg == 1;
     // workgroups per CU: by registers (launch bounds: three waves per SIMD = twelve per CU) at most 12 / nwaves, otherwise what the
     // 160 KB of LDS hold
-    const size_t cap = 160 * 1024, by_regs = 12 / (size_t)nwaves;
+    const size_t cap = 156 * 1024, by_regs = 12 / (size_t)nwaves;      // usable LDS per CU: tools/occ_probe.hip
     auto per_cu = [&](size_t bytes) { const size_t n = bytes ? cap / bytes : by_regs; return n > by_regs ? by_regs : n; };
     return per_cu(smem_bytes(H, m, 1, false, false)) > per_cu(smem_bytes(H, m, 1));
 }
 // Duo tile layout (sdempc_duo.inc.h) for throughput launches of multi-group instances: two waves per instance up to four groups, four
 // waves beyond (SDEMPC_OPT_DUO = 0 keeps the one-group-per-wave layout: A/B, tests)
+// persistent grid: as many workgroups as the device holds at once (registers: twelve waves per CU; LDS: 156 KB usable per CU, measured
+// with tools/occ_probe.hip — three 52 KB workgroups fit, three 53 KB ones do not), each walking its share of the instances
+template <class Kern>
+static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int nwaves, int bnt, bool ust_lds) {
+    const size_t sb = smem_bytes(a.H, a.m, 1, false, ust_lds);
+    hipError_t e = set_smem_attr((const void*)k, sb);
+    if (e != hipSuccess) return e;
+    size_t per_cu = 12 / (size_t)nwaves;
+    const size_t by_lds = (156 * 1024) / (sb ? sb : 1);
+    if (by_lds < per_cu) per_cu = by_lds;
+    if (per_cu < 1) per_cu = 1;
+    size_t grid = per_cu * (size_t)(a.opt.cus > 0 ? a.opt.cus : 256);
+    if (grid > (size_t)a.B) grid = (size_t)a.B;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(bnt), sb, st, a);
+    return hipGetLastError();
+}
 template <class TeamD, int M, bool F16>
 static hipError_t launch_duo_m(const KArgs& a, hipStream_t st) {
-    if (use_global_ust(a.H, a.m, a.opt, TeamD::NWAVES) && a.ustg) return launch_k(sdempc_solve_kernel<TeamD, M, F16, false, 3, true>, a, st, 1, TeamD::BNT, false);
-    return launch_k(sdempc_solve_kernel<TeamD, M, F16, false, 3, false>, a, st, 1, TeamD::BNT);
+    if (use_global_ust(a.H, a.m, a.opt, TeamD::NWAVES) && a.ustg) return launch_persistent(sdempc_solve_kernel<TeamD, M, F16, false, 3, true>, a, st, TeamD::NWAVES, TeamD::BNT, false);
+    return launch_persistent(sdempc_solve_kernel<TeamD, M, F16, false, 3, false>, a, st, TeamD::NWAVES, TeamD::BNT, true);
 }
 template <bool F16>
 static hipError_t launch_duo(const KArgs& a, hipStream_t st) {
@@ -906,7 +949,9 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
         }
     }
     if constexpr (Team::IPB == 1 && !FAST) {
-        if (a.G >= 2 && a.opt.duo != 0) return launch_duo<F16>(a, st);
+        // auto: only where it measured faster — instances of more than four groups (four-wave teams: C3 +1..4 %, C5 +5 %). At C2 (four
+        // groups, two-wave teams) 11 % fewer vector instructions bought nothing ("what bounds the throughput kernel").
+        if (a.G >= 2 && (a.opt.duo == 1 || (a.opt.duo < 0 && a.G > 4))) return launch_duo<F16>(a, st);
         // long horizons: with the control table in LDS only two workgroups fit a CU; without it three do (the kernel is built for three)
         if (use_global_ust(a.H, a.m, a.opt) && a.ustg) {
             if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16, false, 0, true>, a, st, 1, Team::BNT, false);

@@ -278,6 +278,7 @@ def main():
         ev_ms.append(solver.last_kernel_ms())
     torch.cuda.synchronize()
     w_solves, w_grads, w_fwd = solver.work_counters()
+    kernel_name = solver.last_kernel_name()       # the instantiation the timed launches ran, as rocprofv3 names it
     info_h = info.cpu().numpy()
     n_it = float(info_h[:, 2].mean())
     n_ls = float(info_h[:, 7].mean())
@@ -296,15 +297,17 @@ def main():
         k_ms = float(np.mean(ev_ms))
         ach_gbs = bytes_solve * B / (k_ms * 1e-3) / 1e9
         ach_tf = flops_solve * B / (k_ms * 1e-3) / 1e12
-        traffic = None
+        # HBM bytes per launch from the PMC counters: they need rocprofv3 around the process (separate --pmc passes for FETCH_SIZE and
+        # WRITE_SIZE, MI355X_MICROARCH.md), so the figure comes from the committed summary of those passes for this config and batch
+        # (tools/profile_round.sh -> profiles/pmc_traffic.json, which names its source file); null when none was collected
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                rec = json.load(open(pmc))
-                key = f"{os.path.basename(args.config)}:B{B}"
-                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc)).get(f"{os.path.basename(args.config)}:B{B}", {})
+                traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
             except Exception:
-                traffic = None
+                traffic, traffic_src = None, None
         # p50 / p95 latency of a single solve (B=1 launches), outside the timed region: SURVEY.md §8(d) protocol, >= 20 warm-up
         # and >= 1000 timed solves by default, one problem instance after the other (host timestamps around a device sync)
         lat = []
@@ -335,7 +338,7 @@ def main():
                                       "(one particle per wave; three line-search trials and the candidate gradients of the next iteration evaluated at once); bit-identical results",
             "p50_batch_latency_ms": float(np.median(ev_ms)),
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
-                         "traffic": traffic, "kernel": "sdempc::exact::sdempc_solve_kernel<sdempc::exact::%s, %d, %s, false, 0, false>" % ("TeamBlock" if P > 32 else "TeamWave", m if m in (4, 6) else 8, "true" if args.mlp_dtype == "f16" else "false"), "kernel_ms": k_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name, "kernel_ms": k_ms,
                          "note": "f32-exact path: MLP contractions on v_mfma_f32_32x32x2_f32 (157.3 TF dense peak = f32 vector peak); "
                                  "algorithmic flops = SURVEY §8d MLP formula x P*H*(2*N_grad+N_ls+2), N_grad = gradient evaluations actually performed "
                                  "(sdempc_work_counters; identical re-evaluations at an unchanged point are skipped and not counted)"},
@@ -377,11 +380,12 @@ def main():
             out["verified_instances"] = 0
             out["verified_bit_exact"] = None
         if do_cpu:
-            # reported baseline: the same source built -O3 -march=native, one solve at a time per thread on every usable core,
-            # on 2 instances per thread of the same workload (first instances of the GPU batch)
-            n_cpu = min(2 * nthr, B)
+            # reported baseline: the particle-vectorised build, one solve at a time per thread on every usable core, on 40 instances per
+            # thread of the same workload (first instances of the GPU batch; ~10 s of wall time)
+            n_cpu = min(40 * nthr, B)
             v, dt, outs_f = cpu_solve_instances(cfg, blob, nthr, x0_h[:n_cpu], xref_h[:n_cpu], keys[:n_cpu], u0_h[:n_cpu], s0, fast=True)
-            md = max(float(np.max(np.abs(outs_f[i][0] - uopt_h[i]))) for i in range(n_cpu))
+            dev = np.array([float(np.max(np.abs(outs_f[i][0] - uopt_h[i]))) for i in range(n_cpu)])
+            md, mmed = float(dev.max()), float(np.median(dev))
             c1, c1cfg = cpu_c1_single_solve_ms(blob)
             out["cpu_baseline"] = {"value": v, "unit": "solves/s", "cores": nthr, "kind": "port",
                                    "threads_used": nthr, "os_cpu_count": os.cpu_count(), "usable_cores": effective_cores(),
@@ -389,7 +393,7 @@ def main():
                                              f"{nthr} threads = usable host cores: os.cpu_count {os.cpu_count()}, cgroup/affinity limit {effective_cores()}; {dt:.1f} s wall) "
                                              "by the particle-vectorised build of the C oracle (oracle/sde_mpc_oracle.c -DORC_VEC: 16 particles per call, -O3 -march=native, "
                                              "contraction allowed; CPU restatement of SPEC.md, not the reference JAX path: that cannot run here); "
-                                             f"max |uopt - GPU uopt| over the sample {md:.1e}",
+                                             f"|uopt - GPU uopt| over the sample (200-iteration solves; timing build, not the checker): median {mmed:.1e}, max {md:.1e}",
                                    "value_bit_exact_build": (n_ver / dt_exact) if n_ver > 0 and args.mlp_dtype == "f32" else None,
                                    "cpu_c1_single_solve_ms": c1["vec"][0], "cpu_c1_single_solve_ms_scalar_build": c1["scalar"][0],
                                    "cpu_c1_note": f"BASELINE config 1: c1_iris_posctrl_h20_p32.yaml H={c1cfg.horizon} P={c1cfg.num_particles}, one cold-start solve "

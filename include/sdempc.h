@@ -243,6 +243,11 @@ int32_t sdempc_layout_fallbacks(const sdempc_handle* h);
  * not counted). Call after the stream of the last solve has been synchronised. Roofline accounting of bench.py. */
 int sdempc_work_counters(sdempc_handle* h, uint64_t out[4], int32_t reset);
 
+/* Name of the kernel instantiation the last *_dev launch of this handle started, as a profiler prints it (demangled, without the
+ * argument list), e.g. "sdempc::exact::sdempc_solve_kernel<sdempc::exact::TeamBlock, 4, false, false, 0, false>"; empty before the first
+ * launch. For bench.py's roofline record and for matching rocprofv3 kernel traces. */
+int sdempc_last_kernel_name(const sdempc_handle* h, char* buf, size_t n);
+
 /* Times the last *_dev launch on its own stream with HIP events (ms); <0 if unavailable. */
 float sdempc_last_kernel_ms(const sdempc_handle* h);
 

@@ -119,6 +119,8 @@ def load_library():
     lib.sdempc_layout_fallbacks.restype = C.c_int32
     lib.sdempc_work_counters.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     lib.sdempc_work_counters.restype = C.c_int
+    lib.sdempc_last_kernel_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.sdempc_last_kernel_name.restype = C.c_int
     lib.sdempc_last_kernel_ms.argtypes = [vp]
     lib.sdempc_last_kernel_ms.restype = C.c_float
     for name in ("sdempc_set_device", "sdempc_reset", "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch",
@@ -134,6 +136,6 @@ EXPORTED_SYMBOLS = [
     "sdempc_create", "sdempc_destroy", "sdempc_last_error", "sdempc_abi_version", "sdempc_set_device", "sdempc_device_ready", "sdempc_set_option", "sdempc_get_option", "sdempc_reset",
     "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch", "sdempc_noise_dev_floats",
     "sdempc_traj_dev_floats", "sdempc_noise_to_device_layout", "sdempc_solve_batch_dev", "sdempc_rollout_batch_dev",
-    "sdempc_grad_batch_dev", "sdempc_last_kernel_ms", "sdempc_work_counters", "sdempc_solve_status", "sdempc_layout_fallbacks", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev",
+    "sdempc_grad_batch_dev", "sdempc_last_kernel_ms", "sdempc_last_kernel_name", "sdempc_work_counters", "sdempc_solve_status", "sdempc_layout_fallbacks", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev",
     "sdempc_noise_from_keys_dev", "sdempc_noise_from_keys", "sdempc_solve_batch_keys",
 ]

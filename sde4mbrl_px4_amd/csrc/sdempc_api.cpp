@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cxxabi.h>
+
 #include <new>
 #include <string>
 #include <vector>
@@ -70,6 +72,7 @@ struct sdempc_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    const void* last_fn = nullptr;   // host function pointer of the kernel the last *_dev launch started (sdempc_last_kernel_name)
     int spin_us = -1;         // SDEMPC_OPT_COOP_SPIN_US: budget of one grid barrier in microseconds; -1 = derived (coop_spin_ticks)
     float coop_ms_last = 0.0f;   // duration of the last cooperative-layout solve that completed (0: none measured yet)
     int last_coop_B = 0;      // > 0: the last solve launch took the cooperative path with this many instances (error flags to check)
@@ -286,6 +289,7 @@ int timed_launch(sdempc_handle* h, hipStream_t st, F&& f) {
     if (e != hipSuccess) return fail(h, SDEMPC_EDEVICE, "kernel launch failed: %s", hipGetErrorString(e));
     HIPCHK(h, hipEventRecord(h->ev1, st));
     h->timed = true;
+    h->last_fn = last_launched_kernel();
     return 0;
 }
 
@@ -577,6 +581,23 @@ int sdempc_noise_from_keys(sdempc_handle* h, int32_t B, const uint32_t* keys, fl
     HIPCHK(h, launch_relayout(false, (const float*)h->d_noise.p, (float*)h->d_noise_canon.p, B, h->P, h->G, h->H * SDEMPC_NNOISE, h->stream));
     HIPCHK(h, hipMemcpyAsync(noise, h->d_noise_canon.p, sizeof(float) * B * nf, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SDEMPC_OK;
+}
+
+int sdempc_last_kernel_name(const sdempc_handle* h, char* buf, size_t n) {
+    if (!h || !buf || n < 2) return SDEMPC_EINVAL;
+    buf[0] = 0;
+    if (!h->last_fn) return SDEMPC_OK;
+    const char* mangled = hipKernelNameRefByPtr(h->last_fn, h->stream);
+    if (!mangled) return SDEMPC_OK;
+    int status = 0;
+    char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+    std::string name = (status == 0 && dem) ? dem : mangled;
+    free(dem);
+    if (name.rfind("void ", 0) == 0) name = name.substr(5);
+    const size_t par = name.rfind("(sdempc::KArgs)");
+    if (par != std::string::npos) name = name.substr(0, par);
+    snprintf(buf, n, "%s", name.c_str());
     return SDEMPC_OK;
 }
 

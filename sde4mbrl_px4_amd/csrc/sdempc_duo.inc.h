@@ -44,6 +44,17 @@ DI DuoPair duo_pair(int gp, int G, int h) {
     return p;
 }
 
+// The rotation matrix formed a second time (same expressions, same bits) where it is needed again, instead of being kept alive across both MLP
+// passes; the empty asm hides the quaternion's provenance so that the compiler does not simply keep the first copy
+DI void duo_reform_rotation(const float* x, float* Rm) {
+    float xq[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xq[i] = x[i];
+#pragma unroll
+    for (int i = 6; i < 10; ++i) asm volatile("" : "+v"(xq[i]));
+    rot_from_q(xq, Rm);
+}
+
 // One Euler-Maruyama step for the wave's 64 particles. CKPT: stream the second hidden layer of both passes to the groups' checkpoint
 // rows (acA / acB: this step's rows of group A / group B).
 template <bool F16, bool CKPT>
@@ -80,6 +91,7 @@ DI void duo_step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int
     for (int i = 0; i < 6; ++i) o[i] = half_join_sum(PA[i], PB[i]) + a.M.b3[i];
     const float eta = sigmoid_spec(half_join_sum(PA[6], PB[6]) + a.M.b3n);
     SCHED_PHASE();
+    if constexpr (CKPT) duo_reform_rotation(x, A.Rm);   // gradient sweep: nine registers less across both MLP passes (its loop spilled its noise prefetch)
     fwd_tail(a, sm, ust, t, x, xi, A.Rm, o, eta, xn, A);
 }
 
@@ -107,18 +119,20 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
         const DuoPair pr = duo_pair(gp, G, h);
         const bool valid = pr.own && (pr.g * 32 + j) < P;
         // uniform base of the pair (group 2 gp) + a 32-bit per-lane offset (this lane's group and column): scalar-base addressing
-        const int gofs = pr.g - 2 * gp;
-        const float* nz = a.noise + ((size_t)(b * G + 2 * gp) * H) * NN * 32 + (gofs * H * NN * 32 + j);
-        float* tj = a.traj + ((size_t)(b * G + 2 * gp) * (H + 1)) * NX * 32 + (gofs * (H + 1) * NX * 32 + j);
+        const unsigned gofs = (unsigned)(pr.g - 2 * gp);
+        const float* nzb = a.noise + ((size_t)(b * G + 2 * gp) * H) * NN * 32;         // uniform (SGPR) bases of the pair ...
+        float* tjb = a.traj + ((size_t)(b * G + 2 * gp) * (H + 1)) * NX * 32;
+        const unsigned nzo = gofs * (unsigned)(H * NN * 32) + (unsigned)j;              // ... + 32-bit per-lane offsets (group, column)
+        const unsigned tjo = gofs * (unsigned)((H + 1) * NX * 32) + (unsigned)j;
         float* xm = prows + (size_t)pr.g * PS;          // this group's row of per-step particle sums (SPEC.md §6.1/§6.3)
         float x[NX], xn[NX], xi[NN];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = x0r[i];
 #pragma unroll
-        for (int i = 0; i < NN; ++i) xi[i] = nz[i * 32];
+        for (int i = 0; i < NN; ++i) xi[i] = nzb[nzo + (unsigned)(i * 32)];
         if (store_traj && pr.own) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) tj[i * 32] = x[i];
+            for (int i = 0; i < NX; ++i) tjb[tjo + (unsigned)(i * 32)] = x[i];
         }
         if (want_mean) {
 #pragma unroll
@@ -127,10 +141,12 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
         float J = 0.0f;
         StepAux A;
         for (int t = 0; t < H; ++t) {
+            // the noise streams from HBM: next step's rows are requested a whole step ahead (a just-in-time load at the top of the step
+            // measured 33 % slower: the Euler-Maruyama update at the end of the step is not far enough away)
             float xin[NN];
             if (t + 1 < H) {
 #pragma unroll
-                for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
+                for (int i = 0; i < NN; ++i) xin[i] = nzb[nzo + (unsigned)(((t + 1) * NN + i) * 32)];
             }
             duo_step_fwd<F16, false>(a, sm, ww, t, h, lane, pr.hasB, x, xi, xn, A, nullptr, nullptr);
             float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
@@ -143,9 +159,8 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
                 for (int i = 0; i < NN; ++i) xi[i] = xin[i];
             }
             if (store_traj && pr.own) {
-                float* tp = tj + (size_t)(t + 1) * NX * 32;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) tp[i * 32] = x[i];
+                for (int i = 0; i < NX; ++i) tjb[tjo + (unsigned)(((t + 1) * NX + i) * 32)] = x[i];
             }
             if (want_mean) {
 #pragma unroll
@@ -188,12 +203,14 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         const DuoPair pr = duo_pair(gp, G, h);
         const bool valid = pr.own && (pr.g * 32 + j) < P;
         const int gA = 2 * gp, gB = pr.hasB ? 2 * gp + 1 : gA;
-        const int gofs = pr.g - gA;
-        const float* nz = a.noise + ((size_t)(b * G + gA) * H) * NN * 32 + (gofs * H * NN * 32 + j);
-        float* tj = a.traj + ((size_t)(b * G + gA) * (H + 1)) * NX * 32 + (gofs * (H + 1) * NX * 32 + j);
+        const unsigned gofs = (unsigned)(pr.g - gA);
+        const float* nzb = a.noise + ((size_t)(b * G + gA) * H) * NN * 32;             // uniform (SGPR) bases of the pair ...
+        float* tjb = a.traj + ((size_t)(b * G + gA) * (H + 1)) * NX * 32;
+        const unsigned nzo = gofs * (unsigned)(H * NN * 32) + (unsigned)j;              // ... + 32-bit per-lane offsets (group, column)
+        const unsigned tjo = gofs * (unsigned)((H + 1) * NX * 32) + (unsigned)j;
         float* acA = a.act + ((size_t)(b * G + gA) * H) * ACT_STRIDE;       // checkpoint rows of the two groups (tiles: whole wave)
         float* acB = a.act + ((size_t)(b * G + gB) * H) * ACT_STRIDE;
-        float* acS = (h ? acB : acA) + 1024 + j * 8;                         // this lane's particle: step scalars
+        const unsigned aso = gofs * (unsigned)(H * ACT_STRIDE) + 1024u + (unsigned)j * 8u;   // this lane's particle: step scalars, relative to acA
         float* Sq = prows + (size_t)pr.g * PS;                               // this group's row of per-step adjoint sums (SPEC.md §6.1)
         float x[NX], xn[NX], xi[NN];
         StepAux A;
@@ -201,23 +218,23 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = x0r[i];
 #pragma unroll
-        for (int i = 0; i < NN; ++i) xi[i] = nz[i * 32];
+        for (int i = 0; i < NN; ++i) xi[i] = nzb[nzo + (unsigned)(i * 32)];
         if (pr.own) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) tj[i * 32] = x[i];
+            for (int i = 0; i < NX; ++i) tjb[tjo + (unsigned)(i * 32)] = x[i];
         }
         float J = 0.0f;
         for (int t = 0; t < H; ++t) {
             float xin[NN];
             if (t + 1 < H) {
 #pragma unroll
-                for (int i = 0; i < NN; ++i) xin[i] = nz[((t + 1) * NN + i) * 32];
+                for (int i = 0; i < NN; ++i) xin[i] = nzb[nzo + (unsigned)(((t + 1) * NN + i) * 32)];
             }
             duo_step_fwd<F16, true>(a, sm, ww, t, h, lane, pr.hasB, x, xi, xn, A, acA + (size_t)t * ACT_STRIDE, acB + (size_t)t * ACT_STRIDE);
             if (pr.own) {
-                float* sp = acS + (size_t)t * ACT_STRIDE;
-                *reinterpret_cast<float4*>(sp) = make_float4(A.eta, A.Fb[0], A.Fb[1], A.Fb[2]);
-                sp[4] = A.rn;
+                const unsigned so = aso + (unsigned)(t * ACT_STRIDE);
+                *reinterpret_cast<float4*>(acA + so) = make_float4(A.eta, A.Fb[0], A.Fb[1], A.Fb[2]);
+                acA[so + 4] = A.rn;
             }
             float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
             l = FMA(a.C.res_mult * A.eta, A.eta, l);
@@ -229,9 +246,8 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
                 for (int i = 0; i < NN; ++i) xi[i] = xin[i];
             }
             if (pr.own) {
-                float* tp = tj + (size_t)(t + 1) * NX * 32;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) tp[i * 32] = x[i];
+                for (int i = 0; i < NX; ++i) tjb[tjo + (unsigned)(((t + 1) * NX + i) * 32)] = x[i];
             }
         }
         { const float T = group_bfly32(valid ? J : 0.0f); if (j == 0 && pr.own) Sq[PS - 1] = T; }
@@ -247,15 +263,14 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             float4 hA[4], hB[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) hA[q] = *reinterpret_cast<const float4*>(apA + (q * 64 + lane) * 4);
-            const float* sp = acS + (size_t)t * ACT_STRIDE;
-            const float4 ns4 = *reinterpret_cast<const float4*>(sp);
-            const float nrn = sp[4];
+            const unsigned so = aso + (unsigned)(t * ACT_STRIDE);
+            const float4 ns4 = *reinterpret_cast<const float4*>(acA + so);
+            const float nrn = acA[so + 4];
             {
-                const float* tp = tj + (size_t)t * NX * 32;
 #pragma unroll
-                for (int i = 0; i < NX; ++i) xt[i] = tp[i * 32];
+                for (int i = 0; i < NX; ++i) xt[i] = tjb[tjo + (unsigned)((t * NX + i) * 32)];
 #pragma unroll
-                for (int i = 0; i < NN; ++i) xi[i] = nz[(t * NN + i) * 32];
+                for (int i = 0; i < NN; ++i) xi[i] = nzb[nzo + (unsigned)((t * NN + i) * 32)];
             }
             // x = x_{t+1}: fold the stage-cost gradient into the incoming adjoint
             const float dsc = sm.disc[t];
@@ -286,7 +301,8 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             for (int i = 0; i < 6; ++i) half_split(T.ob[i], obA[i], obB[i]);
             SCHED_PHASE();
             float PzA[NN], PuA[M], PzB[NN], PuB[M];
-            // pass B's second-layer checkpoint is fetched while pass A computes
+            // pass B's second-layer checkpoint is requested before pass A computes (requesting it later — once pass A has consumed its own
+            // checkpoint, to reuse the registers — measured 35 % slower: vmcnt is in-order, the wait for it then also covers younger loads)
             if (pr.hasB) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) hB[q] = *reinterpret_cast<const float4*>(apB + (q * 64 + lane) * 4);
@@ -308,6 +324,7 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             for (int k = 0; k < NN; ++k) zb[k] = half_join_sum(PzA[k], PzB[k]);
 #pragma unroll
             for (int jj = 0; jj < M; ++jj) gq[jj] = half_join_sum(PuA[jj], PuB[jj]);
+            duo_reform_rotation(xt, A.Rm);       // nine registers less across both MLP passes
             vjp_tail(sm, t, xt, A, lam, T, zb, lamn);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { lam[i] = lamn[i]; x[i] = xt[i]; }

@@ -87,6 +87,9 @@ __host__ __device__ inline int part_stride(int H) { const int a = H * 12, b = (H
 #endif
 constexpr int ACT_STRIDE = 1280 + 1024 * SDEMPC_CKPT1;
 size_t smem_bytes(int H, int m, int ipb);   // ipb: instances (teams) per workgroup
+// host function pointer of the kernel the calling thread launched last through the launch_* functions below (for sdempc_last_kernel_name)
+void note_kernel(const void* host_fn);
+const void* last_launched_kernel();
 // Cooperative latency path of the solve (exact f32, P >= 2): workgroups per instance, workspace sizes, launcher.
 // coop_max_instances: how many instances fit one workgroup per CU on the current device (0 = path unavailable for this shape)
 int coop_nwg(int P);

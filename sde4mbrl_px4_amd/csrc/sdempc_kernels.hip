@@ -91,6 +91,26 @@ struct TeamBlock2 {
     DI static int team() { return 0; }
     DI static void sync() { __syncthreads(); }
 };
+// Two instances per four-wave workgroup, two waves each: the duo tile layout of instances with up to four particle groups WITHOUT the
+// price of small workgroups (the weights are staged once per workgroup, so the per-step control table stays in LDS at three workgroups =
+// twelve waves per CU). The two teams of a workgroup run independent control flow (different instances), so their barrier cannot be
+// s_barrier: a counter in LDS per team, two arrivals per episode (the arriving wave waits for the counter's next even value).
+__shared__ unsigned sdempc_pair_bar[2];
+struct TeamPair {
+    static constexpr int NT = 128, NWAVES = 2, IPB = 2, BNT = 256;
+    DI static int tid() { return threadIdx.x & 127; }
+    DI static int team() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 7); }
+    DI static void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // this wave's LDS writes are complete before it signals
+        unsigned* c = sdempc_pair_bar + team();
+        unsigned v = 0;
+        if ((threadIdx.x & 63) == 0) v = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        v = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+        const unsigned target = (v | 1u) + 1u;
+        while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
 struct TeamWave {
     static constexpr int NT = 64, NWAVES = 1, IPB = 4, BNT = 256;
     DI static int tid() { return threadIdx.x & 63; }
@@ -835,13 +855,15 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
         LaneW LW;
         CoopCtx CC;
         const int tid = Team::tid();
-        Smem sm = carve(smem, a.H, a.m, 0, false, !USTG);
+        Smem sm = carve(smem, a.H, a.m, Team::team(), false, !USTG);
         WaveW ww;
+        if constexpr (Team::IPB > 1) { if (threadIdx.x < Team::IPB) sdempc_pair_bar[threadIdx.x] = 0u; }
         load_weights(a, sm, ww, threadIdx.x, Team::BNT);
-        for (int bb = blockIdx.x; bb < a.B; bb += gridDim.x) {
+        __syncthreads();                           // weights staged (whole workgroup); from here on every team runs on its own
+        for (int bb = blockIdx.x * Team::IPB + Team::team(); bb < a.B; bb += gridDim.x * Team::IPB) {
             const int b = __builtin_amdgcn_readfirstlane(bb);
             if constexpr (USTG) sm.ust = a.ustg + (size_t)b * a.H * UST;
-            __syncthreads();                       // weights staged / the previous instance's last LDS reads are done
+            Team::sync();                          // the team's previous instance has finished reading its LDS state
             load_common<Team>(a, sm, b, tid);
             solve_instance<Team, M, F16, PK, MODE>(a, sm, ww, LW, CC, b, tid);
         }
@@ -870,6 +892,7 @@ static hipError_t launch_k(Kern k, const KArgs& a, hipStream_t st, int ipb, int 
     const size_t sb = smem_bytes(a.H, a.m, ipb, false, ust_lds);
     hipError_t e = set_smem_attr((const void*)k, sb);
     if (e != hipSuccess) return e;
+    note_kernel((const void*)k);
     hipLaunchKernelGGL(k, dim3((a.B + ipb - 1) / ipb), dim3(bnt), sb, st, a);
     return hipGetLastError();
 }
@@ -900,16 +923,18 @@ bool use_global_ust(int H, int m, const LaunchOpts& o, int nwaves = 4) {
 // persistent grid: as many workgroups as the device holds at once (registers: twelve waves per CU; LDS: 156 KB usable per CU, measured
 // with tools/occ_probe.hip — three 52 KB workgroups fit, three 53 KB ones do not), each walking its share of the instances
 template <class Kern>
-static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int nwaves, int bnt, bool ust_lds) {
-    const size_t sb = smem_bytes(a.H, a.m, 1, false, ust_lds);
+static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int wg_waves, int bnt, bool ust_lds, int ipb = 1) {
+    const size_t sb = smem_bytes(a.H, a.m, ipb, false, ust_lds);
     hipError_t e = set_smem_attr((const void*)k, sb);
     if (e != hipSuccess) return e;
-    size_t per_cu = 12 / (size_t)nwaves;
+    size_t per_cu = 12 / (size_t)wg_waves;
     const size_t by_lds = (156 * 1024) / (sb ? sb : 1);
     if (by_lds < per_cu) per_cu = by_lds;
     if (per_cu < 1) per_cu = 1;
     size_t grid = per_cu * (size_t)(a.opt.cus > 0 ? a.opt.cus : 256);
-    if (grid > (size_t)a.B) grid = (size_t)a.B;
+    const size_t need = ((size_t)a.B + ipb - 1) / ipb;
+    if (grid > need) grid = need;
+    note_kernel((const void*)k);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(bnt), sb, st, a);
     return hipGetLastError();
 }
@@ -918,12 +943,20 @@ static hipError_t launch_duo_m(const KArgs& a, hipStream_t st) {
     if (use_global_ust(a.H, a.m, a.opt, TeamD::NWAVES) && a.ustg) return launch_persistent(sdempc_solve_kernel<TeamD, M, F16, false, 3, true>, a, st, TeamD::NWAVES, TeamD::BNT, false);
     return launch_persistent(sdempc_solve_kernel<TeamD, M, F16, false, 3, false>, a, st, TeamD::NWAVES, TeamD::BNT, true);
 }
+// up to four groups: two waves per instance, two instances per four-wave workgroup (TeamPair) when both fit with the control table in
+// LDS at three workgroups per CU; otherwise 128-thread workgroups (TeamBlock2)
+template <int M, bool F16>
+static hipError_t launch_duo_small(const KArgs& a, hipStream_t st) {
+    if (a.opt.ustg != 1 && smem_bytes(a.H, a.m, 2) * 3 <= 156 * 1024)
+        return launch_persistent(sdempc_solve_kernel<TeamPair, M, F16, false, 3, false>, a, st, 4, TeamPair::BNT, true, 2);
+    return launch_duo_m<TeamBlock2, M, F16>(a, st);
+}
 template <bool F16>
 static hipError_t launch_duo(const KArgs& a, hipStream_t st) {
     if (a.G <= 4) {
-        if (a.m == 4) return launch_duo_m<TeamBlock2, 4, F16>(a, st);
-        if (a.m == 6) return launch_duo_m<TeamBlock2, 6, F16>(a, st);
-        return launch_duo_m<TeamBlock2, 8, F16>(a, st);
+        if (a.m == 4) return launch_duo_small<4, F16>(a, st);
+        if (a.m == 6) return launch_duo_small<6, F16>(a, st);
+        return launch_duo_small<8, F16>(a, st);
     }
     if (a.m == 4) return launch_duo_m<TeamBlock, 4, F16>(a, st);
     if (a.m == 6) return launch_duo_m<TeamBlock, 6, F16>(a, st);
@@ -1012,6 +1045,7 @@ int spec_max_instances(int P, int H, int m, const LaunchOpts& o) {
 // (ROCm 7.2: SIGSEGV in the exit handlers after the profile is written), so it is opt-in.
 template <class K>
 static hipError_t launch_resident(K kern, dim3 grid, dim3 block, size_t sb, hipStream_t st, const KArgs& k) {
+    note_kernel((const void*)kern);
     if (k.opt.coop_launch == 1) {
         KArgs kk = k;
         void* args[] = {(void*)&kk};
@@ -1133,6 +1167,9 @@ hipError_t launch_grad_fast(const KArgs& a, int B, hipStream_t st) { return fast
 hipError_t launch_solve_fast(const KArgs& a, int B, hipStream_t st) { return fastm::launch_solve(a, B, st); }
 #else
 }  // namespace exact
+static thread_local const void* g_last_kernel_fn = nullptr;
+void note_kernel(const void* host_fn) { g_last_kernel_fn = host_fn; }
+const void* last_launched_kernel() { return g_last_kernel_fn; }
 size_t smem_bytes(int H, int m, int ipb) { return exact::smem_bytes(H, m, ipb); }
 int team_ipb(int G, int H, int m) { return exact::team_ipb(G, H, m); }
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) { return exact::launch_rollout(a, B, st); }

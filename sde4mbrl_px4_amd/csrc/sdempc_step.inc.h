@@ -234,7 +234,7 @@ DI float stage_cost(const KArgs& a, const float* x, const float* xr, float* gx) 
 // ------------------------------------------------------------------------------------------------
 // Uniform (per particle) quantities that the three parts of the step's vector-Jacobian product share
 struct VjpTmp {
-    float ebraw, qtb[4], dqb[4], omb[3], Fwb[3], ob[6];
+    float ebraw, qtb[4], omb[3], Fwb[3], ob[6];      // (dqb = qtb * dt is formed in the tail: four registers less across the MLP part)
 };
 
 // ---- head: everything upstream of the MLPs (per particle); gq[M..M+3] = thrust / rotor-torque adjoints ----
@@ -251,9 +251,9 @@ DI void vjp_head(const KArgs& a, const Smem& sm, int t, const float* x, const fl
     for (int i = 0; i < 3; ++i) eb = FMA(L[10 + i] * sdt[3 + i], xi[3 + i], eb);
     T.ebraw = eb * (A.eta * (1.0f - A.eta));
     float dotq = FMA(A.qn[3], L[9], FMA(A.qn[2], L[8], FMA(A.qn[1], L[7], A.qn[0] * L[6])));
-    float* qtb = T.qtb; float* dqb = T.dqb;
+    float* qtb = T.qtb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { qtb[i] = A.rn * FMA(-A.qn[i], dotq, L[6 + i]); dqb[i] = qtb[i] * dt; }
+    for (int i = 0; i < 4; ++i) qtb[i] = A.rn * FMA(-A.qn[i], dotq, L[6 + i]);
     float taub_b[3], crb[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { taub_b[i] = (L[10 + i] * dt) * a.M.iJ[i]; crb[i] = -taub_b[i]; }
@@ -482,7 +482,10 @@ DI void vjp_tail(const Smem& sm, int t, const float* x, const StepAux& A, const 
     const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
     const float* v = x + 3;
     const float* om = x + 10;
-    const float* qtb = T.qtb; const float* dqb = T.dqb; const float* Fwb = T.Fwb;
+    const float* qtb = T.qtb; const float* Fwb = T.Fwb;
+    float dqb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dqb[i] = qtb[i] * dt;
     float omb[3] = {T.omb[0], T.omb[1], T.omb[2]};
 #pragma unroll
     for (int i = 0; i < 3; ++i) omb[i] = omb[i] + zb[3 + i];

@@ -206,5 +206,11 @@ class SdeMpcSolver:
         self._check(self.lib.sdempc_work_counters(self._h, out, int(reset)))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def last_kernel_name(self) -> str:
+        """Kernel instantiation the last *_dev launch started, as rocprofv3 prints it (sdempc_last_kernel_name)."""
+        buf = C.create_string_buffer(512)
+        self._check(self.lib.sdempc_last_kernel_name(self._h, buf, 512))
+        return buf.value.decode()
+
     def last_kernel_ms(self) -> float:
         return float(self.lib.sdempc_last_kernel_ms(self._h))

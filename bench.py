@@ -312,7 +312,7 @@ def main():
         # and >= 1000 timed solves by default, one problem instance after the other (host timestamps around a device sync)
         lat = []
         nv = noise.view(B, -1)
-        for r in range(-args.latency_warmup, args.latency_reps):
+        for r in range(-args.latency_warmup if args.latency_reps > 0 else 0, args.latency_reps):
             i = r % B
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -331,8 +331,8 @@ def main():
             "config": {"workload": f"{os.path.basename(args.config)}: H={H} P={P} m={m}, {B} independent MPC instances per GPU per step, "
                                    f"cold-start solves from the hover guess, max_iter={cfg.max_iter} maxls={cfg.ls_maxls}",
                        "instances_per_gpu": B, "noise": "threefry2x32 keys (seed 10 split per instance), normal draws generated on the device", "N_it_mean": n_it, "N_ls_mean": n_ls, "N_grad_evaluated_mean": n_grad, "N_forward_rollouts_mean": n_fwd, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
-            "p50_solve_latency_ms": float(np.median(lat)),
-            "p95_solve_latency_ms": float(np.percentile(lat, 95)),
+            "p50_solve_latency_ms": float(np.median(lat)) if lat else None,
+            "p95_solve_latency_ms": float(np.percentile(lat, 95)) if lat else None,
             "latency_reps": len(lat), "latency_layout_fallbacks": solver.layout_fallbacks(),
             "p50_solve_latency_note": "one instance alone on the GPU (B = 1 launch of the same C-ABI entry point): the library spreads it over ceil(P/4) x 7 workgroups "
                                       "(one particle per wave; three line-search trials and the candidate gradients of the next iteration evaluated at once); bit-identical results",

@@ -93,6 +93,12 @@ typedef struct sdempc_cfg {
      * hardware transcendentals (v_exp_f32, v_rcp_f32, v_rsq_f32); about 1e-7 relative per operation away from the exact path,
      * deterministic on a given GPU, not reproducible on a CPU. SPEC.md §10. */
     int32_t math_mode;
+    /* state_constr (launch/iris_sitl_traj_mpc.yaml:16-29; commented out in every YAML the reference ships), penalty form
+     * (slack_proximal: False): stage cost += sum_k state_w[k] * (max(0, x[id_k] - hi_k)^2 + max(0, lo_k - x[id_k])^2) at x_{t+1},
+     * state_w = state_penalty * constr_pen (host float32), ids strictly ascending, in the solver's frame. SPEC.md §5.3. */
+    int32_t num_state_constr;         /* 0: none */
+    int32_t state_id[SDEMPC_NX];
+    float state_w[SDEMPC_NX], state_lo[SDEMPC_NX], state_hi[SDEMPC_NX];
 } sdempc_cfg;
 
 /* Optimiser telemetry: the 7 scalars the reference reads from opt_state

@@ -258,6 +258,16 @@ class Restatement:
         ez = fma(-rz, qw, fma(ry, qx, fma(-rx, qy, rw * qz)))
         for w_, e in ((C.qerr[0], ex), (C.qerr[1], ey), (C.qerr[2], ez)):
             l = fma(F(w_) * e, e, l)
+        if C.state_id:                                            # state_constr, penalty form (SPEC.md §5.3)
+            for k, i in enumerate(C.state_id):
+                w = F(F(C.state_penalty[k]) * F(C.constr_pen))
+                with np.errstate(invalid="ignore"):
+                    hi = x[:, i] - F(C.state_bound[k][1])
+                    hi = np.where(hi < 0, F(0), hi).astype(F)
+                    lo = F(C.state_bound[k][0]) - x[:, i]
+                    lo = np.where(lo < 0, F(0), lo).astype(F)
+                l = fma(w * hi, hi, l)
+                l = fma(w * lo, lo, l)
         return l
 
     def particle_sum(self, vals):
@@ -456,6 +466,11 @@ def torch_cost(cfg, model, x0, u, xref, noise):
         ey = rw * qn[:, 2] + rxq * qn[:, 3] - ryq * qn[:, 0] - rzq * qn[:, 1]
         ez = rw * qn[:, 3] - rxq * qn[:, 2] + ryq * qn[:, 1] - rzq * qn[:, 0]
         l = l + float(cfg.qerr[0]) * ex ** 2 + float(cfg.qerr[1]) * ey ** 2 + float(cfg.qerr[2]) * ez ** 2 + float(cfg.res_mult) * eta ** 2
+        if cfg.state_id:
+            for k, i in enumerate(cfg.state_id):
+                w = float(np.float32(cfg.state_penalty[k]) * np.float32(cfg.constr_pen))
+                l = l + w * (torch.clamp(x[:, i] - float(np.float32(cfg.state_bound[k][1])), min=0) ** 2
+                             + torch.clamp(float(np.float32(cfg.state_bound[k][0])) - x[:, i], min=0) ** 2)
         J = J + disc[t] * l
     du = u - T(np.asarray(cfg.uref[:m], np.float64))
     cu = float(cfg.uerr) * du ** 2

@@ -65,6 +65,7 @@ static inline preal pclamp(preal x, float lo, float hi) {
 }
 static inline preal pbroadcast(real v) { return v - (preal){0}; }
 #define PLANE(v, l) ((v)[l])
+#define PPOS(v) psel((v) < pbroadcast(R(0)), pbroadcast(R(0)), (v))      /* v < 0 ? 0 : v  (a NaN stays) */
 #define F16Q(on, v) (v)                                 /* fp16-operand mode is not built for the timing build (ctx_init refuses it) */
 #else
 #define VL 1
@@ -74,6 +75,7 @@ typedef uint32_t puint;
 #define PUB
 #define pbroadcast(v) (v)
 #define PLANE(v, l) (v)
+#define PPOS(v) ((v) < R(0) ? R(0) : (v))
 #define F16Q(on, v) ((on) ? f16_rtz(v) : (v))
 #endif
 
@@ -377,6 +379,15 @@ static preal stage_cost(const sdempc_cfg* C, const preal* x, const real* xr, pre
         gx[7] = PFMA(ry, c, PFMA(-rz, b, rw * a));
         gx[8] = PFMA(-rx, c, PFMA(rw, b, rz * a));
         gx[9] = PFMA(rw, c, PFMA(rx, b, -ry * a));
+    }
+    /* state_constr, penalty form (SPEC.md §5.3; keys launch/iris_sitl_traj_mpc.yaml:16-29): bounded states in ascending index */
+    for (int k = 0; k < C->num_state_constr; ++k) {
+        int i = C->state_id[k];
+        preal hi = x[i] - (real)C->state_hi[k], lo = (real)C->state_lo[k] - x[i];
+        hi = PPOS(hi); lo = PPOS(lo);
+        l = PFMA((real)C->state_w[k] * hi, hi, l);
+        l = PFMA((real)C->state_w[k] * lo, lo, l);
+        if (gx) gx[i] = PFMA(R(2) * (real)C->state_w[k], hi - lo, gx[i]);
     }
     return l;
 }

@@ -44,6 +44,9 @@ class SdempcCfg(C.Structure):
         ("ls_maxls", C.c_int32),
         ("mlp_dtype", C.c_int32),
         ("math_mode", C.c_int32),
+        ("num_state_constr", C.c_int32),
+        ("state_id", C.c_int32 * NX),
+        ("state_w", C.c_float * NX), ("state_lo", C.c_float * NX), ("state_hi", C.c_float * NX),
     ]
 
 

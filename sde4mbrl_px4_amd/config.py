@@ -45,6 +45,11 @@ class MPCConfig:
     u_slew_coeff: float = 0.0
     u_slew_constr: Optional[List[List[float]]] = None
     u_slew_constr_coeff: float = 0.0
+    # state_constr (iris_sitl_traj_mpc.yaml:16-29, commented out in every shipped YAML): penalty form only (slack_proximal: False)
+    state_id: Optional[List[int]] = None
+    state_penalty: Optional[List[float]] = None
+    state_bound: Optional[List[List[float]]] = None
+    constr_pen: float = 1.0
     # horizon / time grid
     horizon: int = 20
     num_short_dt: int = 20
@@ -128,6 +133,18 @@ class MPCConfig:
             raise ValueError(f"linesearch.reset_option must be increase|conservative, got {self.ls_reset_option!r}")
         c.ls_reset_option = 1 if self.ls_reset_option == "increase" else 0
         c.ls_maxls = int(self.ls_maxls)
+        c.num_state_constr = 0
+        if self.state_id:
+            ids = [int(i) for i in self.state_id]
+            if len(ids) != len(self.state_penalty or []) or len(ids) != len(self.state_bound or []):
+                raise ValueError("state_constr: state_id, state_penalty and state_bound must have the same length")
+            if any(i < 0 or i > 12 for i in ids) or any(b <= a for a, b in zip(ids, ids[1:])):
+                raise ValueError("state_constr.state_id must be strictly ascending indices into the 13-state")
+            c.num_state_constr = len(ids)
+            for k, i in enumerate(ids):
+                c.state_id[k] = i
+                c.state_w[k] = float(np.float32(self.state_penalty[k]) * np.float32(self.constr_pen))
+                c.state_lo[k], c.state_hi[k] = float(self.state_bound[k][0]), float(self.state_bound[k][1])
         if self.mlp_dtype not in ("f32", "f16"):
             raise ValueError(f"mlp_dtype must be f32|f16, got {self.mlp_dtype!r}")
         c.mlp_dtype = 1 if self.mlp_dtype == "f16" else 0
@@ -146,8 +163,15 @@ def mpc_config_from_dict(d: dict) -> MPCConfig:
         cfg.input_id = [int(i) for i in ic["input_id"]]
         cfg.input_bound = [[float(a), float(b)] for a, b in ic["input_bound"]]
     cfg.enforce_ubound = bool(d.get("enforce_ubound", True))
-    if "state_constr" in d:
-        raise NotImplementedError("state_constr (slack variables) is commented out in every shipped YAML and is not supported")
+    if d.get("state_constr"):
+        sc = d["state_constr"]
+        if sc.get("slack_proximal", False):
+            raise NotImplementedError("state_constr.slack_proximal: True (slack variables as extra decision variables) is not supported; "
+                                      "the penalty form (slack_proximal: False) is (SPEC.md §5.3)")
+        cfg.state_id = [int(i) for i in sc["state_id"]]
+        cfg.state_penalty = [float(v) for v in sc["state_penalty"]]
+        cfg.state_bound = [[float(a), float(b)] for a, b in sc["state_bound"]]
+        cfg.constr_pen = float(sc.get("constr_pen", 1.0))     # slack_scaling only concerns the slack-variable form
     cp = d.get("cost_params", {})
     m = len(cfg.input_id)
     uref = np.atleast_1d(np.asarray(cp.get("uref", [0.0] * m), dtype=np.float32))

@@ -59,7 +59,7 @@ struct sdempc_handle {
     // host tables
     std::vector<float> h_sdt, h_disc, h_beta;
     // device tables
-    DevBuf d_dt, d_sdt, d_disc, d_beta, d_wts;
+    DevBuf d_dt, d_sdt, d_disc, d_beta, d_wts, d_sctab;
     // workspace + staging (sized for max_batch)
     DevBuf d_ustg;            // per-step control table [B][H][36] of the solve kernel's long-horizon instantiation (KArgs::ustg)
     DevBuf d_part, d_act, d_traj, d_x0, d_u, d_xref, d_noise, d_step, d_cost, d_grad, d_xmean, d_uopt, d_info;
@@ -180,6 +180,15 @@ int ensure_device_impl(sdempc_handle* h) {
     HIPCHK(h, hipMemcpy(h->d_disc.p, h->h_disc.data(), sizeof(float) * (H + 1), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_beta.p, h->h_beta.data(), sizeof(float) * h->h_beta.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->d_wts.p, h->blob_f.data(), sizeof(float) * h->blob_f.size(), hipMemcpyHostToDevice));
+    if (h->cfg.num_state_constr > 0) {       // state_constr table (SPEC.md §5.3)
+        CostK::StateBound tab[SDEMPC_NX];
+        for (int k = 0; k < h->cfg.num_state_constr; ++k)
+            tab[k] = CostK::StateBound{h->cfg.state_id[k], h->cfg.state_w[k], h->cfg.state_lo[k], h->cfg.state_hi[k]};
+        if ((rc = dev_alloc(h, h->d_sctab, sizeof(CostK::StateBound) * h->cfg.num_state_constr))) return rc;
+        HIPCHK(h, hipMemcpy(h->d_sctab.p, tab, sizeof(CostK::StateBound) * h->cfg.num_state_constr, hipMemcpyHostToDevice));
+        h->base.C.sc_n = h->cfg.num_state_constr;
+        h->base.C.sc_tab = (const CostK::StateBound*)h->d_sctab.p;
+    }
     if ((rc = dev_alloc(h, h->d_traj, sizeof(float) * traj_floats(h, B)))) return rc;
     HIPCHK(h, hipMemset(h->d_traj.p, 0, h->d_traj.bytes));
     if ((rc = dev_alloc(h, h->d_act, sizeof(float) * (size_t)B * h->G * H * ACT_STRIDE))) return rc;
@@ -317,6 +326,10 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     if (cfg->horizon < 1 || cfg->horizon > 4096 || cfg->num_particles < 1 || !cfg->time_steps || max_batch < 1)
         return fail(nullptr, SDEMPC_EINVAL, "horizon/num_particles/time_steps/max_batch invalid%s");
     if (cfg->max_iter < 0 || cfg->ls_maxls < 0 || cfg->max_no_improvement_iter < 1) return fail(nullptr, SDEMPC_EINVAL, "apg parameters invalid%s");
+    if (cfg->num_state_constr < 0 || cfg->num_state_constr > SDEMPC_NX) return fail(nullptr, SDEMPC_EINVAL, "num_state_constr out of range%s");
+    for (int k = 0; k < cfg->num_state_constr; ++k)
+        if (cfg->state_id[k] < 0 || cfg->state_id[k] >= SDEMPC_NX || (k > 0 && cfg->state_id[k] <= cfg->state_id[k - 1]))
+            return fail(nullptr, SDEMPC_EINVAL, "state_id must be strictly ascending indices into the 13-state%s");
     for (int t = 0; t < cfg->horizon; ++t)
         if (!(cfg->time_steps[t] > 0.0f)) return fail(nullptr, SDEMPC_EINVAL, "time_steps must be positive%s");
     if (smem_bytes(cfg->horizon, m, team_ipb((cfg->num_particles + 31) / 32, cfg->horizon, m)) > 160 * 1024) return fail(nullptr, SDEMPC_EINVAL, "horizon too large for one workgroup's LDS (160 KiB)%s");
@@ -372,6 +385,7 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
         a.C.slew_lo[j] = cfg->u_slew_lo[j]; a.C.slew_hi[j] = cfg->u_slew_hi[j]; a.C.uref[j] = cfg->uref[j];
         a.C.ulo[j] = cfg->u_lo[j]; a.C.uhi[j] = cfg->u_hi[j];
     }
+    a.C.sc_n = 0; a.C.sc_tab = nullptr;       // the table goes to the device with the other tables (ensure_device)
     a.A.max_iter = cfg->max_iter; a.A.max_noimp = cfg->max_no_improvement_iter; a.A.maxls = cfg->ls_maxls;
     a.A.reset_inc = cfg->ls_reset_option == 1;
     a.A.atol = cfg->atol; a.A.rtol = cfg->rtol; a.A.stepsize = cfg->stepsize; a.A.smax = cfg->ls_max_stepsize;
@@ -393,7 +407,7 @@ namespace {
 void release_device(sdempc_handle* h) {
     if (h->dev_ready || h->stream || h->d_dt.p) {
         (void)hipSetDevice(h->device);
-        for (DevBuf* b : {&h->d_ustg, &h->d_part, &h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys, &h->d_work, &h->d_coop_bar, &h->d_coop_pp, &h->d_coop_ck,
+        for (DevBuf* b : {&h->d_sctab, &h->d_ustg, &h->d_part, &h->d_act, &h->d_dt, &h->d_sdt, &h->d_disc, &h->d_beta, &h->d_wts, &h->d_traj, &h->d_x0, &h->d_u, &h->d_xref, &h->d_noise, &h->d_noise_canon, &h->d_traj_canon, &h->d_keys, &h->d_work, &h->d_coop_bar, &h->d_coop_pp, &h->d_coop_ck,
                           &h->d_step, &h->d_cost, &h->d_grad, &h->d_xmean, &h->d_uopt, &h->d_info})
             dev_free(*b);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -536,7 +550,7 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     // Small batches of multi-particle instances: one instance over ceil(P/4) workgroups, one particle per wave (latency path).
     // Same results bit for bit; only taken when every workgroup of the grid is resident at once.
-    const bool coop_ok = !a.fast && !a.f16 && !h->coop_off;
+    const bool coop_ok = !a.fast && !a.f16 && !h->coop_off && a.C.sc_n == 0;     // lane layouts are built without the state-bound terms
     const int smax = coop_ok ? spec_max_instances(h->P, h->H, h->m, a.opt) : 0;
     int cmax = coop_ok ? coop_max_instances(h->P, h->H, h->m, a.opt) : 0;
     if (smax > cmax) cmax = smax;

@@ -17,6 +17,9 @@ struct CostK {
     float res_mult, uerr, slew, slew_cc;
     int has_sc;
     float slew_lo[8], slew_hi[8], uref[8], ulo[8], uhi[8];
+    int sc_n;                          // state_constr (SPEC.md §5.3): number of bounded states, 0: none
+    struct StateBound { int id; float w, lo, hi; };
+    const StateBound* sc_tab;          // device table [sc_n], ascending state index (owned by the handle)
 };
 struct ApgK {
     int max_iter, max_noimp, maxls, reset_inc;

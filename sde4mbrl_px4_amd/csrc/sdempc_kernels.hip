@@ -998,7 +998,7 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
 }
 // Single-particle lane layout: exact f32 arithmetic only, one wave per instance (SDEMPC_OPT_LANE = 0 forces the tile layout: A/B, tests)
 static bool use_lane(const KArgs& k) {
-    if (FAST || k.f16 || k.P != 1 || !use_wave_team(k.G, k.H, k.m)) return false;
+    if (FAST || k.f16 || k.P != 1 || k.C.sc_n != 0 || !use_wave_team(k.G, k.H, k.m)) return false;   // (state bounds: tile layouts only)
     return k.opt.lane != 0;
 }
 #if SDEMPC_FAST

@@ -241,7 +241,7 @@ DI void lane_particle_rollout(const KArgs& a, const Smem& sm, const LaneW& W, co
         fwd_head(x, A.Rm, z);
         lane_fwd_mlp(a, W, ust, lane, z, h1, h2, o, eta);
         fwd_tail(a, sm, ust, t, x, xi, A.Rm, o, eta, xn, A);
-        float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
+        float l = stage_cost<false, false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
         l = FMA(a.C.res_mult * A.eta, A.eta, l);
         J = FMA(sm.disc[t], l, J);
 #pragma unroll
@@ -301,7 +301,7 @@ DI void lane_particle_grad(const KArgs& a, const Smem& sm, const LaneW& W, const
                 ap[LANE_ACT_SC + 4] = A.rn;
             }
         }
-        float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
+        float l = stage_cost<false, false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
         l = FMA(a.C.res_mult * A.eta, A.eta, l);
         J = FMA(sm.disc[t], l, J);
 #pragma unroll
@@ -348,7 +348,7 @@ DI void lane_particle_grad(const KArgs& a, const Smem& sm, const LaneW& W, const
         const float dsc = sm.disc[t];
         {
             float gx[NX];
-            stage_cost<true>(a, x, sm.xref + (t + 1) * NX, gx);
+            stage_cost<true, false>(a, x, sm.xref + (t + 1) * NX, gx);
 #pragma unroll
             for (int i = 0; i < NX; ++i) lam[i] = FMA(dsc, gx[i], lam[i]);
         }

@@ -203,7 +203,10 @@ DI void rot_from_q(const float* x, float* Rm) {
 }
 
 // SPEC.md §5.3 stage cost at x_{t+1}; GX: also the gradient
-template <bool GX>
+// SC: with the state-bound terms (tile layouts). The lane layouts (single particle, cooperative, speculative) are issue-bound — every
+// instruction of a step is on the critical path, and even the never-taken branch measured +10 % on a single solve — so they are built
+// without them and the C ABI keeps instances with state bounds on the tile layouts.
+template <bool GX, bool SC = true>
 DI float stage_cost(const KArgs& a, const float* x, const float* xr, float* gx) {
     float l = 0.0f;
 #pragma unroll
@@ -224,6 +227,28 @@ DI float stage_cost(const KArgs& a, const float* x, const float* xr, float* gx) 
         gx[7] = FMA(ry, gc, FMA(-rz, gb, rw * ga));
         gx[8] = FMA(-rx, gc, FMA(rw, gb, rz * ga));
         gx[9] = FMA(rw, gc, FMA(rx, gb, -ry * ga));
+    }
+    // state_constr, penalty form (SPEC.md §5.3). Cold path: ONE wave-uniform branch, a rolled loop over the bounded states (ascending index)
+    // whose table is read from memory there, and the state picked by uniform selects — the common case (no bounds) must not pay registers or
+    // basic blocks for it (an unrolled per-state version cost the throughput kernel a third of its speed through register pressure alone).
+    if (SC && __builtin_expect(a.C.sc_n != 0, 0)) {
+#pragma nounroll
+        for (int k = 0; k < a.C.sc_n; ++k) {
+            const int i = a.C.sc_tab[k].id;
+            const float w = a.C.sc_tab[k].w;
+            float xi = x[0];
+#pragma unroll
+            for (int jx = 1; jx < NX; ++jx) xi = (i == jx) ? x[jx] : xi;
+            float hi = xi - a.C.sc_tab[k].hi; hi = hi < 0.0f ? 0.0f : hi;
+            float lo = a.C.sc_tab[k].lo - xi; lo = lo < 0.0f ? 0.0f : lo;
+            l = FMA(w * hi, hi, l);
+            l = FMA(w * lo, lo, l);
+            if (GX) {
+                const float gnew = 2.0f * w;
+#pragma unroll
+                for (int jx = 0; jx < NX; ++jx) gx[jx] = (i == jx) ? FMA(gnew, hi - lo, gx[jx]) : gx[jx];
+            }
+        }
     }
     return l;
 }

@@ -198,3 +198,31 @@ def test_product_and_tools_never_touch_the_oracle():
     assert callers == {"cpu_solve_instances", "cpu_c1_single_solve_ms"}, callers
     timed = src.split("t0 = time.perf_counter()")[1].split("t1 = time.perf_counter()")[0]
     assert "cpu_" not in timed and "orc" not in timed
+
+
+def test_state_constr_section_parses_in_penalty_form(tmp_path):
+    """The state_constr section every reference YAML ships commented out (iris_sitl_traj_mpc.yaml:16-29): uncommented it parses into the
+    penalty form of SPEC.md §5.3; the slack-variable form (slack_proximal: True) is refused with a clear message."""
+    import yaml
+    base = yaml.safe_load(open(os.path.join(CDIR, "iris_traj_shipped_h20_p1.yaml")))
+    base["state_constr"] = {"state_id": [3, 4, 5, 10, 11, 12], "state_penalty": [10.0, 10.0, 20.0, 10.0, 10.0, 10.0],
+                            "slack_scaling": [3.0] * 6, "state_bound": [[-0.5, 0.5], [-0.5, 0.5], [-0.4, 0.7], [-0.8, 0.8], [-0.8, 0.8], [-0.7, 0.7]],
+                            "slack_proximal": False, "constr_pen": 0.1}
+    f = tmp_path / "sc.yaml"
+    f.write_text(yaml.safe_dump(base))
+    c = load_mpc_config(str(f))
+    assert c.state_id == [3, 4, 5, 10, 11, 12] and c.constr_pen == pytest.approx(0.1) and c.state_bound[2] == [-0.4, 0.7]
+    cfg, _ = c.to_cfg()
+    assert cfg.num_state_constr == 6 and list(cfg.state_id)[:6] == [3, 4, 5, 10, 11, 12]
+    assert cfg.state_w[2] == np.float32(np.float32(20.0) * np.float32(0.1)) and cfg.state_lo[2] == np.float32(-0.4) and cfg.state_hi[5] == np.float32(0.7)
+    base["state_constr"]["slack_proximal"] = True
+    f.write_text(yaml.safe_dump(base))
+    with pytest.raises(NotImplementedError, match="slack_proximal"):
+        load_mpc_config(str(f))
+    with pytest.raises(ValueError, match="ascending"):
+        c.replace(state_id=[4, 3, 5, 10, 11, 12]).to_cfg()
+    # the C ABI validates the same
+    from sde4mbrl_px4_amd import synthetic_iris
+    from sde4mbrl_px4_amd.solver import SdeMpcSolver
+    S = SdeMpcSolver(c, synthetic_iris(), max_batch=1)
+    S.close()

@@ -90,6 +90,10 @@ EDGE = {
     "unbounded_u": dict(horizon=10, num_short_dt=10, num_particles=32, enforce_ubound=False),
     "max_iter_0": dict(horizon=8, num_short_dt=8, num_particles=32, max_iter=0),
     "max_no_improvement_1": dict(horizon=8, num_short_dt=8, num_particles=32, max_iter=12, max_no_improvement_iter=1),
+    "state_constr": dict(horizon=12, num_short_dt=12, num_particles=40, state_id=[3, 4, 5, 10, 11, 12], state_penalty=[10.0, 10.0, 20.0, 10.0, 10.0, 10.0],
+                         state_bound=[[-0.5, 0.5], [-0.5, 0.5], [-0.4, 0.7], [-0.8, 0.8], [-0.8, 0.8], [-0.7, 0.7]], constr_pen=0.1),   # iris_sitl_traj_mpc.yaml:16-29
+    "state_constr_open_bounds_P1": dict(horizon=9, num_short_dt=9, num_particles=1, state_id=[2, 5], state_penalty=[50.0, 5.0],
+                                        state_bound=[[0.2, float("inf")], [float("-inf"), 0.1]]),
     "loose_tolerance_early_stop": dict(horizon=8, num_short_dt=8, num_particles=32, max_iter=40, max_no_improvement_iter=40, rtol=5e-2),
 }
 

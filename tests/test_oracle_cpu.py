@@ -219,3 +219,30 @@ def test_vectorised_timing_build_agrees_with_the_checker_build():
         np.testing.assert_allclose(b[1], a[1], rtol=1e-4, atol=1e-4)
         assert b[2][2] == a[2][2] and b[2][7] == a[2][7]                  # same iteration and line-search counts
         np.testing.assert_allclose(b[2][5:7], a[2][5:7], rtol=1e-5)
+
+
+def test_state_constr_penalty_is_active_and_differentiated():
+    """SPEC.md §5.3 state bounds (iris_sitl_traj_mpc.yaml:16-29, penalty form): the term raises the cost when the rollout leaves the box, leaves it
+    unchanged when the box is wide, and its gradient matches central differences of the float64 build."""
+    kw = dict(horizon=8, num_short_dt=8, num_particles=12, u_slew_coeff=1.0)
+    sc = dict(state_id=[3, 4, 5, 10, 11, 12], state_penalty=[10.0, 10.0, 20.0, 10.0, 10.0, 10.0], constr_pen=0.1)
+    tight = MPCConfig(**kw, **sc, state_bound=[[-0.05, 0.05]] * 6)
+    wide = MPCConfig(**kw, **sc, state_bound=[[-1e6, 1e6]] * 6)
+    none = MPCConfig(**kw)
+    model = synthetic_iris()
+    x0 = W.random_initial_states(1, 3)[0]
+    xref = W.reference_window(0.1, none.time_steps)
+    noise = W.make_noise(1, 12, 8, 9)[0]
+    u = np.clip(0.71 + 0.1 * np.random.default_rng(1).standard_normal((8, 4)), 1e-4, 1).astype(np.float32)
+    c_none = orc.Oracle(none, model).rollout(x0, u, xref, noise)[0]
+    c_wide = orc.Oracle(wide, model).rollout(x0, u, xref, noise)[0]
+    c_tight = orc.Oracle(tight, model).rollout(x0, u, xref, noise)[0]
+    assert c_wide == c_none and c_tight > c_none + 0.1                    # (the tracking terms dominate this rollout: 436.3 -> 436.7)
+    Od = orc.Oracle(tight, model, double=True)
+    _, g = Od.grad(x0, u, xref, noise)
+    u64 = u.astype(np.float64)
+    for (t, j) in ((0, 0), (3, 2), (7, 3)):
+        up, um = u64.copy(), u64.copy()
+        up[t, j] += 1e-6; um[t, j] -= 1e-6
+        fd = (Od.cost_du(x0, up, xref, noise) - Od.cost_du(x0, um, xref, noise)) / 2e-6
+        assert abs(fd - g[t, j]) <= 1e-5 * max(1.0, abs(g[t, j])), (t, j, fd, g[t, j])

@@ -25,6 +25,11 @@ def _case(name):
                         u_slew_coeff=0.5, u_slew_constr=[[-0.05, 0.04]] * 6, u_slew_constr_coeff=7.0, res_mult=0.5, max_iter=6, max_no_improvement_iter=3,
                         moment_scale=0.8, ls_maxls=3)
         model = synthetic_hexa()
+    elif name == "state_constr":
+        cfg = MPCConfig(horizon=7, num_short_dt=7, num_particles=35, u_slew_coeff=1.0, max_iter=6, max_no_improvement_iter=6,
+                        state_id=[3, 4, 5, 10, 11, 12], state_penalty=[10.0, 10.0, 20.0, 10.0, 10.0, 10.0], constr_pen=0.1,
+                        state_bound=[[-0.5, 0.5], [-0.5, 0.5], [-0.4, 0.7], [-0.8, 0.8], [-0.8, 0.8], [-0.7, 0.7]])      # iris_sitl_traj_mpc.yaml:16-29
+        model = synthetic_iris()
     else:   # one particle, three rotors, fixed step size, no bounds
         cfg = MPCConfig(horizon=9, num_short_dt=9, num_particles=1, input_id=[0, 1, 2], input_bound=[[1e-4, 1.0]] * 3, uref=[0.6] * 3, enforce_ubound=False,
                         ls_maxls=0, stepsize=2e-4, max_iter=5, max_no_improvement_iter=5)
@@ -66,7 +71,7 @@ def test_elementary_functions_match_the_c_oracle_bit_for_bit():
     assert bits_differ(R2.sigmoid(x * 4), np.array([L.orc_sigmoid(float(v)) for v in x * 4], np.float32)) == 0
 
 
-@pytest.mark.parametrize("name", ["iris", "hexa_slew_constr", "single_particle"])
+@pytest.mark.parametrize("name", ["iris", "hexa_slew_constr", "single_particle", "state_constr"])
 def test_forward_rollout_bit_identical_to_the_c_oracle(name):
     cfg, model, x0, xref, noise, u = _case(name)
     O, N = orc.Oracle(cfg, model), R2.Restatement(cfg, model)
@@ -75,7 +80,7 @@ def test_forward_rollout_bit_identical_to_the_c_oracle(name):
     assert np.float32(c_o) == c_n and bits_differ(traj_n, traj_o) == 0 and bits_differ(mean_n, mean_o) == 0
 
 
-@pytest.mark.parametrize("name", ["iris", "hexa_slew_constr", "single_particle"])
+@pytest.mark.parametrize("name", ["iris", "hexa_slew_constr", "single_particle", "state_constr"])
 def test_optimiser_loop_bit_identical_to_the_c_oracle(name):
     """SPEC.md §8 written a second time (Python control flow, NumPy reductions), fed by the C oracle's cost / gradient: same iterates,
     same line-search decisions, same telemetry."""
@@ -89,7 +94,7 @@ def test_optimiser_loop_bit_identical_to_the_c_oracle(name):
     assert info_o[2] >= 3 and bits_differ(un, uo) == 0 and bits_differ(info_n, info_o) == 0
 
 
-@pytest.mark.parametrize("name", ["iris", "hexa_slew_constr", "single_particle"])
+@pytest.mark.parametrize("name", ["iris", "hexa_slew_constr", "single_particle", "state_constr"])
 def test_adjoint_against_reverse_mode_autodiff(name):
     """The hand-derived vector-Jacobian product of the oracle (SPEC.md §5.4-§5.5) against torch.autograd on a float64 writing of the model
     that shares no code with it: float64 oracle build to 1e-6 (its tables — discount powers, sigma sqrt(dt) — are computed in float64, here

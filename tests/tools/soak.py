@@ -28,6 +28,10 @@ for it in range(n):
               enforce_ubound=bool(rng.random() < 0.85))
     if rng.random() < 0.4: kw.update(u_slew_constr=[[-float(rng.uniform(0.01, 0.1)), float(rng.uniform(0.01, 0.1))]] * m, u_slew_constr_coeff=float(rng.uniform(1, 20)))
     if rng.random() < 0.3: kw.update(moment_scale=float(rng.uniform(0.1, 1.0)))
+    if rng.random() < 0.3:
+        ids = sorted(int(i) for i in rng.choice(13, size=int(rng.integers(1, 7)), replace=False))
+        kw.update(state_id=ids, state_penalty=[float(rng.uniform(0.1, 30)) for _ in ids], constr_pen=float(rng.choice([1.0, 0.1])),
+                  state_bound=[[-float(rng.uniform(0.05, 1.0)), float(rng.uniform(0.05, 1.0))] for _ in ids])
     cfg = MPCConfig(**kw); model = synthetic_multirotor(m, seed=it)
     lname, lopts = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
     used[lname] = used.get(lname, 0) + 1

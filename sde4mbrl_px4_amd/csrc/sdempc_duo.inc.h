@@ -111,9 +111,6 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
     float* prows = a.part + (size_t)b * G * PS;
     float cu = block_ucost<Team>(a, sm, u, tid);
     Team::sync();                                      // prepass table visible to every wave of the team
-    float x0r[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) x0r[i] = a.x0[b * NX + i];
     const int NPAIR = (G + 1) >> 1;
     for (int gp = wave; gp < NPAIR; gp += Team::NWAVES) {
         const DuoPair pr = duo_pair(gp, G, h);
@@ -127,7 +124,7 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
         float* xm = prows + (size_t)pr.g * PS;          // this group's row of per-step particle sums (SPEC.md §6.1/§6.3)
         float x[NX], xn[NX], xi[NN];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = x0r[i];
+        for (int i = 0; i < NX; ++i) x[i] = a.x0[b * NX + i];      // (read here, per pair: nothing of it stays live across the pair loop)
 #pragma unroll
         for (int i = 0; i < NN; ++i) xi[i] = nzb[nzo + (unsigned)(i * 32)];
         if (store_traj && pr.own) {
@@ -195,9 +192,6 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
     float* prows = a.part + (size_t)b * G * PS;
     float cu = block_ucost<Team>(a, sm, y, tid);
     Team::sync();
-    float x0r[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) x0r[i] = a.x0[b * NX + i];
     const int NPAIR = (G + 1) >> 1;
     for (int gp = wave; gp < NPAIR; gp += Team::NWAVES) {
         const DuoPair pr = duo_pair(gp, G, h);
@@ -216,7 +210,7 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         StepAux A;
         // ---- forward sweep, x_t and the second hidden layer streamed to HBM ----
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = x0r[i];
+        for (int i = 0; i < NX; ++i) x[i] = a.x0[b * NX + i];      // (read here, per pair: nothing of it stays live across the pair loop)
 #pragma unroll
         for (int i = 0; i < NN; ++i) xi[i] = nzb[nzo + (unsigned)(i * 32)];
         if (pr.own) {

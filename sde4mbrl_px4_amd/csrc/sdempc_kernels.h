@@ -35,7 +35,7 @@ struct LaunchOpts {
     int pk;            // -1: packed-f32 tanh instantiation when the grid leaves one wave per SIMD (default), 0 / 1: forced
     int ustg;          // -1: per-step control table in global memory when that raises occupancy (default), 0 / 1: forced
     int coop_launch;   // 1: hipLaunchCooperativeKernel for the cooperative layouts, 0: plain launch of a grid sized to be resident (default)
-    int duo;           // throughput launches in the duo tile layout (64 particles per wave): -1 auto (instances of more than four groups), 0 off, 1 on
+    int duo;           // throughput launches in the duo tile layout (64 particles per wave): -1 auto (= on for multi-group instances), 0 off, 1 on
     int coop_fence;    // 1: agent-scope release / acquire fences around the grid barrier, 0: sc1 write-through hand-off only (default)
 };
 struct KArgs {

@@ -982,9 +982,8 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
         }
     }
     if constexpr (Team::IPB == 1 && !FAST) {
-        // auto: only where it measured faster — instances of more than four groups (four-wave teams: C3 +1..4 %, C5 +5 %). At C2 (four
-        // groups, two-wave teams) 11 % fewer vector instructions bought nothing ("what bounds the throughput kernel").
-        if (a.G >= 2 && (a.opt.duo == 1 || (a.opt.duo < 0 && a.G > 4))) return launch_duo<F16>(a, st);
+        // auto: every multi-group instance (measured, same box: C2 +1.3 %, C3 +4.4 %, C5 +7.5 % over one group per wave)
+        if (a.G >= 2 && a.opt.duo != 0) return launch_duo<F16>(a, st);
         // long horizons: with the control table in LDS only two workgroups fit a CU; without it three do (the kernel is built for three)
         if (use_global_ust(a.H, a.m, a.opt) && a.ustg) {
             if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16, false, 0, true>, a, st, 1, Team::BNT, false);

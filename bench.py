@@ -161,11 +161,31 @@ def spawn_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # rank 0's stdout is drained by a thread so that the parent can watch every child: a rank that dies (no GPU for it, bad install)
+    # would otherwise leave the others waiting in the rendezvous / a barrier until the collective timeout
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    failed = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+        if bad:
+            failed = abs(bad[0]) or 1
+            for p in procs:             # exactly the children started above
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    rd.join(timeout=10)
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return failed or max(abs(rc) for rc in rcs)
 
 
 def main():

@@ -67,7 +67,7 @@ DI void duo_step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int
     for (int k = 0; k < NN; ++k) half_split(z[k], zA[k], zB[k]);
     SCHED_PHASE();
     float PA[7], PB[7];
-    fwd_mlp_partials<F16, false>(a, sm, ww, ust, h, lane, zA, A, PA);
+    fwd_mlp_partials<F16, false, CKPT ? 4 : 7>(a, sm, ww, ust, h, lane, zA, A, PA);
     if constexpr (CKPT) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -75,7 +75,7 @@ DI void duo_step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int
     }
     SCHED_PHASE();
     if (hasB) {
-        fwd_mlp_partials<F16, false>(a, sm, ww, ust, h, lane, zB, A, PB);
+        fwd_mlp_partials<F16, false, CKPT ? 4 : 7>(a, sm, ww, ust, h, lane, zB, A, PB);
         if constexpr (CKPT) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)

@@ -27,7 +27,9 @@ DI void fwd_head(const float* x, float* Rm, float* z) {
 // ---- MLPs of a step in the MFMA tile layout (32 particles per wave) ----
 // fwd_mlp_partials: the hidden tiles (A.h1d, A.h1n, A.h2) and the per-half partial chains of the seven output-layer dot products
 // (Po[0..5]: residual force / torque, Po[6]: density pre-activation); fwd_mlp_tiles adds the halves: (P0 + P1) + bias (SPEC.md §5.2).
-template <bool F16, bool PK>
+// OB: how many of the seven output-layer weight quads of a quarter are requested from LDS together (7: all; the gradient's forward sweep,
+// which also carries the noise prefetch and the checkpoint stream, takes 4 + 3: with all seven in flight its noise prefetch spilled)
+template <bool F16, bool PK, int OB = 7>
 DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, StepAux& A, float* Po) {
     // layer 1: C operand = per-step offsets (drift) / bias (density); K = 6 -> 3 MFMAs per tile
     f32x16 accD, accN;
@@ -89,7 +91,7 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 w4 = *reinterpret_cast<const float4*>(sm.A2 + (q * 64 + lane) * 4);
+            float4 w4 = *reinterpret_cast<const float4*>(sm.A2 + (q * 64 + lane) * 4);      // (requesting quad q+1 before these MFMAs: -4 %, registers)
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, accD[4 * q], acc2, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, accD[4 * q + 1], acc2, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, accD[4 * q + 2], acc2, 0, 0, 0);
@@ -102,28 +104,35 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     A.h2 = acc2;
     SCHED_PHASE();
 
-    // output layers on the VALU: per-half partial chains
+    // output layers on the VALU: per-half partial chains (six residual outputs over h2, the density output over h1n). The seven weight
+    // quads of a quarter are requested from LDS together and only then consumed: one exposed LDS round trip per quarter instead of one per
+    // quad (the compiler, left alone, re-used four registers and waited after every read: 28 serialised round trips per pass)
     {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) Po[i] = 0.0f;
+        for (int i = 0; i < 7; ++i) Po[i] = 0.0f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
-                Po[i] = FMA(w4.x, acc2[4 * q], Po[i]); Po[i] = FMA(w4.y, acc2[4 * q + 1], Po[i]); Po[i] = FMA(w4.z, acc2[4 * q + 2], Po[i]); Po[i] = FMA(w4.w, acc2[4 * q + 3], Po[i]);
+            for (int i0 = 0; i0 < 7; i0 += OB) {
+                float4 w[OB];
+#pragma unroll
+                for (int i = 0; i < OB; ++i) {
+                    if (i0 + i < 6) w[i] = *reinterpret_cast<const float4*>(sm.W3 + (i0 + i) * HID + 8 * q + 4 * h);
+                    else if (i0 + i == 6) w[i] = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
+                }
+                SCHED_PHASE();
+#pragma unroll
+                for (int i = 0; i < OB; ++i) {
+                    const int io = i0 + i;
+                    if (io < 6) {
+                        Po[io] = FMA(w[i].x, acc2[4 * q], Po[io]); Po[io] = FMA(w[i].y, acc2[4 * q + 1], Po[io]); Po[io] = FMA(w[i].z, acc2[4 * q + 2], Po[io]); Po[io] = FMA(w[i].w, acc2[4 * q + 3], Po[io]);
+                    } else if (io == 6) {
+                        Po[6] = FMA(w[i].x, accN[4 * q], Po[6]); Po[6] = FMA(w[i].y, accN[4 * q + 1], Po[6]); Po[6] = FMA(w[i].z, accN[4 * q + 2], Po[6]); Po[6] = FMA(w[i].w, accN[4 * q + 3], Po[6]);
+                    }
+                }
+                SCHED_PHASE();
             }
-            SCHED_PHASE();
         }
-    }
-    {
-        float P = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 w4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
-            P = FMA(w4.x, accN[4 * q], P); P = FMA(w4.y, accN[4 * q + 1], P); P = FMA(w4.z, accN[4 * q + 2], P); P = FMA(w4.w, accN[4 * q + 3], P);
-        }
-        Po[6] = P;
     }
 }
 template <bool F16, bool PK>
@@ -420,19 +429,29 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
     {   // density net: abar1n = (w3n * etaraw_bar) * (1 - h1n^2); zbar += W1z[32:64]^T abar1n
         f32x16 hn;
         layer1_tile<F16, false>(sm, ww, ust, h, z, hn);
+        // (weight quads of a quarter are requested from LDS together, then consumed: one exposed LDS round trip per quarter, see fwd_mlp_partials)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
-            float an0 = (wn4.x * ebraw) * FMA(-hn[4 * q], hn[4 * q], 1.0f);
-            float an1 = (wn4.y * ebraw) * FMA(-hn[4 * q + 1], hn[4 * q + 1], 1.0f);
-            float an2 = (wn4.z * ebraw) * FMA(-hn[4 * q + 2], hn[4 * q + 2], 1.0f);
-            float an3 = (wn4.w * ebraw) * FMA(-hn[4 * q + 3], hn[4 * q + 3], 1.0f);
+            float an0, an1, an2, an3;
 #pragma unroll
-            for (int k = 0; k < NN; ++k) {
-                float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + HID + 8 * q + 4 * h);
-                Pz[k] = FMA(w4.x, an0, Pz[k]); Pz[k] = FMA(w4.y, an1, Pz[k]); Pz[k] = FMA(w4.z, an2, Pz[k]); Pz[k] = FMA(w4.w, an3, Pz[k]);
+            for (int k0 = 0; k0 < NN; k0 += 3) {       // three weight quads in flight at a time (the adjoint has no registers for six)
+                float4 wz[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) wz[k] = *reinterpret_cast<const float4*>(sm.W1zT + (k0 + k) * 2 * HID + HID + 8 * q + 4 * h);
+                SCHED_PHASE();
+                if (k0 == 0) {
+                    an0 = (wn4.x * ebraw) * FMA(-hn[4 * q], hn[4 * q], 1.0f);
+                    an1 = (wn4.y * ebraw) * FMA(-hn[4 * q + 1], hn[4 * q + 1], 1.0f);
+                    an2 = (wn4.z * ebraw) * FMA(-hn[4 * q + 2], hn[4 * q + 2], 1.0f);
+                    an3 = (wn4.w * ebraw) * FMA(-hn[4 * q + 3], hn[4 * q + 3], 1.0f);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    Pz[k0 + k] = FMA(wz[k].x, an0, Pz[k0 + k]); Pz[k0 + k] = FMA(wz[k].y, an1, Pz[k0 + k]); Pz[k0 + k] = FMA(wz[k].z, an2, Pz[k0 + k]); Pz[k0 + k] = FMA(wz[k].w, an3, Pz[k0 + k]);
+                }
+                SCHED_PHASE();
             }
-            SCHED_PHASE();
         }
     }
     f32x16 accB;
@@ -442,9 +461,15 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
         for (int q = 0; q < 4; ++q) {
             float hb0 = 0.0f, hb1 = 0.0f, hb2 = 0.0f, hb3 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
-                hb0 = FMA(w4.x, ob[i], hb0); hb1 = FMA(w4.y, ob[i], hb1); hb2 = FMA(w4.z, ob[i], hb2); hb3 = FMA(w4.w, ob[i], hb3);
+            for (int i0 = 0; i0 < 6; i0 += 3) {
+                float4 w3[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) w3[i] = *reinterpret_cast<const float4*>(sm.W3 + (i0 + i) * HID + 8 * q + 4 * h);
+                SCHED_PHASE();
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    hb0 = FMA(w3[i].x, ob[i0 + i], hb0); hb1 = FMA(w3[i].y, ob[i0 + i], hb1); hb2 = FMA(w3[i].z, ob[i0 + i], hb2); hb3 = FMA(w3[i].w, ob[i0 + i], hb3);
+                }
             }
             const float4 hq = h2c[q];
             a2b[4 * q] = hb0 * FMA(-hq.x, hq.x, 1.0f);
@@ -475,14 +500,26 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
             float ad2 = accB[4 * q + 2] * FMA(-hd[4 * q + 2], hd[4 * q + 2], 1.0f);
             float ad3 = accB[4 * q + 3] * FMA(-hd[4 * q + 3], hd[4 * q + 3], 1.0f);
 #pragma unroll
-            for (int k = 0; k < NN; ++k) {
-                float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + 8 * q + 4 * h);
-                Pz[k] = FMA(w4.x, ad0, Pz[k]); Pz[k] = FMA(w4.y, ad1, Pz[k]); Pz[k] = FMA(w4.z, ad2, Pz[k]); Pz[k] = FMA(w4.w, ad3, Pz[k]);
+            for (int k0 = 0; k0 < NN; k0 += 3) {
+                float4 wz[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) wz[k] = *reinterpret_cast<const float4*>(sm.W1zT + (k0 + k) * 2 * HID + 8 * q + 4 * h);
+                SCHED_PHASE();
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    Pz[k0 + k] = FMA(wz[k].x, ad0, Pz[k0 + k]); Pz[k0 + k] = FMA(wz[k].y, ad1, Pz[k0 + k]); Pz[k0 + k] = FMA(wz[k].z, ad2, Pz[k0 + k]); Pz[k0 + k] = FMA(wz[k].w, ad3, Pz[k0 + k]);
+                }
             }
 #pragma unroll
-            for (int jj = 0; jj < M; ++jj) {
-                float4 w4 = *reinterpret_cast<const float4*>(sm.W1uT + jj * HID + 8 * q + 4 * h);
-                Pu[jj] = FMA(w4.x, ad0, Pu[jj]); Pu[jj] = FMA(w4.y, ad1, Pu[jj]); Pu[jj] = FMA(w4.z, ad2, Pu[jj]); Pu[jj] = FMA(w4.w, ad3, Pu[jj]);
+            for (int j0 = 0; j0 < M; j0 += 2) {
+                float4 wu[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) wu[jj] = *reinterpret_cast<const float4*>(sm.W1uT + (j0 + jj) * HID + 8 * q + 4 * h);
+                SCHED_PHASE();
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    Pu[j0 + jj] = FMA(wu[jj].x, ad0, Pu[j0 + jj]); Pu[j0 + jj] = FMA(wu[jj].y, ad1, Pu[j0 + jj]); Pu[j0 + jj] = FMA(wu[jj].z, ad2, Pu[j0 + jj]); Pu[j0 + jj] = FMA(wu[jj].w, ad3, Pu[j0 + jj]);
+                }
             }
             SCHED_PHASE();
         }

@@ -126,7 +126,7 @@ class MpcProblem:
         u0 = np.asarray(opt_state.yk, np.float32)[None]
         uopt, xevol, info = self.solver().solve_keys(xs[None], xref, sub[None], u0, np.array([opt_state.stepsize], np.float32))
         if self.convert_to_enu:                                     # predicted states back in the frame of x
-            xevol = np.stack([enu2ned(r, np) for r in xevol[0]])[None]
+            xevol = enu2ned(xevol, np)
         uo = uopt[0]
         yk = np.concatenate([uo[1:], uo[-1:]], axis=0) if self.shift_warm_start else uo
         i = info[0]

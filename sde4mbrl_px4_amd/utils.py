@@ -17,26 +17,29 @@ _SQ = np.float32(np.sqrt(0.5))
 
 
 def _qmul(a, b, xp):
-    aw, ax, ay, az = a[0], a[1], a[2], a[3]
-    bw, bx, by, bz = b[0], b[1], b[2], b[3]
+    """Hamilton product on the last axis (components are [..., 4]); float32 operations in the order written (no fma in numpy)."""
+    aw, ax, ay, az = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bw, bx, by, bz = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
     return xp.stack([aw * bw - ax * bx - ay * by - az * bz,
                      aw * bx + ax * bw + ay * bz - az * by,
                      aw * by - ax * bz + ay * bw + az * bx,
-                     aw * bz + ax * by - ay * bx + az * bw])
+                     aw * bz + ax * by - ay * bx + az * bw], axis=-1)
 
 
 def enu2ned(x, xp=np):
-    """13-state frame flip world ENU/body FLU <-> world NED/body FRD (an involution).
+    """13-state frame flip world ENU/body FLU <-> world NED/body FRD (an involution); x: [13] or [..., 13] (rows are flipped
+    independently, elementwise — a batch gives the same bits as its rows one by one).
 
     p, v: (x, y, z) -> (y, x, -z); body rates: (wx, wy, wz) -> (wx, -wy, -wz);
     attitude: q' = q_w (x) q (x) q_b with q_w = (0, s, s, 0), q_b = (0, 1, 0, 0), s = sqrt(1/2).
     Signature follows the reference call `enu2ned(curr_state, np)` (sde_control.py:400)."""
     x = xp.asarray(x)
-    p, v, q, w = x[0:3], x[3:6], x[6:10], x[10:13]
+    p, v, q, w = x[..., 0:3], x[..., 3:6], x[..., 6:10], x[..., 10:13]
     qw = xp.asarray([0.0, _SQ, _SQ, 0.0], dtype=x.dtype)
     qb = xp.asarray([0.0, 1.0, 0.0, 0.0], dtype=x.dtype)
     qn = _qmul(_qmul(qw, q, xp), qb, xp)
-    out = xp.concatenate([xp.stack([p[1], p[0], -p[2]]), xp.stack([v[1], v[0], -v[2]]), qn, xp.stack([w[0], -w[1], -w[2]])])
+    out = xp.concatenate([xp.stack([p[..., 1], p[..., 0], -p[..., 2]], axis=-1), xp.stack([v[..., 1], v[..., 0], -v[..., 2]], axis=-1), qn,
+                          xp.stack([w[..., 0], -w[..., 1], -w[..., 2]], axis=-1)], axis=-1)
     return out.astype(x.dtype)
 
 
@@ -98,8 +101,7 @@ class TrajectoryCSV:
         out[..., 6], out[..., 9] = np.cos(0.5 * yaw), np.sin(0.5 * yaw)
         out = out.astype(np.float32)
         if self.ned:
-            flat = out.reshape(-1, 13)
-            out = np.stack([enu2ned(r, np) for r in flat]).reshape(out.shape)
+            out = enu2ned(out, np)
         return out
 
     __call__ = state

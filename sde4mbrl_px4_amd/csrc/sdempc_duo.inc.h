@@ -57,8 +57,41 @@ DI void duo_reform_rotation(const float* x, float* Rm) {
 
 // One Euler-Maruyama step for the wave's 64 particles. CKPT: stream the second hidden layer of both passes to the groups' checkpoint
 // rows (acA / acB: this step's rows of group A / group B).
-template <bool F16, bool CKPT>
-DI void duo_step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, bool hasB, const float* x, const float* xi, float* xn,
+// ------------------------------------------------------------------------------------------------
+// Noise staging of the forward sweeps. The six noise rows of step t are used once, by the Euler-Maruyama update at the END of step t.
+// Held in registers from a request early enough to cover HBM latency they are live across both MLP passes, and the compiler spilled
+// them: load -> s_waitcnt -> scratch store, six synchronous HBM round trips per step. They travel by LDS-DMA instead
+// (global_load_lds_dword: no destination registers): requested right after step t - 1 has consumed its own rows, taken from LDS just
+// before the update of step t. vmcnt retires in order, so the wait leaves the PENDING youngest operations (this step's checkpoint
+// stores, all issued after the request) in flight.
+// ------------------------------------------------------------------------------------------------
+DI void duo_noise_request(const float* nzb, unsigned nzo, int t, const float* stage) {
+    // Written as one asm block: the compiler knows nothing of these six DMAs (declared through the builtin it made every LDS read that
+    // follows — the weights at the top of the next step — wait for them: vmcnt(0) right behind the request). Row i lands at
+    // stage + 256 i bytes: LDS address = M0 + instruction offset + 4 lane, memory address = base + lane offset + instruction offset,
+    // so M0 advances by 128 per row beside the instruction offset's 128. (SALU write of M0 -> LDS-DMA needs a wait state: s_nop.)
+    const float* rows = nzb + (size_t)t * (NN * 32);                                  // uniform: SGPR pair
+    const unsigned m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(const __attribute__((address_space(3))) float*)stage);
+    asm volatile(
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\t"
+        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:128\n\t"
+        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:256\n\t"
+        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:384\n\t"
+        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:512\n\t"
+        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:640"
+        :: "v"(nzo * 4u), "s"(rows), "s"(m0) : "memory", "scc");      // (M0 is a reserved register: the compiler keeps nothing live in it)
+}
+template <int PENDING>
+DI void duo_noise_take(const float* stage, int lane, float* xi) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory");
+#pragma unroll
+    for (int i = 0; i < NN; ++i) xi[i] = stage[i * 64 + lane];
+}
+
+// NZS: noise from the staging rows (above); !NZS: from the caller's registers xi (instances whose LDS has no room for staging rows
+// without losing a workgroup per CU: long horizons)
+template <bool F16, bool CKPT, bool NZS>
+DI void duo_step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, bool hasB, const float* x, const float* xi_reg, float* xn,
                      StepAux& A, float* acA, float* acB) {
     const float* ust = sm.ust + t * UST;
     float z[NN], zA[NN], zB[NN];
@@ -91,14 +124,20 @@ DI void duo_step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int
     for (int i = 0; i < 6; ++i) o[i] = half_join_sum(PA[i], PB[i]) + a.M.b3[i];
     const float eta = sigmoid_spec(half_join_sum(PA[6], PB[6]) + a.M.b3n);
     SCHED_PHASE();
-    if constexpr (CKPT) duo_reform_rotation(x, A.Rm);   // gradient sweep: nine registers less across both MLP passes (its loop spilled its noise prefetch)
+    if constexpr (CKPT) duo_reform_rotation(x, A.Rm);   // gradient sweep: nine registers less across both MLP passes
+    float xi[NN];
+    if constexpr (NZS) duo_noise_take<CKPT ? 4 : 0>(sm.nzs, lane, xi);     // (gradient sweep: pass A's four checkpoint stores at least are younger than the request)
+    else {
+#pragma unroll
+        for (int i = 0; i < NN; ++i) xi[i] = xi_reg[i];
+    }
     fwd_tail(a, sm, ust, t, x, xi, A.Rm, o, eta, xn, A);
 }
 
 // ------------------------------------------------------------------------------------------------
 // team-level rollout: expected cost of control sequence u (LDS). Same contract as block_rollout.
 // ------------------------------------------------------------------------------------------------
-template <class Team, bool F16>
+template <class Team, bool F16, bool NZS>
 DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;
@@ -125,8 +164,16 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
         float x[NX], xn[NX], xi[NN];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = a.x0[b * NX + i];      // (read here, per pair: nothing of it stays live across the pair loop)
+        if constexpr (NZS) {
+            duo_noise_request(nzb, nzo, 0, sm.nzs);
+            // the initial state is in registers BEFORE the step loop: left to the compiler its wait sits in the loop header (first use),
+            // where every iteration it would also wait for the DMAs requested at the end of the previous step
 #pragma unroll
-        for (int i = 0; i < NN; ++i) xi[i] = nzb[nzo + (unsigned)(i * 32)];
+            for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(x[i]));
+        } else {
+#pragma unroll
+            for (int i = 0; i < NN; ++i) xi[i] = nzb[nzo + (unsigned)(i * 32)];
+        }
         if (store_traj && pr.own) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) tjb[tjo + (unsigned)(i * 32)] = x[i];
@@ -138,22 +185,27 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
         float J = 0.0f;
         StepAux A;
         for (int t = 0; t < H; ++t) {
-            // the noise streams from HBM: next step's rows are requested a whole step ahead (a just-in-time load at the top of the step
-            // measured 33 % slower: the Euler-Maruyama update at the end of the step is not far enough away)
+            // !NZS: next step's rows requested a whole step ahead into registers (a just-in-time load at the top of the step measured 33 %
+            // slower: the compiler sinks it to its use)
             float xin[NN];
-            if (t + 1 < H) {
+            if constexpr (!NZS) {
+                if (t + 1 < H) {
 #pragma unroll
-                for (int i = 0; i < NN; ++i) xin[i] = nzb[nzo + (unsigned)(((t + 1) * NN + i) * 32)];
+                    for (int i = 0; i < NN; ++i) xin[i] = nzb[nzo + (unsigned)(((t + 1) * NN + i) * 32)];
+                }
             }
-            duo_step_fwd<F16, false>(a, sm, ww, t, h, lane, pr.hasB, x, xi, xn, A, nullptr, nullptr);
+            duo_step_fwd<F16, false, NZS>(a, sm, ww, t, h, lane, pr.hasB, x, xi, xn, A, nullptr, nullptr);
+            if constexpr (NZS) { if (t + 1 < H) duo_noise_request(nzb, nzo, t + 1, sm.nzs); }     // a whole step ahead of its use
             float l = stage_cost<false>(a, xn, sm.xref + (t + 1) * NX, nullptr);
             l = FMA(a.C.res_mult * A.eta, A.eta, l);
             J = FMA(sm.disc[t], l, J);
 #pragma unroll
             for (int i = 0; i < NX; ++i) x[i] = xn[i];
-            if (t + 1 < H) {
+            if constexpr (!NZS) {
+                if (t + 1 < H) {
 #pragma unroll
-                for (int i = 0; i < NN; ++i) xi[i] = xin[i];
+                    for (int i = 0; i < NN; ++i) xi[i] = xin[i];
+                }
             }
             if (store_traj && pr.own) {
 #pragma unroll
@@ -179,7 +231,7 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
 // team-level cost + gradient (forward sweep with trajectory / checkpoint store, adjoint sweep). Same contract as block_cost_grad;
 // no register prefetch buffer: built for three waves per SIMD, which hide the latency of the adjoint's loads.
 // ------------------------------------------------------------------------------------------------
-template <class Team, int M, bool F16>
+template <class Team, int M, bool F16, bool NZS>
 DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const float* y, float* gout, int b, int tid) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;
@@ -211,20 +263,29 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         // ---- forward sweep, x_t and the second hidden layer streamed to HBM ----
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = a.x0[b * NX + i];      // (read here, per pair: nothing of it stays live across the pair loop)
-#pragma unroll
-        for (int i = 0; i < NN; ++i) xi[i] = nzb[nzo + (unsigned)(i * 32)];
         if (pr.own) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) tjb[tjo + (unsigned)(i * 32)] = x[i];
         }
+        if constexpr (NZS) {
+            duo_noise_request(nzb, nzo, 0, sm.nzs);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) asm volatile("" : "+v"(x[i]));      // (as in duo_rollout: no wait for the initial state inside the loop)
+        } else {
+#pragma unroll
+            for (int i = 0; i < NN; ++i) xi[i] = nzb[nzo + (unsigned)(i * 32)];
+        }
         float J = 0.0f;
         for (int t = 0; t < H; ++t) {
             float xin[NN];
-            if (t + 1 < H) {
+            if constexpr (!NZS) {
+                if (t + 1 < H) {
 #pragma unroll
-                for (int i = 0; i < NN; ++i) xin[i] = nzb[nzo + (unsigned)(((t + 1) * NN + i) * 32)];
+                    for (int i = 0; i < NN; ++i) xin[i] = nzb[nzo + (unsigned)(((t + 1) * NN + i) * 32)];
+                }
             }
-            duo_step_fwd<F16, true>(a, sm, ww, t, h, lane, pr.hasB, x, xi, xn, A, acA + (size_t)t * ACT_STRIDE, acB + (size_t)t * ACT_STRIDE);
+            duo_step_fwd<F16, true, NZS>(a, sm, ww, t, h, lane, pr.hasB, x, xi, xn, A, acA + (size_t)t * ACT_STRIDE, acB + (size_t)t * ACT_STRIDE);
+            if constexpr (NZS) { if (t + 1 < H) duo_noise_request(nzb, nzo, t + 1, sm.nzs); }   // before this step's scalar / trajectory stores: older than they are
             if (pr.own) {
                 const unsigned so = aso + (unsigned)(t * ACT_STRIDE);
                 *reinterpret_cast<float4*>(acA + so) = make_float4(A.eta, A.Fb[0], A.Fb[1], A.Fb[2]);
@@ -235,9 +296,11 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             J = FMA(sm.disc[t], l, J);
 #pragma unroll
             for (int i = 0; i < NX; ++i) x[i] = xn[i];
-            if (t + 1 < H) {
+            if constexpr (!NZS) {
+                if (t + 1 < H) {
 #pragma unroll
-                for (int i = 0; i < NN; ++i) xi[i] = xin[i];
+                    for (int i = 0; i < NN; ++i) xi[i] = xin[i];
+                }
             }
             if (pr.own) {
 #pragma unroll

@@ -134,7 +134,9 @@ struct Smem {
     float *red;                                        // [16] block-reduction scratch
     float *tot;                                        // cooperative path only: [H*12] particle sums of the adjoint outputs
     float *v[6];                                       // N-vectors: 0 xk, 1 yk, 2 xn, 3 g, 4 d1, 5 ucur
+    float *nzs;                                        // duo layout only: this WAVE's noise staging rows [6][64] (LDS-DMA target), behind every team's state
 };
+constexpr int NZ_STAGE = 6 * 64;                       // floats per wave
 constexpr int UST = 36;
 
 DI Smem carve(float* base, int H, int m, int team, bool coop = false, bool ust_lds = true) {
@@ -163,13 +165,18 @@ DI Smem carve(float* base, int H, int m, int team, bool coop = false, bool ust_l
     s.red = p; p += 16;
     for (int i = 0; i < 6; ++i) { s.v[i] = p; p += nv; }
     s.tot = p;                       // only the cooperative kernel (one team per workgroup) reserves it: see smem_bytes
+    s.nzs = nullptr;                 // set by the duo kernel (smem_floats(...) + wave * NZ_STAGE)
     (void)coop;
     return s;
 }
-size_t smem_bytes(int H, int m, int ipb, bool coop = false, bool ust_lds = true) {
+__host__ __device__ inline size_t smem_floats(int H, int m, int ipb, bool coop = false, bool ust_lds = true) {
     size_t shared = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + 2 * HID * HID + 512 + ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3);
     size_t per_team = (ust_lds ? (size_t)H * UST : 0) + (((H + 1) * NX + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
-    return (shared + ipb * per_team + (coop ? (size_t)((H * 12 + 3) & ~3) : 0)) * sizeof(float);
+    return shared + ipb * per_team + (coop ? (size_t)((H * 12 + 3) & ~3) : 0);
+}
+// nz_waves: waves per workgroup that get a noise staging area (duo launches), 0 otherwise
+size_t smem_bytes(int H, int m, int ipb, bool coop = false, bool ust_lds = true, int nz_waves = 0) {
+    return (smem_floats(H, m, ipb, coop, ust_lds) + (size_t)nz_waves * NZ_STAGE) * sizeof(float);
 }
 
 // blob float payload offsets (SPEC.md §2)
@@ -670,14 +677,14 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 // wave, one instance over several workgroups); 3: duo tile layout (64 particles per wave, throughput launches)
 template <class Team, bool F16, bool PK, int MODE>
 DI float team_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, CoopCtx& CC, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
-    if constexpr (MODE == 3) return duo_rollout<Team, F16>(a, sm, ww, u, b, tid, store_traj, xmean_out);
+    if constexpr (MODE >= 3) return duo_rollout<Team, F16, MODE == 3>(a, sm, ww, u, b, tid, store_traj, xmean_out);
     else if constexpr (MODE == 2) return coop_rollout<Team>(a, sm, LW, CC, u, b, tid, xmean_out);
     else if constexpr (MODE == 1) return lane_rollout<Team>(a, sm, LW, u, b, tid, store_traj, xmean_out);
     else return block_rollout<Team, F16, PK>(a, sm, ww, u, b, tid, store_traj, xmean_out);
 }
 template <class Team, int M, bool F16, bool PK, bool PREF, int MODE>
 DI float team_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, CoopCtx& CC, const float* y, float* gout, int b, int tid) {
-    if constexpr (MODE == 3) return duo_cost_grad<Team, M, F16>(a, sm, ww, y, gout, b, tid);
+    if constexpr (MODE >= 3) return duo_cost_grad<Team, M, F16, MODE == 3>(a, sm, ww, y, gout, b, tid);
     else if constexpr (MODE == 2) return coop_cost_grad<Team, M>(a, sm, LW, CC, y, gout, b, tid);
     else if constexpr (MODE == 1) return lane_cost_grad<Team, M>(a, sm, LW, y, gout, b, tid);
     else return block_cost_grad<Team, M, F16, PK, PREF>(a, sm, ww, y, gout, b, tid);
@@ -846,8 +853,8 @@ DI void solve_instance(const KArgs& a, const Smem& sm, const WaveW& ww, const La
 
 template <class Team, int M, bool F16, bool PK = false, int MODE = 0, bool USTG = false>
 __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 || MODE == 2) ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
-    if constexpr (MODE == 3) {
-        // Duo throughput launches are PERSISTENT: the grid holds as many workgroups as are resident at once (launch_duo_m) and every
+    if constexpr (MODE >= 3) {
+        // Duo throughput launches (MODE 3: noise through LDS staging rows; 4: through registers) are PERSISTENT: the grid holds as many workgroups as are resident at once (launch_duo_m) and every
         // workgroup walks the instances b = blockIdx.x, + gridDim.x, ... With only two rounds of six small workgroups per CU the
         // hardware dispatcher's placement of a plain one-workgroup-per-instance grid leaves CUs idle for a sixth of the launch
         // (tools/occ_probe.hip; measured with SQ_BUSY_CYCLES / SQ_CYCLES); no workgroup depends on another, so nothing needs co-residency.
@@ -856,6 +863,7 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
         CoopCtx CC;
         const int tid = Team::tid();
         Smem sm = carve(smem, a.H, a.m, Team::team(), false, !USTG);
+        if constexpr (MODE == 3) sm.nzs = smem + smem_floats(a.H, a.m, Team::IPB, false, !USTG) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * NZ_STAGE;
         WaveW ww;
         if constexpr (Team::IPB > 1) { if (threadIdx.x < Team::IPB) sdempc_pair_bar[threadIdx.x] = 0u; }
         load_weights(a, sm, ww, threadIdx.x, Team::BNT);
@@ -923,8 +931,8 @@ bool use_global_ust(int H, int m, const LaunchOpts& o, int nwaves = 4) {
 // persistent grid: as many workgroups as the device holds at once (registers: twelve waves per CU; LDS: 156 KB usable per CU, measured
 // with tools/occ_probe.hip — three 52 KB workgroups fit, three 53 KB ones do not), each walking its share of the instances
 template <class Kern>
-static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int wg_waves, int bnt, bool ust_lds, int ipb = 1) {
-    const size_t sb = smem_bytes(a.H, a.m, ipb, false, ust_lds);
+static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int wg_waves, int bnt, bool ust_lds, int ipb = 1, bool stage = true) {
+    const size_t sb = smem_bytes(a.H, a.m, ipb, false, ust_lds, stage ? wg_waves : 0);      // + one noise staging area per wave
     hipError_t e = set_smem_attr((const void*)k, sb);
     if (e != hipSuccess) return e;
     size_t per_cu = 12 / (size_t)wg_waves;
@@ -938,16 +946,28 @@ static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int 
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(bnt), sb, st, a);
     return hipGetLastError();
 }
+// Which of the three builds of a duo team shape: noise staging rows + control table in LDS, staging rows + table in global memory, or
+// neither in LDS (long horizons) — the first in that order of preference that keeps the most workgroups per CU.
 template <class TeamD, int M, bool F16>
 static hipError_t launch_duo_m(const KArgs& a, hipStream_t st) {
-    if (use_global_ust(a.H, a.m, a.opt, TeamD::NWAVES) && a.ustg) return launch_persistent(sdempc_solve_kernel<TeamD, M, F16, false, 3, true>, a, st, TeamD::NWAVES, TeamD::BNT, false);
-    return launch_persistent(sdempc_solve_kernel<TeamD, M, F16, false, 3, false>, a, st, TeamD::NWAVES, TeamD::BNT, true);
+    constexpr int W = TeamD::NWAVES;
+    const size_t cap = 156 * 1024, by_regs = 12 / (size_t)W;
+    auto per_cu = [&](bool ust_lds, bool stage) { const size_t n = cap / smem_bytes(a.H, a.m, 1, false, ust_lds, stage ? W : 0); return n > by_regs ? by_regs : n; };
+    const bool can_g = a.ustg != nullptr && a.opt.ustg != 0, must_g = can_g && a.opt.ustg == 1;
+    int pick = 0;                                            // 0: stage + LDS table, 1: stage + global table, 2: global table only
+    size_t best = must_g ? 0 : per_cu(true, true);
+    if (must_g) pick = 1, best = per_cu(false, true);
+    else if (can_g && per_cu(false, true) > best) pick = 1, best = per_cu(false, true);
+    if (can_g && per_cu(false, false) > best) pick = 2;
+    if (pick == 2) return launch_persistent(sdempc_solve_kernel<TeamD, M, F16, false, 4, true>, a, st, W, TeamD::BNT, false, 1, false);
+    if (pick == 1) return launch_persistent(sdempc_solve_kernel<TeamD, M, F16, false, 3, true>, a, st, W, TeamD::BNT, false);
+    return launch_persistent(sdempc_solve_kernel<TeamD, M, F16, false, 3, false>, a, st, W, TeamD::BNT, true);
 }
 // up to four groups: two waves per instance, two instances per four-wave workgroup (TeamPair) when both fit with the control table in
 // LDS at three workgroups per CU; otherwise 128-thread workgroups (TeamBlock2)
 template <int M, bool F16>
 static hipError_t launch_duo_small(const KArgs& a, hipStream_t st) {
-    if (a.opt.ustg != 1 && smem_bytes(a.H, a.m, 2) * 3 <= 156 * 1024)
+    if (a.opt.ustg != 1 && smem_bytes(a.H, a.m, 2, false, true, 4) * 3 <= 156 * 1024)
         return launch_persistent(sdempc_solve_kernel<TeamPair, M, F16, false, 3, false>, a, st, 4, TeamPair::BNT, true, 2);
     return launch_duo_m<TeamBlock2, M, F16>(a, st);
 }

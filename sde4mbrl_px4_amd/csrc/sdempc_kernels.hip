@@ -40,6 +40,13 @@
 #ifndef SDEMPC_FAST
 #define SDEMPC_FAST 0
 #endif
+// The exact-mode build is spread over three translation units so that `make -j` compiles them side by side (one hipcc process per
+// unit; the solve kernel has ~90 instantiations of ~25k instructions each): SDEMPC_TU = 0 — every kernel except the duo solve
+// kernels, and all launchers; 1 — the duo solve kernels of the two-wave teams (TeamPair, TeamBlock2); 2 — those of the four-wave
+// team (TeamBlock). Units 1 and 2 hold nothing but explicit instantiations (list macros below), unit 0 declares them `extern template`.
+#ifndef SDEMPC_TU
+#define SDEMPC_TU 0
+#endif
 
 namespace sdempc {
 #if SDEMPC_FAST
@@ -175,7 +182,7 @@ __host__ __device__ inline size_t smem_floats(int H, int m, int ipb, bool coop =
     return shared + ipb * per_team + (coop ? (size_t)((H * 12 + 3) & ~3) : 0);
 }
 // nz_waves: waves per workgroup that get a noise staging area (duo launches), 0 otherwise
-size_t smem_bytes(int H, int m, int ipb, bool coop = false, bool ust_lds = true, int nz_waves = 0) {
+inline size_t smem_bytes(int H, int m, int ipb, bool coop = false, bool ust_lds = true, int nz_waves = 0) {
     return (smem_floats(H, m, ipb, coop, ust_lds) + (size_t)nz_waves * NZ_STAGE) * sizeof(float);
 }
 
@@ -881,6 +888,31 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
     solve_instance<Team, M, F16, PK, MODE>(a, sm, ww, LW, CC, b, tid);
 }
 
+// duo solve kernels (MODE 3: noise staging rows, control table in LDS or global memory; MODE 4: neither in LDS), by team shape
+#define SDEMPC_DUO_M(X, TEAM, M)                                                                                   \
+    X(TEAM, M, false, 3, false) X(TEAM, M, true, 3, false) X(TEAM, M, false, 3, true) X(TEAM, M, true, 3, true)  \
+    X(TEAM, M, false, 4, true) X(TEAM, M, true, 4, true)
+#define SDEMPC_DUO_TEAM(X, TEAM) SDEMPC_DUO_M(X, TEAM, 4) SDEMPC_DUO_M(X, TEAM, 6) SDEMPC_DUO_M(X, TEAM, 8)
+#define SDEMPC_DUO_PAIR(X)                                                                                          \
+    X(TeamPair, 4, false, 3, false) X(TeamPair, 4, true, 3, false) X(TeamPair, 6, false, 3, false) X(TeamPair, 6, true, 3, false) \
+    X(TeamPair, 8, false, 3, false) X(TeamPair, 8, true, 3, false)
+#define SDEMPC_DUO_DECL(TEAM, M, F16, MODE, USTG) extern template __global__ void sdempc_solve_kernel<TEAM, M, F16, false, MODE, USTG>(KArgs);
+#define SDEMPC_DUO_DEF(TEAM, M, F16, MODE, USTG) template __global__ void sdempc_solve_kernel<TEAM, M, F16, false, MODE, USTG>(KArgs);
+
+#if SDEMPC_TU == 1
+SDEMPC_DUO_PAIR(SDEMPC_DUO_DEF)
+SDEMPC_DUO_TEAM(SDEMPC_DUO_DEF, TeamBlock2)
+}  // namespace exact
+#elif SDEMPC_TU == 2
+SDEMPC_DUO_TEAM(SDEMPC_DUO_DEF, TeamBlock)
+}  // namespace exact
+#else
+#if !SDEMPC_FAST
+SDEMPC_DUO_PAIR(SDEMPC_DUO_DECL)
+SDEMPC_DUO_TEAM(SDEMPC_DUO_DECL, TeamBlock2)
+SDEMPC_DUO_TEAM(SDEMPC_DUO_DECL, TeamBlock)
+#endif
+
 #include "sdempc_spec.inc.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -1205,5 +1237,6 @@ hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int 
     return exact::launch_relayout(to_dev, in, out, B, P, G, C, st);
 }
 #endif
+#endif  // SDEMPC_TU == 0
 
 }  // namespace sdempc

@@ -91,7 +91,7 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 w4 = *reinterpret_cast<const float4*>(sm.A2 + (q * 64 + lane) * 4);      // (requesting quad q+1 before these MFMAs: -4 %, registers)
+            float4 w4 = *reinterpret_cast<const float4*>(sm.A2 + (q * 64 + lane) * 4);      // (requesting quad q+1 before these MFMAs: -4 % while the loop was short of registers, neutral since)
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, accD[4 * q], acc2, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, accD[4 * q + 1], acc2, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, accD[4 * q + 2], acc2, 0, 0, 0);

@@ -193,7 +193,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=3072, help="MPC problem instances per GPU per step (3 workgroups per CU x 256 CUs x 4 rounds)")
+    ap.add_argument("--batch", type=int, default=12288, help="MPC problem instances per GPU per step (eight rounds of the 1,536 instances an MI355X holds "
+                    "at once: 256 CUs x 3 workgroups x 2 instances; from three rounds on the persistent launch hands instances out by ticket)")
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "c2_iris_traj_h50_p128.yaml"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

@@ -204,7 +204,7 @@ int ensure_device_impl(sdempc_handle* h) {
     if ((rc = dev_alloc(h, h->d_xmean, sizeof(float) * B * (H + 1) * SDEMPC_NX))) return rc;
     if ((rc = dev_alloc(h, h->d_uopt, sizeof(float) * B * H * m))) return rc;
     if ((rc = dev_alloc(h, h->d_info, sizeof(float) * B * 8))) return rc;
-    if ((rc = dev_alloc(h, h->d_work, sizeof(unsigned long long) * 4))) return rc;
+    if ((rc = dev_alloc(h, h->d_work, sizeof(unsigned long long) * 5))) return rc;      // 4 counters + the persistent launches' instance ticket
     HIPCHK(h, hipMemset(h->d_work.p, 0, h->d_work.bytes));
     h->base.work = (unsigned long long*)h->d_work.p;
     h->base.dt = (const float*)h->d_dt.p;
@@ -704,7 +704,7 @@ int sdempc_work_counters(sdempc_handle* h, uint64_t out[4], int32_t reset) {
     unsigned long long v[4];
     HIPCHK(h, hipMemcpy(v, h->d_work.p, sizeof v, hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out[i] = v[i];
-    if (reset) HIPCHK(h, hipMemset(h->d_work.p, 0, h->d_work.bytes));
+    if (reset) HIPCHK(h, hipMemset(h->d_work.p, 0, sizeof v));
     return SDEMPC_OK;
 }
 

@@ -144,6 +144,7 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
     const int lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: the pair's base addresses stay in SGPRs
     const bool want_mean = xmean_out != nullptr;
+    CLK_BEGIN(t_roll);
     Team::sync();
     block_prepass<Team>(a, sm, u, tid);
     const int PS = part_stride(H);
@@ -184,6 +185,7 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
         }
         float J = 0.0f;
         StepAux A;
+        CLK_BEGIN(t_loop);
         for (int t = 0; t < H; ++t) {
             // !NZS: next step's rows requested a whole step ahead into registers (a just-in-time load at the top of the step measured 33 %
             // slower: the compiler sinks it to its use)
@@ -216,6 +218,7 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
                 for (int i = 0; i < NX; ++i) { float s = group_bfly32(valid ? x[i] : 0.0f); if (j == 0 && pr.own) xm[(t + 1) * NX + i] = s; }
             }
         }
+        CLK_END(2, t_loop);
         const float T = group_bfly32(valid ? J : 0.0f);
         if (j == 0 && pr.own) xm[PS - 1] = T;          // group total of the particle costs (last element of the group's row)
     }
@@ -224,6 +227,7 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
     if (want_mean) {
         for (int i = tid; i < (H + 1) * NX; i += Team::NT) xmean_out[i] = group_ordered_sum(prows, G, PS, i) * a.invP;
     }
+    CLK_END(1, t_roll);
     return FMA(tot, a.invP, cu);
 }
 
@@ -238,6 +242,7 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
     constexpr int nq = M + 4;
     const int lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform: the pair's base addresses stay in SGPRs
+    CLK_BEGIN(t_grad);
     Team::sync();
     block_prepass<Team>(a, sm, y, tid);
     const int PS = part_stride(H);
@@ -260,6 +265,7 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         float* Sq = prows + (size_t)pr.g * PS;                               // this group's row of per-step adjoint sums (SPEC.md §6.1)
         float x[NX], xn[NX], xi[NN];
         StepAux A;
+        CLK_BEGIN(t_fwd);
         // ---- forward sweep, x_t and the second hidden layer streamed to HBM ----
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = a.x0[b * NX + i];      // (read here, per pair: nothing of it stays live across the pair loop)
@@ -308,6 +314,8 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             }
         }
         { const float T = group_bfly32(valid ? J : 0.0f); if (j == 0 && pr.own) Sq[PS - 1] = T; }
+        CLK_END(4, t_fwd);
+        CLK_BEGIN(t_adj);
         // ---- adjoint sweep: x (registers) currently holds x_H ----
         float lam[NX], xt[NX];
 #pragma unroll
@@ -392,10 +400,12 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
                 if (j == 0 && pr.own) Sq[t * 12 + k] = s;
             }
         }
+        CLK_END(5, t_adj);
     }
     Team::sync();
     const float tot = group_ordered_sum(prows, G, PS, PS - 1);
     assemble_gradient<Team, M>(a, sm, y, gout, tid, [&](int q) { return group_ordered_sum(prows, G, PS, q); });
     Team::sync();
+    CLK_END(3, t_grad);
     return FMA(tot, a.invP, cu);
 }

@@ -75,7 +75,9 @@ struct KArgs {
     unsigned coop_spin;        // time one grid barrier may wait before it gives up, in ticks of the 100 MHz s_memrealtime clock (10 ns)
     float* coop_pp;            // [B][2][part_stride(H)][G*32]
     float* coop_ck;            // [B][P][H+1][160]
-    unsigned long long* work;  // [4] cumulative work of sdempc_solve_kernel launches: solves, gradient evaluations, forward-only rollouts, spare
+    unsigned long long* work;  // [4] cumulative work of sdempc_solve_kernel launches: solves, gradient evaluations, forward-only rollouts, spare;
+                               // [4] (as unsigned) the instance ticket of a persistent launch (set by its launcher: next instance to hand out)
+    int tickets;               // persistent launches: 1 = instances beyond the grid's first ones are handed out by the ticket word (set by the launcher)
     int fast;                  // SPEC.md §10: hardware transcendentals (selects the fastm translation unit; host-side switch)
     LaunchOpts opt;
 };

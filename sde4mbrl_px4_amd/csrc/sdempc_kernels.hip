@@ -47,6 +47,9 @@
 #ifndef SDEMPC_TU
 #define SDEMPC_TU 0
 #endif
+#ifndef SDEMPC_VAR_PHASE_CLK
+#define SDEMPC_VAR_PHASE_CLK 0
+#endif
 
 namespace sdempc {
 #if SDEMPC_FAST
@@ -103,11 +106,25 @@ struct TeamBlock2 {
 // twelve waves per CU). The two teams of a workgroup run independent control flow (different instances), so their barrier cannot be
 // s_barrier: a counter in LDS per team, two arrivals per episode (the arriving wave waits for the counter's next even value).
 __shared__ unsigned sdempc_pair_bar[2];
+// Diagnostic builds only (tools/build_variant.sh clk "-DSDEMPC_VAR_PHASE_CLK=1", tools/phase_clock.py): per-wave time by phase
+// (s_memrealtime ticks of 10 ns), summed in LDS over a solve and flushed into KArgs::work in place of the work counters.
+// slots: 0 solve, 1 cost rollouts, 2 their step loops, 3 gradient evaluations, 4 forward sweeps, 5 adjoint sweeps, 6 team barriers
+#if SDEMPC_VAR_PHASE_CLK
+__shared__ unsigned long long sdempc_clk[8][8];
+DI unsigned long long clk_now() { return __builtin_amdgcn_s_memrealtime(); }
+DI void clk_add(int slot, unsigned long long t0) { if ((threadIdx.x & 63) == 0) sdempc_clk[threadIdx.x >> 6][slot] += clk_now() - t0; }
+#define CLK_BEGIN(v) const unsigned long long v = clk_now()
+#define CLK_END(slot, v) clk_add(slot, v)
+#else
+#define CLK_BEGIN(v) ((void)0)
+#define CLK_END(slot, v) ((void)0)
+#endif
 struct TeamPair {
     static constexpr int NT = 128, NWAVES = 2, IPB = 2, BNT = 256;
     DI static int tid() { return threadIdx.x & 127; }
     DI static int team() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 7); }
     DI static void sync() {
+        CLK_BEGIN(tb);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // this wave's LDS writes are complete before it signals
         unsigned* c = sdempc_pair_bar + team();
         unsigned v = 0;
@@ -116,6 +133,7 @@ struct TeamPair {
         const unsigned target = (v | 1u) + 1u;
         while ((int)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        CLK_END(6, tb);
     }
 };
 struct TeamWave {
@@ -771,6 +789,10 @@ DI void solve_instance(const KArgs& a, const Smem& sm, const WaveW& ww, const La
     }
     // wave-uniform optimiser scalars are pinned to SGPRs (uni_f): a uniform value left in a VGPR can be spilled under the partial EXEC
     // mask of a divergent block and restored under the full one (seen in the speculative kernel; see sdempc_spec.inc.h)
+#if SDEMPC_VAR_PHASE_CLK
+    if ((threadIdx.x & 63) == 0) for (int i = 0; i < 8; ++i) sdempc_clk[threadIdx.x >> 6][i] = 0ull;
+#endif
+    CLK_BEGIN(t_solve);
     const float c_init = uni_f(team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xk, b, tid, false, nullptr));
     float c_x = c_init, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f;
     int kr = 0, noimp = 0, nit = 0, nls_tot = 0, plain = 1;
@@ -841,16 +863,32 @@ DI void solve_instance(const KArgs& a, const Smem& sm, const WaveW& ww, const La
     if (MODE != 2 || CC.wgi == 0)
         for (int e = tid; e < N; e += Team::NT) a.uopt[(size_t)b * N + e] = xk[e];
     team_rollout<Team, F16, PK, MODE>(a, sm, ww, LW, CC, xk, b, tid, false, a.xmean + (size_t)b * (a.H + 1) * NX);
+#if SDEMPC_VAR_PHASE_CLK
+    CLK_END(0, t_solve);
+    if (a.work && (threadIdx.x & 63) == 0) {
+        const unsigned long long* c = sdempc_clk[threadIdx.x >> 6];
+        __hip_atomic_fetch_add(a.work + 0, ((c[0] >> 8) << 32) | (c[1] >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.work + 1, ((c[2] >> 8) << 32) | (c[3] >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.work + 2, ((c[4] >> 8) << 32) | (c[5] >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.work + 3, ((c[6] >> 8) << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
     if (tid == 0 && (MODE != 2 || CC.wgi == 0)) {
         float* inf = a.info + (size_t)b * 8;
         const float fn = (float)nit;
         inf[0] = nit ? sum_ls / fn : 0.0f; inf[1] = s; inf[2] = fn; inf[3] = gsq; inf[4] = nit ? sum_s / fn : 0.0f;
         inf[5] = c_init; inf[6] = c_x; inf[7] = (float)nls_tot;
-        if (a.work) {   // work actually done (roofline accounting, sdempc_work_counters): solves, gradient evaluations, forward-only rollouts
+        if (a.work && !SDEMPC_VAR_PHASE_CLK) {   // work actually done (roofline accounting, sdempc_work_counters): solves, gradient evaluations, forward-only rollouts
             __hip_atomic_fetch_add(a.work + 0, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(a.work + 1, (unsigned long long)ngrad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(a.work + 2, (unsigned long long)(nls_tot + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#if SDEMPC_VAR_PHASE_CLK    // diagnostic build: where and when this instance was solved, in place of three telemetry words
+        inf[0] = __uint_as_float(__builtin_amdgcn_s_getreg(63492));                       // HW_REG_HW_ID
+        inf[1] = __uint_as_float(__builtin_amdgcn_s_getreg(63508));                       // HW_REG_XCC_ID
+        inf[3] = (float)(unsigned)(t_solve & 0x3FFFFFFFull) * 1e-5f;                      // start, ms (wraps at 10.7 s)
+        inf[4] = (float)(clk_now() - t_solve) * 1e-5f;                                    // duration, ms
+#endif
         if constexpr (MODE == 2) {   // a grid barrier gave up (never seen in testing; bounded so that a fault cannot hang the GPU): poison the telemetry
             if (__hip_atomic_load(CC.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
                 for (int i = 0; i < 8; ++i) inf[i] = __builtin_nanf("");
@@ -875,12 +913,30 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
         if constexpr (Team::IPB > 1) { if (threadIdx.x < Team::IPB) sdempc_pair_bar[threadIdx.x] = 0u; }
         load_weights(a, sm, ww, threadIdx.x, Team::BNT);
         __syncthreads();                           // weights staged (whole workgroup); from here on every team runs on its own
-        for (int bb = blockIdx.x * Team::IPB + Team::team(); bb < a.B; bb += gridDim.x * Team::IPB) {
+        // From three instances per team on, instances are handed out in order of completion (a ticket word behind KArgs::work, set by
+        // the launcher to the first instance beyond the grid's initial ones) instead of striped over the teams. Two things were
+        // measured with tools/phase_clock.py (per-instance start, duration and XCD in a diagnostic build): the XCDs differ in speed by
+        // up to 12 % (striping makes every launch as slow as its slowest XCD), and teams that start together stay in phase — every
+        // wave of the chip in its gradient sweeps, i.e. its checkpoint traffic, at the same time; tickets let the fast XCDs take
+        // more instances and the phases drift apart: C2 2,925 -> 3,120 solves/s from three rounds on (C3 1,486 -> 1,576). With two
+        // instances per team the coarse granularity at the end of the launch costs more than it gains (2,743), so short launches
+        // stay striped. Which team solves an instance does not change its bits.
+        unsigned* ticket = a.tickets ? reinterpret_cast<unsigned*>(a.work + 4) : nullptr;
+        int bb = blockIdx.x * Team::IPB + Team::team();
+        while (bb < a.B) {
             const int b = __builtin_amdgcn_readfirstlane(bb);
             if constexpr (USTG) sm.ust = a.ustg + (size_t)b * a.H * UST;
             Team::sync();                          // the team's previous instance has finished reading its LDS state
             load_common<Team>(a, sm, b, tid);
             solve_instance<Team, M, F16, PK, MODE>(a, sm, ww, LW, CC, b, tid);
+            if (ticket) {
+                Team::sync();                      // every wave of the team is done with the reduction scratch
+                if (tid == 0) reinterpret_cast<unsigned*>(sm.red)[0] = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                Team::sync();
+                bb = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<const unsigned*>(sm.red)[0]);
+            } else {
+                bb += gridDim.x * Team::IPB;
+            }
         }
         return;
     }
@@ -974,8 +1030,14 @@ static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int 
     size_t grid = per_cu * (size_t)(a.opt.cus > 0 ? a.opt.cus : 256);
     const size_t need = ((size_t)a.B + ipb - 1) / ipb;
     if (grid > need) grid = need;
+    KArgs ka = a;
+    ka.tickets = a.work != nullptr && (size_t)a.B >= 3 * grid * (size_t)ipb;
+    if (ka.tickets) {                               // instance ticket: the teams' initial instances are 0 .. grid * ipb - 1
+        e = hipMemsetD32Async((hipDeviceptr_t)(a.work + 4), (int)(grid * (size_t)ipb), 1, st);
+        if (e != hipSuccess) return e;
+    }
     note_kernel((const void*)k);
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(bnt), sb, st, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(bnt), sb, st, ka);
     return hipGetLastError();
 }
 // Which of the three builds of a duo team shape: noise staging rows + control table in LDS, staging rows + table in global memory, or

@@ -644,6 +644,33 @@ def test_baseline_configs_full_size_throughput_kernel_bit_exact(cfg_name, B, ite
         assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0, b
 
 
+def test_ticketed_persistent_launch_matches_striped_launches_bit_for_bit():
+    """From three instances per team on, a persistent duo launch hands its instances out by ticket (order of completion) instead of striping
+    them over the teams (sdempc_kernels.hip, launch_persistent). Which team solves an instance must not change a bit: C2 at B = 4700 (> 3 x
+    1536 team slots: ticketed) against the same instances solved in striped launches of 600, and against the oracle on two of them."""
+    from sde4mbrl_px4_amd import prng
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(max_iter=2, max_no_improvement_iter=2)
+    model = synthetic_iris()
+    B, H, P = 4700, cfg.horizon, cfg.num_particles
+    x0 = W.random_initial_states(B, 3)
+    xref = np.stack([W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(B)])
+    keys = prng.split(prng.PRNGKey(10), B)
+    S = _solver(cfg, model, B)
+    yk, i0 = S.reset()
+    u0 = np.tile(yk[None], (B, 1, 1))
+    s0 = np.full(B, i0["stepsize"], np.float32)
+    uopt, xevol, info = S.solve_keys(x0, xref, keys, u0, s0)
+    assert ", false, 3, " in S.last_kernel_name() and 3 * 6 * S.get_option("device_cus") <= B
+    for sl in (slice(0, 600), slice(2300, 2900), slice(4100, 4700)):
+        u2, x2, i2 = S.solve_keys(x0[sl], xref[sl], keys[sl], u0[sl], s0[sl])
+        assert bits_differ(uopt[sl], u2) == 0 and bits_differ(xevol[sl], x2) == 0 and bits_differ(info[sl], i2) == 0
+    O = orc.Oracle(cfg, model)
+    for b in (1536, 4699):
+        uo, xe, io = O.solve(x0[b], xref[b], orc.noise_from_key(keys[b], P, H), u0[b], float(s0[b]))[:3]
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0
+    S.close()
+
+
 def test_c5_full_size_solve_f32_bit_exact_and_f16_within_tolerance():
     """BASELINE config C5 (H=200, P=1024: 32 particle groups per instance, control table in global memory) as a SOLVE at full size, B > CUs:
     f32 bit for bit against the oracle; fp16-operand MLP mode (the mode C5 names) against the oracle's emulation within the north star's

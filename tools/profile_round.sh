@@ -2,7 +2,7 @@
 # One round of profiling evidence on the GPU box: tools/profile_round.sh <tag> [batch]
 # kernel trace of bench.py + separate PMC passes (HBM bytes: FETCH_SIZE / WRITE_SIZE in their own passes, MI355X_MICROARCH.md) +
 # counter calibration on the rollout / gradient kernels whose traffic is known. Summarise with tools/summarize_profile.py.
-tag=${1:-r03}; B=${2:-3072}
+tag=${1:-r03}; B=${2:-12288}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --latency-reps 40 > $out/bench_trace.log 2>&1

@@ -299,6 +299,8 @@ def main():
         ev_ms.append(solver.last_kernel_ms())
     torch.cuda.synchronize()
     w_solves, w_grads, w_fwd = solver.work_counters()
+    if w_solves != B * len(ev_ms):
+        raise SystemExit(f"bench.py: {w_solves} solves counted on the device for {len(ev_ms)} launches of {B} instances")
     kernel_name = solver.last_kernel_name()       # the instantiation the timed launches ran, as rocprofv3 names it
     info_h = info.cpu().numpy()
     n_it = float(info_h[:, 2].mean())

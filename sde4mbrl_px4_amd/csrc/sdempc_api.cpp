@@ -56,6 +56,7 @@ struct sdempc_handle {
     bool dev_ready = false;
     std::string err;
     KArgs base;
+    unsigned ticket_total = 0;   // running value of the device ticket word (KArgs::ticket_host points here; sdempc_kernels.hip, launch_persistent)
     // host tables
     std::vector<float> h_sdt, h_disc, h_beta;
     // device tables
@@ -207,6 +208,8 @@ int ensure_device_impl(sdempc_handle* h) {
     if ((rc = dev_alloc(h, h->d_work, sizeof(unsigned long long) * 5))) return rc;      // 4 counters + the persistent launches' instance ticket
     HIPCHK(h, hipMemset(h->d_work.p, 0, h->d_work.bytes));
     h->base.work = (unsigned long long*)h->d_work.p;
+    h->base.ticket_host = &h->ticket_total;
+    h->ticket_total = 0;                                   // matches the zeroed ticket word
     h->base.dt = (const float*)h->d_dt.p;
     h->base.sdt = (const float*)h->d_sdt.p;
     h->base.disc = (const float*)h->d_disc.p;

@@ -76,8 +76,11 @@ struct KArgs {
     float* coop_pp;            // [B][2][part_stride(H)][G*32]
     float* coop_ck;            // [B][P][H+1][160]
     unsigned long long* work;  // [4] cumulative work of sdempc_solve_kernel launches: solves, gradient evaluations, forward-only rollouts, spare;
-                               // [4] (as unsigned) the instance ticket of a persistent launch (set by its launcher: next instance to hand out)
+                               // [4] (as unsigned) the instance ticket word of the persistent launches (see ticket_base)
     int tickets;               // persistent launches: 1 = instances beyond the grid's first ones are handed out by the ticket word (set by the launcher)
+    unsigned ticket_base;      // value of the ticket word when this launch starts (set by the launcher from *ticket_host)
+    unsigned* ticket_host;     // HOST memory, owned by the handle: running total of the ticket word (it is never reset: every ticketed launch of B
+                               // instances advances it by exactly B — B - S successful draws and one failing draw by each of the S teams)
     int fast;                  // SPEC.md §10: hardware transcendentals (selects the fastm translation unit; host-side switch)
     LaunchOpts opt;
 };

@@ -914,14 +914,18 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
         load_weights(a, sm, ww, threadIdx.x, Team::BNT);
         __syncthreads();                           // weights staged (whole workgroup); from here on every team runs on its own
         // From three instances per team on, instances are handed out in order of completion (a ticket word behind KArgs::work, set by
-        // the launcher to the first instance beyond the grid's initial ones) instead of striped over the teams. Two things were
-        // measured with tools/phase_clock.py (per-instance start, duration and XCD in a diagnostic build): the XCDs differ in speed by
-        // up to 12 % (striping makes every launch as slow as its slowest XCD), and teams that start together stay in phase — every
-        // wave of the chip in its gradient sweeps, i.e. its checkpoint traffic, at the same time; tickets let the fast XCDs take
-        // more instances and the phases drift apart: C2 2,925 -> 3,120 solves/s from three rounds on (C3 1,486 -> 1,576). With two
-        // instances per team the coarse granularity at the end of the launch costs more than it gains (2,743), so short launches
-        // stay striped. Which team solves an instance does not change its bits.
+        // the launcher to the first instance beyond the grid's initial ones) instead of striped over the teams. The three waves that
+        // share a SIMD do not advance at the same rate: the issue arbiter favours the older wave slot, and a diagnostic build
+        // (tools/phase_clock.py: start, duration and hardware wave slot of every instance) shows solves of identical work taking 382 /
+        // 438 / 765 ms in wave slots 0 / 1 / 2. A striped launch is over when the teams in the slowest slots have finished their
+        // share; with tickets the fast slots solve twice as many instances as the slow ones: C2 2,925 -> 3,120-3,200 solves/s from
+        // three rounds on (C3 1,486 -> 1,576). With two instances per team the coarse granularity at the end of the launch costs more
+        // than the balance gains (2,743), so short launches stay striped. Which team solves an instance does not change its bits.
+        // The ticket word is never reset (a reset by hipMemsetD32Async ahead of the launch was seen to take effect late on some boxes:
+        // the first 1,536 instances were then solved twice — same bits, wasted work — and a stale HIGH value would have left instances
+        // unsolved): a draw is relative to the word's value at launch, which the launcher knows because every launch advances it by B.
         unsigned* ticket = a.tickets ? reinterpret_cast<unsigned*>(a.work + 4) : nullptr;
+        const unsigned nteams = gridDim.x * Team::IPB, ndraw = (unsigned)a.B - nteams;     // successful draws of this launch
         int bb = blockIdx.x * Team::IPB + Team::team();
         while (bb < a.B) {
             const int b = __builtin_amdgcn_readfirstlane(bb);
@@ -931,9 +935,10 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
             solve_instance<Team, M, F16, PK, MODE>(a, sm, ww, LW, CC, b, tid);
             if (ticket) {
                 Team::sync();                      // every wave of the team is done with the reduction scratch
-                if (tid == 0) reinterpret_cast<unsigned*>(sm.red)[0] = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) reinterpret_cast<unsigned*>(sm.red)[0] = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ticket_base;
                 Team::sync();
-                bb = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<const unsigned*>(sm.red)[0]);
+                const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const unsigned*>(sm.red)[0]);
+                bb = t < ndraw ? (int)(nteams + t) : a.B;      // (anything else — this team's one failing draw — ends the team)
             } else {
                 bb += gridDim.x * Team::IPB;
             }
@@ -1031,14 +1036,16 @@ static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int 
     const size_t need = ((size_t)a.B + ipb - 1) / ipb;
     if (grid > need) grid = need;
     KArgs ka = a;
-    ka.tickets = a.work != nullptr && (size_t)a.B >= 3 * grid * (size_t)ipb;
-    if (ka.tickets) {                               // instance ticket: the teams' initial instances are 0 .. grid * ipb - 1
-        e = hipMemsetD32Async((hipDeviceptr_t)(a.work + 4), (int)(grid * (size_t)ipb), 1, st);
-        if (e != hipSuccess) return e;
-    }
+    ka.tickets = a.work != nullptr && a.ticket_host != nullptr && (size_t)a.B >= 3 * grid * (size_t)ipb;
+#if SDEMPC_VAR_STATIC       // diagnostic builds: striped assignment at every batch size (tools/phase_clock.py)
+    ka.tickets = 0;
+#endif
+    if (ka.tickets) ka.ticket_base = *a.ticket_host;       // the teams' initial instances are 0 .. grid * ipb - 1; the draws hand out the rest
     note_kernel((const void*)k);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(bnt), sb, st, ka);
-    return hipGetLastError();
+    e = hipGetLastError();
+    if (e == hipSuccess && ka.tickets) *a.ticket_host = ka.ticket_base + (unsigned)a.B;
+    return e;
 }
 // Which of the three builds of a duo team shape: noise staging rows + control table in LDS, staging rows + table in global memory, or
 // neither in LDS (long horizons) — the first in that order of preference that keeps the most workgroups per CU.

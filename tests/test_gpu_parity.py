@@ -659,8 +659,12 @@ def test_ticketed_persistent_launch_matches_striped_launches_bit_for_bit():
     yk, i0 = S.reset()
     u0 = np.tile(yk[None], (B, 1, 1))
     s0 = np.full(B, i0["stepsize"], np.float32)
+    S.work_counters(reset=True)
     uopt, xevol, info = S.solve_keys(x0, xref, keys, u0, s0)
     assert ", false, 3, " in S.last_kernel_name() and 3 * 6 * S.get_option("device_cus") <= B
+    assert S.work_counters()[0] == B                                      # every instance solved exactly once
+    ub, xb, ib = S.solve_keys(x0, xref, keys, u0, s0)                     # second ticketed launch of the handle: the ticket word is not reset between launches
+    assert S.work_counters()[0] == 2 * B and bits_differ(uopt, ub) == 0 and bits_differ(xevol, xb) == 0 and bits_differ(info, ib) == 0
     for sl in (slice(0, 600), slice(2300, 2900), slice(4100, 4700)):
         u2, x2, i2 = S.solve_keys(x0[sl], xref[sl], keys[sl], u0[sl], s0[sl])
         assert bits_differ(uopt[sl], u2) == 0 and bits_differ(xevol[sl], x2) == 0 and bits_differ(info[sl], i2) == 0

@@ -50,3 +50,12 @@ first = start < 1.0
 print(f"first-round instances ({first.sum()}): mean {dur[first].mean():.1f} ms; later ones: mean {dur[~first].mean():.1f} ms")
 for name, key in [("XCC", xcc), ("SE", se), ("SH", sh), ("CU", cu), ("SIMD of the team's first wave", simd)]:
     print(name + ": " + "  ".join(f"{k}: {dur[key == k].mean():.0f} ms x{(key == k).sum()}" for k in np.unique(key)))
+print("duration deciles (ms):", " ".join(f"{np.percentile(dur, q):.0f}" for q in range(0, 101, 10)), f"  N_ls min/median/max {nls.min():.0f}/{np.median(nls):.0f}/{nls.max():.0f}")
+order = np.argsort(start)
+nseg = 8
+print("mean duration by start time (eighths of the launch):", " ".join(f"{dur[order[i * B // nseg:(i + 1) * B // nseg]].mean():.0f}" for i in range(nseg)))
+wave = hw & 15
+print("wave slot of the team's first wave: " + "  ".join(f"{k}: {dur[wave == k].mean():.0f} ms x{(wave == k).sum()}" for k in np.unique(wave)))
+key = (xcc.astype(np.int64) << 16) | (se.astype(np.int64) << 8) | cu
+cm = np.array([dur[key == k].mean() for k in np.unique(key)])
+print(f"per-CU mean duration: min {cm.min():.0f}, p50 {np.median(cm):.0f}, max {cm.max():.0f} ms over {cm.size} CUs")

@@ -41,6 +41,8 @@ for r in range(a.reps):
     extra = ""
     if a.mode == "solve":
         ih = info.cpu().numpy(); extra = f" N_it {ih[:,2].mean():.1f} N_ls {ih[:,7].mean():.1f} -> {B/ms*1e3:.1f} solves/s"
+        wc = S.work_counters(reset=True)
+        if wc[0] != B: extra += f"  [work counters: {wc[0]} solves for a batch of {B}]"
     else:
         extra = f" -> {B*H*P/ms*1e3/1e9:.3f} G particle-steps/s"
     print(f"{a.mode} {a.math_mode}/{a.mlp_dtype} B={B} H={H} P={P} rep {r}: {ms:.3f} ms{extra}")

@@ -12,6 +12,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("src"); ap.add_argument("tag")
 ap.add_argument("--batch", type=int, default=2048)
 ap.add_argument("--config", default="c2_iris_traj_h50_p128.yaml")
+ap.add_argument("--mfma-per-eval", type=float, default=0.0, help="f32 MFMAs of one forward sweep of one instance (C2: 2 pairs x 50 steps x 44 = 4400); enables the SQ sum check")
+ap.add_argument("--sq-batch", type=int, default=0, help="batch of the SQ_* / GRBM passes (pmc_3, pmc_4) when it differs from --batch (tools/profile_round.sh)")
 a = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "profiles")
@@ -34,9 +36,15 @@ if os.path.exists(log):
     for line in open(log):
         if line.startswith("{"):
             bench = json.loads(line)
-solve = counters("pmc_*", "solve")
+solve = counters("pmc_[12]", "solve") if a.sq_batch else counters("pmc_*", "solve")
+if a.sq_batch:
+    solve.update(counters("pmc_[3-9]", "solve"))
 cal_r = counters("cal_rollout_*", "rollout"); cal_g = counters("cal_grad_*", "grad")
 res = {"tag": a.tag, "batch": a.batch, "config": a.config, "solve_kernel_per_launch": solve, "bench_under_rocprof": bench}
+if a.sq_batch:
+    res["sq_counters_batch"] = a.sq_batch
+    res["note"] = (f"FETCH_SIZE / WRITE_SIZE per launch of {a.batch} instances; every SQ_* / GRBM_* counter per launch of {a.sq_batch} instances "
+                   "(at 12,288 rocprofv3's SQ sums come out 9/8 of the work the kernel's own counters report; they match at 3,072 / 4,608 / 6,144)")
 KiB = 1024.0
 if "FETCH_SIZE" in solve and "WRITE_SIZE" in solve:
     rd, wr = 2.0 * solve["FETCH_SIZE"] * KiB, solve["WRITE_SIZE"] * KiB
@@ -53,5 +61,15 @@ if "GRBM_GUI_ACTIVE" in solve and "SQ_INSTS_VALU" in solve:
     cyc = solve["GRBM_GUI_ACTIVE"] / 8.0
     res["derived"] = {"kernel_cycles": cyc, "valu_insts_per_simd": solve["SQ_INSTS_VALU"] / 1024, "mfma_busy_frac": solve.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / cyc,
                       "valu_issue_frac_at_2.8cyc": solve["SQ_INSTS_VALU"] / 1024 * 2.8 / cyc}
+# rocprofv3's SQ_* / GRBM_* sums (added over the 8 XCDs) came out k/8 too large in some runs (k = 9, 10: seen at 6,144 and 12,288 instances per
+# launch, never at 3,072): SQ_INSTS_MFMA is known exactly from the kernel's own work counters (bench line), so the factor is measured and
+# the absolute counts are corrected by it; ratios of two such counters (busy fractions) are unaffected.
+if bench and "SQ_INSTS_MFMA" in solve and a.mfma_per_eval:
+    cfgb = bench["config"]
+    exp = a.mfma_per_eval * (2 * cfgb["N_grad_evaluated_mean"] + cfgb["N_forward_rollouts_mean"]) * (a.sq_batch or a.batch)
+    f = solve["SQ_INSTS_MFMA"] / exp
+    res["sq_sum_check"] = {"expected_SQ_INSTS_MFMA": exp, "measured": solve["SQ_INSTS_MFMA"], "factor": f,
+                           "SQ_INSTS_VALU_per_solve_corrected": solve.get("SQ_INSTS_VALU", 0) / f / (a.sq_batch or a.batch),
+                           "SQ_INSTS_LDS_per_solve_corrected": solve.get("SQ_INSTS_LDS", 0) / f / (a.sq_batch or a.batch)}
 json.dump(res, open(os.path.join(out, f"{a.tag}_pmc.json"), "w"), indent=1)
-print(json.dumps({k: res[k] for k in res if k in ("hbm_bytes_per_launch", "derived", "calibration")}, indent=1))
+print(json.dumps({k: res[k] for k in res if k in ("hbm_bytes_per_launch", "derived", "calibration", "sq_sum_check")}, indent=1))

@@ -2,9 +2,7 @@
 # One round of profiling evidence on the GPU box: tools/profile_round.sh <tag> [batch]
 # kernel trace of bench.py + separate PMC passes (HBM bytes: FETCH_SIZE / WRITE_SIZE in their own passes, MI355X_MICROARCH.md) +
 # counter calibration on the rollout / gradient kernels whose traffic is known. Summarise with tools/summarize_profile.py.
-# The instruction-counter passes (3, 4) run at SQB instances: at 12,288 (4.3 s kernels) rocprofv3's SQ_* sums come out 9/8 of the work
-# the kernel's own counters report (SQ_INSTS_MFMA: 3.318e6 per solve at 3,072 / 4,608 / 6,144, 3.732e6 at 12,288), one XCD's share more.
-tag=${1:-r03}; B=${2:-12288}; SQB=${3:-6144}
+tag=${1:-r03}; B=${2:-12288}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --latency-reps 40 > $out/bench_trace.log 2>&1
@@ -13,8 +11,7 @@ for c in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" \
          "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  PB=$B; if [ $i -ge 3 ]; then PB=$SQB; fi
-  timeout -k 10 300 rocprofv3 --pmc $c -d $out/pmc_$i --output-format csv -- python3 tools/prof_solve.py --mode solve --batch $PB --reps 1 > $out/pmc_$i.log 2>&1 || echo "pmc pass $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $c -d $out/pmc_$i --output-format csv -- python3 tools/prof_solve.py --mode solve --batch $B --reps 1 > $out/pmc_$i.log 2>&1 || echo "pmc pass $i failed"
   echo "pmc pass $i done"
 done
 for mode in rollout grad; do

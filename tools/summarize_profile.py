@@ -61,9 +61,8 @@ if "GRBM_GUI_ACTIVE" in solve and "SQ_INSTS_VALU" in solve:
     cyc = solve["GRBM_GUI_ACTIVE"] / 8.0
     res["derived"] = {"kernel_cycles": cyc, "valu_insts_per_simd": solve["SQ_INSTS_VALU"] / 1024, "mfma_busy_frac": solve.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / cyc,
                       "valu_issue_frac_at_2.8cyc": solve["SQ_INSTS_VALU"] / 1024 * 2.8 / cyc}
-# rocprofv3's SQ_* / GRBM_* sums (added over the 8 XCDs) came out k/8 too large in some runs (k = 9, 10: seen at 6,144 and 12,288 instances per
-# launch, never at 3,072): SQ_INSTS_MFMA is known exactly from the kernel's own work counters (bench line), so the factor is measured and
-# the absolute counts are corrected by it; ratios of two such counters (busy fractions) are unaffected.
+# SQ_INSTS_MFMA is known exactly from the kernel's own work counters (bench line): a factor other than 1 means the profiled launches did
+# not do the work the bench line describes (round 2: launches whose instance tickets were reset late solved 1,536 instances twice)
 if bench and "SQ_INSTS_MFMA" in solve and a.mfma_per_eval:
     cfgb = bench["config"]
     exp = a.mfma_per_eval * (2 * cfgb["N_grad_evaluated_mean"] + cfgb["N_forward_rollouts_mean"]) * (a.sq_batch or a.batch)

@@ -40,7 +40,7 @@
 #ifndef SDEMPC_FAST
 #define SDEMPC_FAST 0
 #endif
-// The exact-mode build is spread over three translation units so that `make -j` compiles them side by side (one hipcc process per
+// Each arithmetic mode's build is spread over three translation units so that `make -j` compiles them side by side (one hipcc process per
 // unit; the solve kernel has ~90 instantiations of ~25k instructions each): SDEMPC_TU = 0 — every kernel except the duo solve
 // kernels, and all launchers; 1 — the duo solve kernels of the two-wave teams (TeamPair, TeamBlock2); 2 — those of the four-wave
 // team (TeamBlock). Units 1 and 2 hold nothing but explicit instantiations (list macros below), unit 0 declares them `extern template`.
@@ -963,16 +963,14 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
 #if SDEMPC_TU == 1
 SDEMPC_DUO_PAIR(SDEMPC_DUO_DEF)
 SDEMPC_DUO_TEAM(SDEMPC_DUO_DEF, TeamBlock2)
-}  // namespace exact
+}  // namespace exact / fastm
 #elif SDEMPC_TU == 2
 SDEMPC_DUO_TEAM(SDEMPC_DUO_DEF, TeamBlock)
-}  // namespace exact
+}  // namespace exact / fastm
 #else
-#if !SDEMPC_FAST
 SDEMPC_DUO_PAIR(SDEMPC_DUO_DECL)
 SDEMPC_DUO_TEAM(SDEMPC_DUO_DECL, TeamBlock2)
 SDEMPC_DUO_TEAM(SDEMPC_DUO_DECL, TeamBlock)
-#endif
 
 #include "sdempc_spec.inc.h"
 
@@ -1102,7 +1100,7 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
             return launch_k(sdempc_solve_kernel<Team, 8, false, true>, a, st, Team::IPB);
         }
     }
-    if constexpr (Team::IPB == 1 && !FAST) {
+    if constexpr (Team::IPB == 1) {
         // auto: every multi-group instance (measured, same box: C2 +1.3 %, C3 +4.4 %, C5 +7.5 % over one group per wave)
         if (a.G >= 2 && a.opt.duo != 0) return launch_duo<F16>(a, st);
         // long horizons: with the control table in LDS only two workgroups fit a CU; without it three do (the kernel is built for three)

@@ -602,9 +602,9 @@ def test_global_control_table_instantiation_bit_exact(H, P, m):
 # A batch larger than the number of CUs makes launch_solve_team pick the throughput instantiation by itself (three waves per SIMD, scalar
 # tanh; for P > 32 the duo layout, template MODE 3 / 4: sdempc_solve_kernel<TeamPair | TeamBlock, m, F16, false, 3 | 4, USTG> — the kernel `bench.py`
 # names in roofline.kernel, read back from the HIP runtime through sdempc_last_kernel_name), with no option forced.
-def _full_size_case(cfg_name, B, iters, mlp="f32", sample=(0, 1), seed=0, stepsize=None):
+def _full_size_case(cfg_name, B, iters, mlp="f32", sample=(0, 1), seed=0, stepsize=None, math="exact"):
     from sde4mbrl_px4_amd import prng
-    cfg = load_mpc_config(os.path.join(CDIR, cfg_name)).replace(max_iter=iters, max_no_improvement_iter=iters, mlp_dtype=mlp)
+    cfg = load_mpc_config(os.path.join(CDIR, cfg_name)).replace(max_iter=iters, max_no_improvement_iter=iters, mlp_dtype=mlp, math_mode=math)
     model = synthetic_iris() if cfg.num_motors == 4 else synthetic_hexa()
     pos = "posctrl" in cfg_name
     H, P = cfg.horizon, cfg.num_particles
@@ -619,11 +619,12 @@ def _full_size_case(cfg_name, B, iters, mlp="f32", sample=(0, 1), seed=0, stepsi
     uopt, xevol, info = S.solve_keys(x0, xref, keys, u0, s0)
     assert S.get_option("device_cus") < B                                 # grid > CUs: the throughput instantiation ran
     kname = S.last_kernel_name()
-    assert kname.startswith("sdempc::exact::sdempc_solve_kernel<sdempc::exact::Team") and (", true, " in kname) == (mlp == "f16"), kname
+    ns = "exact" if math == "exact" else "fastm"
+    assert kname.startswith(f"sdempc::{ns}::sdempc_solve_kernel<sdempc::{ns}::Team") and (", true, " in kname) == (mlp == "f16"), kname
     if P > 32:                                                            # scalar-tanh (throughput) instantiation of the duo layout: MODE 3 (noise
         assert ", false, 3, " in kname or ", false, 4, " in kname, kname  # through LDS staging rows) or, when LDS has no room for them (C5), MODE 4
     assert np.all(info[:, 2] == iters) and np.all(info[:, 6] <= info[:, 5]) and uopt.min() >= 1e-4 and uopt.max() <= 1.0
-    O = orc.Oracle(cfg, model)
+    O = orc.Oracle(cfg.replace(math_mode="exact"), model)                # (the oracle has no fast mode: it IS the exact arithmetic)
     res = []
     for b in sample:
         noise = orc.noise_from_key(keys[b], P, H)
@@ -642,6 +643,17 @@ def test_baseline_configs_full_size_throughput_kernel_bit_exact(cfg_name, B, ite
     for b, (uo, xe, io) in res:
         _close(uopt[b], uo, "uopt")
         assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0, b
+
+
+def test_c2_full_size_fast_math_mode_in_the_duo_layout_within_tolerance():
+    """`math_mode: fast` (hardware transcendentals, SPEC.md §10) runs the same duo throughput kernels as the exact mode (namespace fastm): full-size
+    C2, B > CUs, against the exact oracle within the north star's 1e-4 on the controls, identical line-search decisions."""
+    uopt, xevol, info, res = _full_size_case("c2_iris_traj_h50_p128.yaml", 512, 30, sample=(0, 300, 511), math="fast")
+    for b, (uo, xe, io) in res:
+        np.testing.assert_allclose(uopt[b], uo, rtol=RTOL, atol=1e-5)
+        np.testing.assert_allclose(info[b, 5:7], io[5:7], rtol=2e-5)
+        assert info[b, 7] == io[7] and np.abs(uopt[b] - 0.71).max() > 1e-4      # same line-search decisions; the iterations moved the controls
+        assert bits_differ(xevol[b], xe) > 0                                    # and genuinely another arithmetic than the exact mode
 
 
 def test_ticketed_persistent_launch_matches_striped_launches_bit_for_bit():

@@ -10,6 +10,7 @@ rm -rf $dir; mkdir -p $dir/pkg/csrc $dir/include
 cp -p $root/include/*.h $dir/include/
 cp -p $root/sde4mbrl_px4_amd/csrc/* $dir/pkg/csrc/
 rm -f $dir/pkg/csrc/sdempc_kernels.o $dir/pkg/csrc/sdempc_kernels_duo2.o $dir/pkg/csrc/sdempc_kernels_duo4.o $dir/pkg/csrc/libsdempc.so
+touch $dir/pkg/csrc/sdempc_kernels_fast*.o $dir/pkg/csrc/sdempc_prng.o $dir/pkg/csrc/sdempc_api.o   # (the fast-mode objects keep the in-tree knobs)
 make -j3 -C $dir/pkg/csrc EXTRA="$extra" libsdempc.so > $dir/build.log 2>&1
 mkdir -p $root/build && cp $dir/pkg/csrc/libsdempc.so $root/build/libsdempc_$name.so
 ls -la $root/build/libsdempc_$name.so

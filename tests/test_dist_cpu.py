@@ -73,3 +73,20 @@ def test_two_rank_gloo_broadcast_shard_gather(tmp_path):
     x0 = W.random_initial_states(7, 0)
     ref = [O.rollout(x0[b], u, W.reference_window(0.0, cfg.time_steps), W.make_noise(1, 8, 6, b)[0])[0] for b in range(7)]
     np.testing.assert_array_equal(np.array(res["costs"], np.float32), np.array(ref, np.float32))
+
+
+def test_bench_self_start_stops_all_ranks_when_one_fails():
+    """`bench.py --gpus 2` without a launcher starts its own ranks before touching the GPU; a rank that cannot run (here: no GPU in the
+    container, every rank exits with "needs a GPU") must end the whole job promptly with a non-zero code instead of leaving the others in
+    the rendezvous, and nothing may reach stdout (the driver parses ONE JSON line from it)."""
+    import time
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU: with one the two ranks would run the benchmark")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "needs a GPU" in r.stderr
+    assert time.time() - t0 < 90

@@ -30,16 +30,16 @@ S.lib.sdempc_work_counters(S._h, out, 0)
 w = [int(v) for v in out]
 hi = lambda v: (v >> 32) * 2.56
 lo = lambda v: (v & 0xFFFFFFFF) * 2.56
-t_solve, t_roll, t_loop, t_grad, t_fwd, t_adj, t_sync = hi(w[0]), lo(w[0]), hi(w[1]), lo(w[1]), hi(w[2]), lo(w[2]), hi(w[3])
+t_solve, t_roll, ngrad, t_fwd, t_adj, t_sync = hi(w[0]), lo(w[0]), w[1], hi(w[2]), lo(w[2]), hi(w[3])
 nwaves = w[3] & 0xFFFFFFFF
 ms = S.last_kernel_ms()
-print(f"{S.last_kernel_name()}\nkernel {ms:.1f} ms; {nwaves} wave-solves; wave time in solves {t_solve / 1e6:.1f} s = {t_solve / (ms * 1e3 * 12 * S.get_option('device_cus')):.1%} of the wave slots")
-for name, v in [("cost rollouts (whole call)", t_roll), ("  their step loops", t_loop), ("gradient evaluations (whole call)", t_grad), ("  forward sweeps", t_fwd),
-                ("  adjoint sweeps", t_adj), ("optimiser between the calls", t_solve - t_roll - t_grad), ("team barriers (inside all of the above)", t_sync)]:
-    print(f"{name:45s} {v / t_solve:6.1%}   {v / nwaves / 1e3:8.2f} ms per wave-solve")
 G = (P + 31) // 32; pairs = (G + 1) // 2
-print(f"(C2: 188.5 gradients + 377.3 rollouts per solve, {H} steps each: step loop {t_loop / nwaves / (377.3 * H):.2f} us, forward {t_fwd / nwaves / (188.5 * H):.2f} us, adjoint {t_adj / nwaves / (188.5 * H):.2f} us per wave-step if every wave owns one pair)")
-
+nfwd = float((info[:, 7] + 2).sum())                 # cost rollouts: line-search trials + initial + final
+print(f"{S.last_kernel_name()}\nkernel {ms:.1f} ms; {B} solves on {nwaves} wave-solves; {ngrad / B:.1f} gradient evaluations and {nfwd / B:.1f} cost rollouts per solve")
+for name, v in [("cost rollouts (whole call)", t_roll), ("gradient evaluations: forward sweeps", t_fwd), ("gradient evaluations: adjoint sweeps", t_adj),
+                ("everything else (optimiser, reductions, gradient assembly)", t_solve - t_roll - t_fwd - t_adj), ("team barriers (inside all of the above)", t_sync)]:
+    print(f"{name:60s} {v / t_solve:6.1%}")
+print(f"per wave-step: cost rollout {t_roll / (nfwd * pairs * H):.2f} us (whole call / steps), forward sweep {t_fwd / (ngrad * pairs * H):.2f} us, adjoint sweep {t_adj / (ngrad * pairs * H):.2f} us")
 # where and when each instance was solved (diagnostic telemetry words)
 hw = info[:, 0].view(np.uint32); xcc = info[:, 1].view(np.uint32) & 15
 start = info[:, 3].astype(np.float64); start -= start.min(); dur = info[:, 4].astype(np.float64); nls = info[:, 7]

@@ -57,6 +57,21 @@ DI void duo_reform_rotation(const float* x, float* Rm) {
 
 // One Euler-Maruyama step for the wave's 64 particles. CKPT: stream the second hidden layer of both passes to the groups' checkpoint
 // rows (acA / acB: this step's rows of group A / group B).
+// Issue priority, rotated among the waves of a SIMD. The arbiter serves the higher s_setprio first and, among equals, the OLDER wave slot:
+// left alone, identical work takes 382 / 438 / 765 ms in wave slots 0 / 1 / 2 (tools/phase_clock.py), and a launch that gives every team the
+// same number of instances waits for the teams in slot 2. Every step each wave sets its priority to (time slice + its wave slot) mod 3: the
+// three waves of a SIMD read the same clock, so at any moment they hold three different priorities and each is the favoured one for a third of
+// the time (slices of 0.66 ms; 0.08 ... 42 ms measured alike, 10 us slices recover only half). Striped launches: C2 at 3,072 instances
+// 2,905 -> 3,150 solves/s, C3 at 1,536 1,486 -> 1,583, C5 at 768 (one round) 884 -> 959; ticketed launches unchanged (3,150).
+constexpr int PRIO_SLICE_LOG2 = 16;               // 2^16 ticks of the 100 MHz s_memrealtime clock
+DI void duo_rotate_priority() {
+    const unsigned slot = __builtin_amdgcn_s_getreg(63492) & 15u;                              // HW_REG_HW_ID[3:0]: wave slot on its SIMD
+    const unsigned r = ((unsigned)(__builtin_amdgcn_s_memrealtime() >> PRIO_SLICE_LOG2) + slot) % 3u;
+    if (r == 0) __builtin_amdgcn_s_setprio(0);
+    else if (r == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(2);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Noise staging of the forward sweeps. The six noise rows of step t are used once, by the Euler-Maruyama update at the END of step t.
 // Held in registers from a request early enough to cover HBM latency they are live across both MLP passes, and the compiler spilled
@@ -187,6 +202,7 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
         StepAux A;
         CLK_BEGIN(t_loop);
         for (int t = 0; t < H; ++t) {
+            duo_rotate_priority();
             // !NZS: next step's rows requested a whole step ahead into registers (a just-in-time load at the top of the step measured 33 %
             // slower: the compiler sinks it to its use)
             float xin[NN];
@@ -283,6 +299,7 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         }
         float J = 0.0f;
         for (int t = 0; t < H; ++t) {
+            duo_rotate_priority();
             float xin[NN];
             if constexpr (!NZS) {
                 if (t + 1 < H) {
@@ -323,6 +340,7 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         // this wave's own stores of x_t / activations must be visible to its loads (same CU: workgroup scope)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         for (int t = H - 1; t >= 0; --t) {
+            duo_rotate_priority();
             // (the 25 loads below are requested at the top of their own step. A register prefetch a step ahead spills; the LDS staging rows
             // have room for 6 of the 24 dwords. A timing-only build that redirected these loads to cache-resident rows bounds what a perfect
             // prefetch could buy: 12 % of the adjoint sweep, 4 % of the launch.)

@@ -340,7 +340,7 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         // this wave's own stores of x_t / activations must be visible to its loads (same CU: workgroup scope)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         for (int t = H - 1; t >= 0; --t) {
-            duo_rotate_priority();
+            duo_rotate_priority();                   // (requesting this step's loads at top priority instead: no gain)
             // (the 25 loads below are requested at the top of their own step. A register prefetch a step ahead spills; the LDS staging rows
             // have room for 6 of the 24 dwords. A timing-only build that redirected these loads to cache-resident rows bounds what a perfect
             // prefetch could buy: 12 % of the adjoint sweep, 4 % of the launch.)

@@ -62,7 +62,9 @@ DI void duo_reform_rotation(const float* x, float* Rm) {
 // same number of instances waits for the teams in slot 2. Every step each wave sets its priority to (time slice + its wave slot) mod 3: the
 // three waves of a SIMD read the same clock, so at any moment they hold three different priorities and each is the favoured one for a third of
 // the time (slices of 0.66 ms; 0.08 ... 42 ms measured alike, 10 us slices recover only half). Striped launches: C2 at 3,072 instances
-// 2,905 -> 3,150 solves/s, C3 at 1,536 1,486 -> 1,583, C5 at 768 (one round) 884 -> 959; ticketed launches unchanged (3,150).
+// 2,905 -> 3,150 solves/s, C3 at 1,536 1,486 -> 1,583, C5 at 768 (one round) 884 -> 959; ticketed launches unchanged (3,150). Only the
+// persistent duo launches rotate: a plain grid of one-wave teams (C1) is rebalanced by the dispatcher as workgroups retire, and there the
+// arbiter's own oldest-first order is the better one (rotation: 55,300 -> 52,750 solves/s).
 constexpr int PRIO_SLICE_LOG2 = 16;               // 2^16 ticks of the 100 MHz s_memrealtime clock
 DI void duo_rotate_priority() {
     const unsigned slot = __builtin_amdgcn_s_getreg(63492) & 15u;                              // HW_REG_HW_ID[3:0]: wave slot on its SIMD

@@ -67,6 +67,9 @@ DI void duo_reform_rotation(const float* x, float* Rm) {
 // arbiter's own oldest-first order is the better one (rotation: 55,300 -> 52,750 solves/s).
 constexpr int PRIO_SLICE_LOG2 = 16;               // 2^16 ticks of the 100 MHz s_memrealtime clock
 DI void duo_rotate_priority() {
+#if SDEMPC_VAR_NO_ROTATE      // diagnostic builds: the arbiter's own order (profiles/r2_phase_clock.txt)
+    return;
+#endif
     const unsigned slot = __builtin_amdgcn_s_getreg(63492) & 15u;                              // HW_REG_HW_ID[3:0]: wave slot on its SIMD
     const unsigned r = ((unsigned)(__builtin_amdgcn_s_memrealtime() >> PRIO_SLICE_LOG2) + slot) % 3u;
     if (r == 0) __builtin_amdgcn_s_setprio(0);

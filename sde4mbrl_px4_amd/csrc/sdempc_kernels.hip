@@ -107,7 +107,7 @@ struct TeamBlock2 {
 // s_barrier: a counter in LDS per team, two arrivals per episode (the arriving wave waits for the counter's next even value).
 __shared__ unsigned sdempc_pair_bar[2];
 // Diagnostic builds only (tools/build_variant.sh clk "-DSDEMPC_VAR_PHASE_CLK=1", tools/phase_clock.py): per-wave time by phase
-// (s_memrealtime ticks of 10 ns), summed in LDS over a solve and flushed into KArgs::work in place of the work counters.
+// (s_memrealtime ticks of 10 ns), summed in LDS over a solve and flushed (>> 10: 10.24 us units, two per word) into KArgs::work in place of the work counters.
 // slots: 0 solve, 1 cost rollouts, 2 their step loops, 3 gradient evaluations (2, 3: kept in LDS only), 4 forward sweeps, 5 adjoint sweeps, 6 team barriers
 #if SDEMPC_VAR_PHASE_CLK
 __shared__ unsigned long long sdempc_clk[8][8];
@@ -867,10 +867,10 @@ DI void solve_instance(const KArgs& a, const Smem& sm, const WaveW& ww, const La
     CLK_END(0, t_solve);
     if (a.work && (threadIdx.x & 63) == 0) {
         const unsigned long long* c = sdempc_clk[threadIdx.x >> 6];
-        __hip_atomic_fetch_add(a.work + 0, ((c[0] >> 8) << 32) | (c[1] >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.work + 0, ((c[0] >> 10) << 32) | (c[1] >> 10), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) __hip_atomic_fetch_add(a.work + 1, (unsigned long long)ngrad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (as in the product build)
-        __hip_atomic_fetch_add(a.work + 2, ((c[4] >> 8) << 32) | (c[5] >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(a.work + 3, ((c[6] >> 8) << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.work + 2, ((c[4] >> 10) << 32) | (c[5] >> 10), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.work + 3, ((c[6] >> 10) << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
     if (tid == 0 && (MODE != 2 || CC.wgi == 0)) {

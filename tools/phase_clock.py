@@ -1,6 +1,6 @@
 """Where a duo solve launch spends its wave time (diagnostic build only: tools/build_variant.sh clk "-DSDEMPC_VAR_PHASE_CLK=1", run with
 SDEMPC_LIB=build/libsdempc_clk.so): forward and adjoint sweeps of the gradient evaluations from the packed counter work[3]
-(s_memrealtime, 100 MHz, >> 8), the cost rollouts as the remainder of waves x kernel time."""
+(s_memrealtime, 100 MHz, >> 10), the cost rollouts as the remainder of waves x kernel time."""
 import argparse, ctypes, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -28,8 +28,8 @@ S.lib.sdempc_work_counters(S._h, out, 1)
 uopt, xevol, info = S.solve_keys(x0, xref, keys, u0, s0)
 S.lib.sdempc_work_counters(S._h, out, 0)
 w = [int(v) for v in out]
-hi = lambda v: (v >> 32) * 2.56
-lo = lambda v: (v & 0xFFFFFFFF) * 2.56
+hi = lambda v: (v >> 32) * 10.24
+lo = lambda v: (v & 0xFFFFFFFF) * 10.24
 t_solve, t_roll, ngrad, t_fwd, t_adj, t_sync = hi(w[0]), lo(w[0]), w[1], hi(w[2]), lo(w[2]), hi(w[3])
 nwaves = w[3] & 0xFFFFFFFF
 ms = S.last_kernel_ms()

@@ -64,7 +64,8 @@ DI void duo_reform_rotation(const float* x, float* Rm) {
 // the time (slices of 0.66 ms; 0.08 ... 42 ms measured alike, 10 us slices recover only half). Striped launches: C2 at 3,072 instances
 // 2,905 -> 3,150 solves/s, C3 at 1,536 1,486 -> 1,583, C5 at 768 (one round) 884 -> 959; ticketed launches unchanged (3,150). Only the
 // persistent duo launches rotate: a plain grid of one-wave teams (C1) is rebalanced by the dispatcher as workgroups retire, and there the
-// arbiter's own oldest-first order is the better one (rotation: 55,300 -> 52,750 solves/s).
+// arbiter's own oldest-first order is the better one (rotation: 55,300 -> 52,750 solves/s). Priorities by PHASE instead of by time slice
+// (the stall-prone adjoint sweep first, or last) were measured too: -0.4 % / -2.2 %.
 constexpr int PRIO_SLICE_LOG2 = 16;               // 2^16 ticks of the 100 MHz s_memrealtime clock
 DI void duo_rotate_priority() {
 #if SDEMPC_VAR_NO_ROTATE      // diagnostic builds: the arbiter's own order (profiles/r2_phase_clock.txt)

@@ -5,7 +5,7 @@
 tag=${1:-r03}; B=${2:-12288}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --latency-reps 40 > $out/bench_trace.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-tolerance-modes --latency-reps 40 > $out/bench_trace.log 2>&1
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" \

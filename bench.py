@@ -423,16 +423,17 @@ def main():
                                    "cpu_c1_note": f"BASELINE config 1: c1_iris_posctrl_h20_p32.yaml H={c1cfg.horizon} P={c1cfg.num_particles}, one cold-start solve "
                                                   f"(N_it {c1['vec'][1]:.0f}) on ONE thread, median of 3: particle-vectorised build / bit-exact scalar -O2 build"}
         if world == 1 and args.mlp_dtype == "f32" and cfg.math_mode == "exact" and not args.no_tolerance_modes and os.path.basename(args.config).startswith("c2_"):
-            # The optional tolerance-parity modes on the same instances (one launch each: ~4 s), never the reported value:
+            # The optional tolerance-parity modes on the same instances (a warm-up and a timed launch each: ~20 s in all), never the reported value:
             # solves/s and how far their controls are from the exact path's (north star: 1e-4). SPEC.md 9 / 10, DESIGN.md 2.
             modes = {}
             u2 = torch.empty_like(uopt); x2 = torch.empty_like(xevol); i2 = torch.empty_like(info)
             for name, kw in (("math_mode_fast", dict(math_mode="fast")), ("mlp_dtype_f16", dict(mlp_dtype="f16")),
                              ("math_mode_fast+mlp_dtype_f16", dict(math_mode="fast", mlp_dtype="f16"))):
                 s2 = SdeMpcSolver(cfg.replace(**kw), blob, max_batch=B, device=dev_ord)
-                s2.solve_dev(B, x0.data_ptr(), xref.data_ptr(), noise.data_ptr(), u0.data_ptr(), step_in.data_ptr(),
-                             u2.data_ptr(), x2.data_ptr(), i2.data_ptr(), stream)
-                ms2 = s2.last_kernel_ms()
+                for _ in range(2):                  # (a first launch of these kernels measured 7 % slow)
+                    s2.solve_dev(B, x0.data_ptr(), xref.data_ptr(), noise.data_ptr(), u0.data_ptr(), step_in.data_ptr(),
+                                 u2.data_ptr(), x2.data_ptr(), i2.data_ptr(), stream)
+                    ms2 = s2.last_kernel_ms()
                 torch.cuda.synchronize()
                 du = np.abs(u2.cpu().numpy() - uopt_h).reshape(B, -1)
                 ok = np.all(du <= 1e-4 + 1e-4 * np.abs(uopt_h).reshape(B, -1), axis=1)

@@ -37,6 +37,10 @@
 extern "C" {
 #endif
 
+/* Version of this header's struct layouts and entry points; sdempc_abi_version() returns the one the library was built with. A binding
+ * compares the two before it passes a struct (2: sdempc_cfg grew the state_constr fields, handle options, work counters). */
+#define SDEMPC_ABI_VERSION 2
+
 #define SDEMPC_NX 13          /* state dims */
 #define SDEMPC_NNOISE 6       /* noisy state dims: v(3), omega(3) */
 #define SDEMPC_MAX_MOTORS 8
@@ -235,8 +239,11 @@ int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const 
 
 /* After the stream of the last sdempc_solve_batch_dev call has been synchronised: SDEMPC_OK, or SDEMPC_EDEVICE when a grid barrier of
  * a cooperative layout gave up (results of that call invalid, telemetry NaN). The handle then stays off the cooperative layouts, so
- * repeating the call runs in the one-workgroup-per-instance layout. New in this build (no reference counterpart: the reference's
- * solver call, sde_control.py:405-416, either returns or kills the process). */
+ * repeating the call runs in the one-workgroup-per-instance layout. Also SDEMPC_EDEVICE when a large throughput launch that hands its
+ * instances out by ticket (three rounds of the persistent grid or more) ended with a ticket count other than the one the host expects:
+ * instances of that launch may then be unsolved (the handle re-synchronises itself; repeat the call). Such launches are issued one at a
+ * time per handle, in order, and cannot be captured into a hipGraph (the launch carries the ticket base of its own moment). New in this
+ * build (no reference counterpart: the reference's solver call, sde_control.py:405-416, either returns or kills the process). */
 int sdempc_solve_status(sdempc_handle* h);
 /* Number of times this handle left the cooperative layouts because a grid barrier gave up (0 in normal operation). */
 int32_t sdempc_layout_fallbacks(const sdempc_handle* h);

@@ -7,11 +7,12 @@ language and another loop order (all particles at once instead of one particle a
 
   * forward rollout, particle x horizon tensor, mean trajectory, expected cost, control cost: BIT-IDENTICAL to the C oracle
     (SPEC.md §3-§6; float32 with an exact software fma, see `fma`);
-  * the accelerated proximal gradient loop of SPEC.md §8, driven by the C oracle's cost / gradient callbacks but with its own
-    reductions (§6.2) and decision logic: BIT-IDENTICAL controls and telemetry;
-  * the adjoint (§5.4-§5.5): the C oracle's float32 gradient against reverse-mode automatic differentiation (torch.autograd,
-    float64, libm activations) of the same model written here a third time (`torch_cost`) — a check that does not share the
-    hand-derived vector-Jacobian product with anything.
+  * the adjoint sweep and gradient assembly (§5.4-§5.5), written here a second time in float32 with the same software fma, all
+    particles at once: gradient BIT-IDENTICAL to the C oracle's;
+  * the accelerated proximal gradient loop of SPEC.md §8 on THIS file's own cost and gradient (`solve_own`: nothing of the C oracle
+    takes part), own reductions (§6.2) and decision logic: BIT-IDENTICAL controls and telemetry;
+  * and, independent of both hand-derived adjoints: the float32 gradient against reverse-mode automatic differentiation
+    (torch.autograd, float64, libm activations) of the same model written here a third time (`torch_cost`).
 
 Follows (reference): call shapes sde_control.py:702-719,400-416; YAML keys launch/iris_sitl_traj_mpc.yaml:8-85.
 """
@@ -195,7 +196,7 @@ class Restatement:
         return c, F(Tz), (F(t0), F(t1), F(t2))
 
     # ---- §5.2: all particles at once; x [P,13], xi [P,6] ----
-    def step(self, x, xi, u_terms, t):
+    def step(self, x, xi, u_terms, t, want_aux=False):
         M = self.M
         c, Tz, tau = u_terms
         dt = self.dt[t]
@@ -241,7 +242,109 @@ class Restatement:
         rn = rsqrt(n2)
         for i in range(4):
             xn[:, 6 + i] = qt[i] * rn
+        if want_aux:
+            return xn, eta, dict(R=R, h1d=h1d, h1n=h1n, h2=h2, eta=eta, Fb=Fb, Jom=Jom, rn=rn, qn=[xn[:, 6 + i] for i in range(4)])
         return xn, eta
+
+    # ---- §5.4: vector-Jacobian product of one step, all particles at once (own writing of the hand-derived adjoint; float32, exact fma) ----
+    def step_vjp(self, x, xi, t, A, L, etabar_cost):
+        """x [P,13] = x_t, xi [P,6], A = auxiliaries of step(x_t), L [P,13] = adjoint of x_{t+1} (stage-cost gradient folded in),
+        etabar_cost [P] = direct d(cost)/d(eta). -> (lam [P,13], gu [P,m], gT [P], gtau [P,3])"""
+        M, m = self.M, self.m
+        dt, sdt = self.dt[t], self.sdt[t]
+        v, q, om = [x[:, 3 + i] for i in range(3)], [x[:, 6 + i] for i in range(4)], [x[:, 10 + i] for i in range(3)]
+        Lp, Lv, Lq, Lo = [L[:, i] for i in range(3)], [L[:, 3 + i] for i in range(3)], [L[:, 6 + i] for i in range(4)], [L[:, 10 + i] for i in range(3)]
+        R, qn, rn, Jom, Fb, eta = A["R"], A["qn"], A["rn"], A["Jom"], A["Fb"], A["eta"]
+        qw, qx, qy, qz = q
+        eb = np.asarray(etabar_cost, F)
+        for i in range(3):
+            eb = fma(Lv[i] * sdt[i], xi[:, i], eb)
+        for i in range(3):
+            eb = fma(Lo[i] * sdt[3 + i], xi[:, 3 + i], eb)
+        ebraw = eb * (eta * (F(1) - eta))
+        dotq = fma(qn[3], Lq[3], fma(qn[2], Lq[2], fma(qn[1], Lq[1], qn[0] * Lq[0])))
+        qtb = [rn * fma(-qn[i], dotq, Lq[i]) for i in range(4)]
+        dqb = [qtb[i] * dt for i in range(4)]
+        taub_b = [(Lo[i] * dt) * M.iJ[i] for i in range(3)]
+        crb = [-taub_b[i] for i in range(3)]
+        omb = [Lo[0] + fma(Jom[1], crb[2], -(Jom[2] * crb[1])),
+               Lo[1] + fma(Jom[2], crb[0], -(Jom[0] * crb[2])),
+               Lo[2] + fma(Jom[0], crb[1], -(Jom[1] * crb[0]))]
+        Jb = [fma(crb[1], om[2], -(crb[2] * om[1])), fma(crb[2], om[0], -(crb[0] * om[2])), fma(crb[0], om[1], -(crb[1] * om[0]))]
+        omb = [fma(M.J[i], Jb[i], omb[i]) for i in range(3)]
+        Fwb = [(Lv[i] * dt) * M.inv_mass for i in range(3)]
+        Fbb = [fma(R[6 + j], Fwb[2], fma(R[3 + j], Fwb[1], R[j] * Fwb[0])) for j in range(3)]
+        ob = [M.sF[i] * Fbb[i] for i in range(3)] + [M.sT[i] * taub_b[i] for i in range(3)]
+        gT, gtau = Fbb[2], np.stack(taub_b, axis=1)
+        # MLP part: abar2 = (W3^T obar) (1 - h2^2); hbar1d = W2^T abar2 in the k order of §4; abar1 = hbar1 (1 - h1^2)
+        h1d, h1n, h2 = A["h1d"], A["h1n"], A["h2"]
+        hb2 = np.zeros_like(h2)
+        for i in range(6):
+            hb2 = fma(M.W3[i][None, :], ob[i][:, None], hb2)
+        a2b = hb2 * fma(-h2, h2, F(1))
+        hb1 = np.zeros_like(h1d)
+        for i in korder():
+            hb1 = fma(M.W2[i, :][None, :], a2b[:, i][:, None], hb1)
+        a1d = hb1 * fma(-h1d, h1d, F(1))
+        a1n = (M.w3n[None, :] * ebraw[:, None]) * fma(-h1n, h1n, F(1))
+        zb = []
+        for k in range(6):
+            P0, P1 = np.zeros(x.shape[0], F), np.zeros(x.shape[0], F)
+            for tile, a1 in ((32, a1n), (0, a1d)):                       # density tile first, then the drift tile
+                for r in range(16):
+                    k0, k1 = (r & 3) + 8 * (r >> 2), (r & 3) + 8 * (r >> 2) + 4
+                    P0 = fma(M.W1z[tile + k0, k], a1[:, k0], P0)
+                    P1 = fma(M.W1z[tile + k1, k], a1[:, k1], P1)
+            zb.append(P0 + P1)
+        gu = np.stack([half_sums(M.W1u[:, j], a1d) for j in range(m)], axis=1)
+        omb = [omb[i] + zb[3 + i] for i in range(3)]
+        vbar = [fma(Lp[i], dt, Lv[i]) + fma(R[3 * i + 2], zb[2], fma(R[3 * i + 1], zb[1], R[3 * i] * zb[0])) for i in range(3)]
+        Rb = [fma(v[i], zb[j], Fwb[i] * Fb[j]) for i in range(3) for j in range(3)]
+        qb = [fma(F(0.5), fma(dqb[3], om[2], fma(dqb[2], om[1], dqb[1] * om[0])), qtb[0]),
+              fma(F(0.5), fma(dqb[3], om[1], fma(-dqb[2], om[2], -(dqb[0] * om[0]))), qtb[1]),
+              fma(F(0.5), fma(-dqb[3], om[0], fma(dqb[1], om[2], -(dqb[0] * om[1]))), qtb[2]),
+              fma(F(0.5), fma(dqb[2], om[0], fma(-dqb[1], om[1], -(dqb[0] * om[2]))), qtb[3])]
+        omb = [fma(F(0.5), fma(-dqb[3], qy, fma(dqb[2], qz, fma(dqb[1], qw, -(dqb[0] * qx)))), omb[0]),
+               fma(F(0.5), fma(dqb[3], qx, fma(dqb[2], qw, fma(-dqb[1], qz, -(dqb[0] * qy)))), omb[1]),
+               fma(F(0.5), fma(dqb[3], qw, fma(-dqb[2], qx, fma(dqb[1], qy, -(dqb[0] * qz)))), omb[2])]
+        s01, d10 = Rb[1] + Rb[3], Rb[3] - Rb[1]
+        s02, d02 = Rb[2] + Rb[6], Rb[2] - Rb[6]
+        s12, d21 = Rb[5] + Rb[7], Rb[7] - Rb[5]
+        qb = [fma(F(2), fma(qx, d21, fma(qy, d02, qz * d10)), qb[0]),
+              fma(F(2), fma(qw, d21, fma(qz, s02, qy * s01)), fma(F(-4) * qx, Rb[4] + Rb[8], qb[1])),
+              fma(F(2), fma(qz, s12, fma(qw, d02, qx * s01)), fma(F(-4) * qy, Rb[0] + Rb[8], qb[2])),
+              fma(F(2), fma(qy, s12, fma(qx, s02, qw * d10)), fma(F(-4) * qz, Rb[0] + Rb[4], qb[3]))]
+        lam = np.stack(Lp + vbar + qb + omb, axis=1).astype(F)
+        return lam, gu, gT, gtau
+
+    # gradient of the stage cost of §5.3 at x [P,13]
+    def stage_cost_grad(self, x, xr):
+        C = self.cfg
+        gx = np.zeros_like(x)
+        for w_, off in ((C.perr, 0), (C.verr, 3), (C.werr, 10)):
+            for i in range(3):
+                e = x[:, off + i] - xr[off + i]
+                gx[:, off + i] = F(2) * (F(w_[i]) * e)
+        qw, qx, qy, qz = x[:, 6], x[:, 7], x[:, 8], x[:, 9]
+        rw, rx, ry, rz = xr[6], xr[7], xr[8], xr[9]
+        ex = fma(rz, qy, fma(-ry, qz, fma(-rx, qw, rw * qx)))
+        ey = fma(-rz, qx, fma(-ry, qw, fma(rx, qz, rw * qy)))
+        ez = fma(-rz, qw, fma(ry, qx, fma(-rx, qy, rw * qz)))
+        a, b, c = F(2) * (F(C.qerr[0]) * ex), F(2) * (F(C.qerr[1]) * ey), F(2) * (F(C.qerr[2]) * ez)
+        gx[:, 6] = fma(-rz, c, fma(-ry, b, -rx * a))
+        gx[:, 7] = fma(ry, c, fma(-rz, b, rw * a))
+        gx[:, 8] = fma(-rx, c, fma(rw, b, rz * a))
+        gx[:, 9] = fma(rw, c, fma(rx, b, -ry * a))
+        if C.state_id:
+            for k, i in enumerate(C.state_id):
+                w = F(F(C.state_penalty[k]) * F(C.constr_pen))
+                with np.errstate(invalid="ignore"):
+                    hi = x[:, i] - F(C.state_bound[k][1])
+                    hi = np.where(hi < 0, F(0), hi).astype(F)
+                    lo = F(C.state_bound[k][0]) - x[:, i]
+                    lo = np.where(lo < 0, F(0), lo).astype(F)
+                gx[:, i] = fma(F(2) * w, hi - lo, gx[:, i])
+        return gx
 
     # ---- §5.3 ----
     def stage_cost(self, x, xr):
@@ -321,6 +424,74 @@ class Restatement:
                         c = fma(F(F(C.u_slew_constr_coeff) * lo), lo, c)
                 el[t, j] = F(self.disc[t] * F(c))
         return self.dot256(el)
+
+    def control_cost_grad(self, u):
+        """analytic gradient of control_cost (SPEC.md §5.5)"""
+        C, H, m = self.cfg, self.H, self.m
+        u = np.asarray(u, F)
+        dw = np.zeros((H, m), F)
+        for t in range(1, H):
+            for j in range(m):
+                ds = F(u[t, j] - u[t - 1, j])
+                d = F(F(F(2) * F(C.u_slew_coeff)) * ds)
+                if C.u_slew_constr is not None:
+                    lo_b, hi_b = C.u_slew_constr[j]
+                    hi = max(F(0.0), F(ds - F(hi_b)))
+                    lo = max(F(0.0), F(F(lo_b) - ds))
+                    d = fma(F(F(2) * F(C.u_slew_constr_coeff)), F(hi - lo), d)
+                dw[t, j] = d
+        g = np.zeros((H, m), F)
+        for t in range(H):
+            for j in range(m):
+                du = F(u[t, j] - F(C.uref[j]))
+                gg = F(self.disc[t] * fma(F(F(2) * F(C.uerr)), du, dw[t, j]))
+                if t + 1 < H:
+                    gg = fma(-self.disc[t + 1], dw[t + 1, j], gg)
+                g[t, j] = gg
+        return g
+
+    def cost_grad(self, x0, u, xref, noise):
+        """-> (expected cost, gradient [H,m]) by the adjoint sweep of SPEC.md §5.4-§5.5, all particles at once"""
+        M, H, P, m = self.M, self.H, self.P, self.m
+        x0, u, xref, noise = (np.asarray(a, F) for a in (x0, u, xref, noise))
+        res = F(self.cfg.res_mult)
+        ut = [self.ustep(u[t]) for t in range(H)]
+        x = np.broadcast_to(x0, (P, 13)).astype(F).copy()
+        traj = [x]
+        J = np.zeros(P, F)
+        for t in range(H):
+            xn, eta = self.step(x, noise[:, t], ut[t], t)
+            l = fma(res * eta, eta, self.stage_cost(xn, xref[t + 1]))
+            J = fma(self.disc[t], l, J)
+            x = xn
+            traj.append(x)
+        lam = np.zeros((P, 13), F)
+        g = np.zeros((H, m), F)
+        gcu = self.control_cost_grad(u)
+        for t in range(H - 1, -1, -1):
+            xt, x1 = traj[t], traj[t + 1]
+            _, _, A = self.step(xt, noise[:, t], ut[t], t, want_aux=True)
+            gx = self.stage_cost_grad(x1, xref[t + 1])
+            L = fma(self.disc[t], gx, lam)
+            ebc = self.disc[t] * ((F(2) * res) * A["eta"])
+            lam, gu, gT, gtau = self.step_vjp(xt, noise[:, t], t, A, L, ebc)
+            S_gu, S_T, S_tau = self.particle_sum(gu), self.particle_sum(gT), self.particle_sum(gtau)
+            for j in range(m):
+                uj = u[t, j]
+                dT = fma(F(2) * M.ct2, uj, M.ct1)
+                dM = F(M.dir[j] * fma(F(2) * M.cm2, uj, M.cm1))
+                a = S_gu[j]
+                a = fma(S_T, dT, a)
+                a = fma(S_tau[0], F(M.ry[j] * dT), a)
+                a = fma(S_tau[1], F(-(M.rx[j] * dT)), a)
+                a = fma(S_tau[2], dM, a)
+                g[t, j] = fma(a, self.invP, gcu[t, j])
+        tot = self.particle_sum(J)
+        return F(fma(tot, self.invP, self.control_cost(u))), g
+
+    def solve_own(self, x0, xref, noise, u_init, stepsize_in):
+        """SPEC.md §8 with THIS file's cost and gradient: nothing of the C oracle takes part."""
+        return self.solve(lambda uu: self.rollout(x0, uu, xref, noise)[0], lambda yy: self.cost_grad(x0, yy, xref, noise), u_init, stepsize_in)
 
     def rollout(self, x0, u, xref, noise):
         """-> (expected cost, traj [P,H+1,13], mean trajectory [H+1,13])"""

@@ -61,6 +61,8 @@ INFO_FIELDS = [f[0] for f in SdempcInfo._fields_]
 # execution options of a handle (include/sdempc.h, SDEMPC_OPT_*)
 OPTIONS = {"lane": 1, "coop": 2, "spec": 3, "pk": 4, "ustg": 5, "coop_launch": 6, "coop_fence": 7, "coop_spin_us": 8, "device_cus": 9, "duo": 10}
 
+ABI_VERSION = 2          # include/sdempc.h: SDEMPC_ABI_VERSION (the layout of SdempcCfg / SdempcInfo below)
+
 _LIB = None
 
 
@@ -91,6 +93,10 @@ def load_library():
     lib.sdempc_last_error.argtypes = [vp]
     lib.sdempc_last_error.restype = C.c_char_p
     lib.sdempc_abi_version.restype = C.c_int
+    got = lib.sdempc_abi_version()
+    if got != ABI_VERSION:       # a stale build (or an SDEMPC_LIB override made against an older header) would read SdempcCfg past its end
+        raise RuntimeError(f"{path} reports ABI version {got}, this package's struct layouts are version {ABI_VERSION} "
+                           "(include/sdempc.h: SDEMPC_ABI_VERSION): rebuild the library (make -C sde4mbrl_px4_amd/csrc)")
     lib.sdempc_set_device.argtypes = [vp, i32]
     lib.sdempc_device_ready.argtypes = [vp]
     lib.sdempc_device_ready.restype = C.c_int

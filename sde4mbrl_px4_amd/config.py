@@ -72,7 +72,8 @@ class MPCConfig:
     ls_increase_factor: float = 1.3
     ls_reset_option: str = "increase"
     ls_maxls: int = 4
-    # extension key (not in the reference schema): "f32" (default, bit-reproducible) or "f16" (SPEC.md §9)
+    # extension key (not in the reference schema): "f32" (default), "f16" (SPEC.md §9) or "f32x3" (§9b: layer-2 contractions as three-limb
+    # bf16 splits on the matrix pipe, f32-level accuracy); all three are reproduced bit for bit by the oracle
     mlp_dtype: str = "f32"
     math_mode: str = "exact"
 
@@ -145,9 +146,9 @@ class MPCConfig:
                 c.state_id[k] = i
                 c.state_w[k] = float(np.float32(self.state_penalty[k]) * np.float32(self.constr_pen))
                 c.state_lo[k], c.state_hi[k] = float(self.state_bound[k][0]), float(self.state_bound[k][1])
-        if self.mlp_dtype not in ("f32", "f16"):
-            raise ValueError(f"mlp_dtype must be f32|f16, got {self.mlp_dtype!r}")
-        c.mlp_dtype = 1 if self.mlp_dtype == "f16" else 0
+        if self.mlp_dtype not in ("f32", "f16", "f32x3"):
+            raise ValueError(f"mlp_dtype must be f32|f16|f32x3, got {self.mlp_dtype!r}")
+        c.mlp_dtype = {"f32": 0, "f16": 1, "f32x3": 2}[self.mlp_dtype]
         if self.math_mode not in ("exact", "fast"):
             raise ValueError(f"math_mode must be exact|fast, got {self.math_mode!r}")
         c.math_mode = 1 if self.math_mode == "fast" else 0

@@ -15,7 +15,9 @@
 
 #include <cxxabi.h>
 
+#include <memory>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -54,9 +56,10 @@ struct sdempc_handle {
     int m = 0, H = 0, P = 0, G = 0, max_batch = 0;
     int device = 0;
     bool dev_ready = false;
-    std::string err;
+    mutable std::string err;
     KArgs base;
     unsigned ticket_total = 0;   // running value of the device ticket word (KArgs::ticket_host points here; sdempc_kernels.hip, launch_persistent)
+    bool last_ticketed = false;  // the last solve launch handed its instances out by ticket: sdempc_solve_status compares the word with the mirror
     // host tables
     std::vector<float> h_sdt, h_disc, h_beta;
     // device tables
@@ -88,6 +91,21 @@ int fail(sdempc_handle* h, int code, const char* fmt, const char* detail = "") {
     snprintf(buf, sizeof buf, fmt, detail);
     if (h) h->err = buf; else g_create_error = buf;
     return code;
+}
+
+// No exception may cross the C ABI (include/sdempc.h: "never aborts or throws"; an exception in the reference's forked worker would
+// end mpc_process silently, sde_control.py:365-419): every entry point runs inside guarded(), which turns std::bad_alloc into
+// SDEMPC_ENOMEM and anything else into SDEMPC_EINVAL. The handlers themselves allocate nothing that can throw past them.
+void set_error_nothrow(const sdempc_handle* h, const char* msg) noexcept {
+    try { if (h) h->err = msg; else g_create_error = msg; } catch (...) { /* no room even for the message: the code still reports it */ }
+}
+template <class F>
+int guarded(const sdempc_handle* h, F&& f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { set_error_nothrow(h, "out of host memory"); return SDEMPC_ENOMEM; }
+    catch (const std::length_error&) { set_error_nothrow(h, "a table size derived from the arguments exceeds what the host can allocate"); return SDEMPC_ENOMEM; }
+    catch (const std::exception& e) { set_error_nothrow(h, e.what()); return SDEMPC_EINVAL; }
+    catch (...) { set_error_nothrow(h, "unexpected exception inside libsdempc"); return SDEMPC_EINVAL; }
 }
 
 #define HIPCHK(h, call)                                                                 \
@@ -294,6 +312,24 @@ int coop_timed_out(sdempc_handle* h, bool* timed_out) {
     return 0;
 }
 
+// A ticketed persistent launch (sdempc_kernels.hip, launch_persistent) draws its instances relative to the value the device's ticket word
+// had at launch, which the host mirrors (ticket_total) on the assumption that every launch advances the word by exactly its batch size.
+// Anything that breaks the assumption — a kernel that was aborted, two launches of one handle overlapping on different streams, a
+// captured graph replaying a launch with its baked-in base — would leave instances unsolved with stale outputs. Call after the launch's
+// stream has been synchronised: compares the word with the mirror, re-synchronises the mirror and reports the launch as failed.
+int tickets_consistent(sdempc_handle* h) {
+    if (!h->last_ticketed || !h->dev_ready) return 0;
+    h->last_ticketed = false;
+    unsigned word = 0;
+    HIPCHK(h, hipMemcpy(&word, (const char*)h->d_work.p + 4 * sizeof(unsigned long long), sizeof word, hipMemcpyDeviceToHost));
+    if (word == h->ticket_total) return 0;
+    char msg[256];
+    snprintf(msg, sizeof msg, "ticketed launch: the device's ticket word reads %u where the host expects %u (aborted kernel, overlapping launches of one "
+                              "handle, or a replayed graph); instances of that launch may be unsolved", word, h->ticket_total);
+    h->ticket_total = word;
+    return fail(h, SDEMPC_EDEVICE, "%s", msg);
+}
+
 template <class F>
 int timed_launch(sdempc_handle* h, hipStream_t st, F&& f) {
     HIPCHK(h, hipEventRecord(h->ev0, st));
@@ -311,11 +347,12 @@ int solve_staged(sdempc_handle* h, int32_t B, float* uopt, float* xevol, sdempc_
 
 extern "C" {
 
-int sdempc_abi_version(void) { return 1; }
+int sdempc_abi_version(void) { return SDEMPC_ABI_VERSION; }
 
 const char* sdempc_last_error(const sdempc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_bytes, int32_t max_batch, sdempc_handle** out) {
+    return guarded(nullptr, [&]() -> int {
     if (!out) return fail(nullptr, SDEMPC_EINVAL, "out is NULL%s");
     *out = nullptr;
     if (!cfg || cfg->struct_size != (int32_t)sizeof(sdempc_cfg)) return fail(nullptr, SDEMPC_EINVAL, "cfg NULL or struct_size mismatch%s");
@@ -336,7 +373,9 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     for (int t = 0; t < cfg->horizon; ++t)
         if (!(cfg->time_steps[t] > 0.0f)) return fail(nullptr, SDEMPC_EINVAL, "time_steps must be positive%s");
     if (smem_bytes(cfg->horizon, m, team_ipb((cfg->num_particles + 31) / 32, cfg->horizon, m)) > 160 * 1024) return fail(nullptr, SDEMPC_EINVAL, "horizon too large for one workgroup's LDS (160 KiB)%s");
-    sdempc_handle* h = new (std::nothrow) sdempc_handle();
+    if (cfg->max_iter > 10 * 1000 * 1000) return fail(nullptr, SDEMPC_EINVAL, "max_iter beyond 10^7%s");
+    std::unique_ptr<sdempc_handle> hp(new (std::nothrow) sdempc_handle());      // released into *out on success only
+    sdempc_handle* h = hp.get();
     if (!h) return fail(nullptr, SDEMPC_ENOMEM, "out of memory%s");
     h->cfg = *cfg;
     h->H = cfg->horizon; h->P = cfg->num_particles; h->m = m; h->G = (h->P + 31) / 32; h->max_batch = max_batch;
@@ -344,8 +383,8 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     h->cfg.time_steps = h->time_steps.data();
     const float* f = (const float*)(hd + SDEMPC_BLOB_HEADER_INTS);
     h->blob_f.assign(f, f + SDEMPC_BLOB_FLOATS);
-    if (cfg->mlp_dtype != 0 && cfg->mlp_dtype != 1) { delete h; return fail(nullptr, SDEMPC_EINVAL, "mlp_dtype must be 0 (f32) or 1 (f16)%s"); }
-    if (cfg->math_mode != 0 && cfg->math_mode != 1) { delete h; return fail(nullptr, SDEMPC_EINVAL, "math_mode must be 0 (exact) or 1 (fast)%s"); }
+    if (cfg->mlp_dtype < 0 || cfg->mlp_dtype > 2) return fail(nullptr, SDEMPC_EINVAL, "mlp_dtype must be 0 (f32), 1 (f16) or 2 (f32x3)%s");
+    if (cfg->math_mode != 0 && cfg->math_mode != 1) return fail(nullptr, SDEMPC_EINVAL, "math_mode must be 0 (exact) or 1 (fast)%s");
     if (cfg->mlp_dtype == 1) {   // layer-1 state-input weights and layer-2 weights live in fp16 (forward and adjoint alike)
         for (int i = 0; i < 64 * 6; ++i) h->blob_f[56 + i] = f16_rtz_host(h->blob_f[56 + i]);
         for (int i = 0; i < 32 * 32; ++i) h->blob_f[760 + i] = f16_rtz_host(h->blob_f[760 + i]);
@@ -371,7 +410,7 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     memset(&a, 0, sizeof a);
     a.H = h->H; a.P = h->P; a.m = m; a.G = h->G;
     a.invP = 1.0f / (float)h->P;
-    a.f16 = cfg->mlp_dtype == 1;
+    a.f16 = cfg->mlp_dtype;              // 0 f32, 1 fp16 operands (SPEC.md §9), 2 three-limb bf16 split of the layer-2 contractions (§9b)
     a.fast = cfg->math_mode == 1;
     a.M.inv_mass = f[0]; a.M.grav = f[1];
     for (int i = 0; i < 3; ++i) { a.M.J[i] = f[2 + i]; a.M.iJ[i] = f[5 + i]; }
@@ -394,8 +433,9 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     a.A.atol = cfg->atol; a.A.rtol = cfg->rtol; a.A.stepsize = cfg->stepsize; a.A.smax = cfg->ls_max_stepsize;
     a.A.coef = cfg->ls_coef; a.A.dec = cfg->ls_decrease_factor; a.A.inc = cfg->ls_increase_factor;
     default_options(h);
-    *out = h;
+    *out = hp.release();
     return SDEMPC_OK;
+    });
 }
 
 void sdempc_destroy(sdempc_handle* h) {
@@ -425,16 +465,19 @@ void release_device(sdempc_handle* h) {
 extern "C" {
 
 int sdempc_set_device(sdempc_handle* h, int32_t device) {
+    return guarded(h, [&]() -> int {
     if (!h) return SDEMPC_EINVAL;
     if (h->dev_ready) return fail(h, SDEMPC_EINVAL, "sdempc_set_device must precede the first device call%s");
     if (device < 0) return fail(h, SDEMPC_EINVAL, "negative device ordinal%s");
     h->device = device;
     return SDEMPC_OK;
+    });
 }
 
 int sdempc_device_ready(const sdempc_handle* h) { return h && h->dev_ready ? 1 : 0; }
 
 int sdempc_set_option(sdempc_handle* h, int32_t key, int32_t value) {
+    return guarded(h, [&]() -> int {
     if (!h) return SDEMPC_EINVAL;
     LaunchOpts& o = h->base.opt;
     auto flag = [&](int& dst) { if (value != 0 && value != 1) return fail(h, SDEMPC_EINVAL, "option value must be 0 or 1%s"); dst = value; return (int)SDEMPC_OK; };
@@ -454,9 +497,11 @@ int sdempc_set_option(sdempc_handle* h, int32_t key, int32_t value) {
             return SDEMPC_OK;
         default: return fail(h, SDEMPC_EINVAL, "unknown option key%s");
     }
+    });
 }
 
 int sdempc_get_option(const sdempc_handle* h, int32_t key, int32_t* value) {
+    return guarded(h, [&]() -> int {
     if (!h || !value) return SDEMPC_EINVAL;
     const LaunchOpts& o = h->base.opt;
     switch (key) {
@@ -473,9 +518,11 @@ int sdempc_get_option(const sdempc_handle* h, int32_t key, int32_t* value) {
         default: return SDEMPC_EINVAL;
     }
     return SDEMPC_OK;
+    });
 }
 
 int sdempc_reset(sdempc_handle* h, const float* x, const float* xdes, float* yk, sdempc_info* info) {
+    return guarded(h, [&]() -> int {
     if (!h || !yk || !info) return SDEMPC_EINVAL;
     (void)x; (void)xdes;
     for (int t = 0; t < h->H; ++t)
@@ -483,18 +530,22 @@ int sdempc_reset(sdempc_handle* h, const float* x, const float* xdes, float* yk,
     memset(info, 0, sizeof *info);
     info->stepsize = h->cfg.ls_maxls > 0 ? h->cfg.ls_init_stepsize : h->cfg.stepsize;
     return SDEMPC_OK;
+    });
 }
 
 size_t sdempc_noise_dev_floats(const sdempc_handle* h, int32_t B) { return h ? noise_floats(h, B) : 0; }
 size_t sdempc_traj_dev_floats(const sdempc_handle* h, int32_t B) { return h ? traj_floats(h, B) : 0; }
 
 int sdempc_noise_to_device_layout(const sdempc_handle* h, int32_t B, const float* noise_host, float* out_host) {
+    return guarded(h, [&]() -> int {
     if (!h || !noise_host || !out_host || B < 1) return SDEMPC_EINVAL;
     noise_to_dev_layout(h, B, noise_host, out_host);
     return SDEMPC_OK;
+    });
 }
 
 int sdempc_noise_to_device_layout_dev(sdempc_handle* h, int32_t B, const void* noise_canonical_dev, void* noise_out_dev, void* stream) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!noise_canonical_dev || !noise_out_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
@@ -502,9 +553,11 @@ int sdempc_noise_to_device_layout_dev(sdempc_handle* h, int32_t B, const void* n
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     HIPCHK(h, launch_relayout(true, (const float*)noise_canonical_dev, (float*)noise_out_dev, B, h->P, h->G, h->H * SDEMPC_NNOISE, st));
     return SDEMPC_OK;
+    });
 }
 
 int sdempc_traj_to_canonical_dev(sdempc_handle* h, int32_t B, void* traj_out_dev, void* stream) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!traj_out_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
@@ -512,10 +565,12 @@ int sdempc_traj_to_canonical_dev(sdempc_handle* h, int32_t B, void* traj_out_dev
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     HIPCHK(h, launch_relayout(false, (const float*)h->d_traj.p, (float*)traj_out_dev, B, h->P, h->G, (h->H + 1) * SDEMPC_NX, st));
     return SDEMPC_OK;
+    });
 }
 
 int sdempc_rollout_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* u_dev, const void* xref_dev, const void* noise_dev,
                              void* cost_dev, void* xmean_dev, int32_t store_traj, void* stream) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!x0_dev || !u_dev || !xref_dev || !noise_dev || !cost_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
@@ -525,10 +580,12 @@ int sdempc_rollout_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, co
     a.cost = (float*)cost_dev; a.xmean = (float*)xmean_dev; a.store_traj = store_traj;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     return timed_launch(h, st, [&] { return a.fast ? launch_rollout_fast(a, B, st) : launch_rollout(a, B, st); });
+    });
 }
 
 int sdempc_grad_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* u_dev, const void* xref_dev, const void* noise_dev,
                           void* cost_dev, void* grad_dev, void* stream) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!x0_dev || !u_dev || !xref_dev || !noise_dev || !cost_dev || !grad_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
@@ -538,10 +595,12 @@ int sdempc_grad_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const
     a.cost = (float*)cost_dev; a.grad = (float*)grad_dev;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     return timed_launch(h, st, [&] { return a.fast ? launch_grad_fast(a, B, st) : launch_grad(a, B, st); });
+    });
 }
 
 int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const void* xref_dev, const void* noise_dev, const void* u_init_dev,
                            const void* stepsize_dev, void* uopt_dev, void* xevol_dev, void* info_dev, void* stream) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!x0_dev || !xref_dev || !noise_dev || !u_init_dev || !stepsize_dev || !uopt_dev || !xevol_dev || !info_dev)
@@ -569,25 +628,32 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
             HIPCHK(h, hipMemsetAsync(h->d_coop_bar.p, 0, sizeof(unsigned) * 2 * (size_t)B, st));
             a.coop_bar = (unsigned*)h->d_coop_bar.p; a.coop_pp = (float*)h->d_coop_pp.p; a.coop_ck = (float*)h->d_coop_ck.p;
             a.coop_spin = coop_spin_ticks(h);
-            h->last_coop_B = B;
+            h->last_coop_B = B; h->last_ticketed = false;
             if (B <= smax) return timed_launch(h, st, [&] { return launch_solve_spec(a, B, st); });
             if (B <= coop_max_instances(h->P, h->H, h->m, a.opt)) return timed_launch(h, st, [&] { return launch_solve_coop(a, B, st); });
             h->last_coop_B = 0;
         }
     }
     h->last_coop_B = 0;
-    return timed_launch(h, st, [&] { return a.fast ? launch_solve_fast(a, B, st) : launch_solve(a, B, st); });
+    const unsigned tickets_before = h->ticket_total;
+    rc = timed_launch(h, st, [&] { return a.fast ? launch_solve_fast(a, B, st) : launch_solve(a, B, st); });
+    h->last_ticketed = rc == SDEMPC_OK && h->ticket_total != tickets_before;
+    return rc;
+    });
 }
 
 int sdempc_noise_from_keys_dev(sdempc_handle* h, int32_t B, const uint32_t* keys, void* noise_out_dev, void* stream) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!keys || !noise_out_dev) return fail(h, SDEMPC_EINVAL, "NULL pointer%s");
     if ((rc = ensure_device(h))) return rc;
     return noise_from_keys(h, B, keys, (float*)noise_out_dev, stream ? (hipStream_t)stream : h->stream);
+    });
 }
 
 int sdempc_noise_from_keys(sdempc_handle* h, int32_t B, const uint32_t* keys, float* noise) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!keys || !noise) return fail(h, SDEMPC_EINVAL, "NULL pointer%s");
@@ -599,9 +665,11 @@ int sdempc_noise_from_keys(sdempc_handle* h, int32_t B, const uint32_t* keys, fl
     HIPCHK(h, hipMemcpyAsync(noise, h->d_noise_canon.p, sizeof(float) * B * nf, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return SDEMPC_OK;
+    });
 }
 
 int sdempc_last_kernel_name(const sdempc_handle* h, char* buf, size_t n) {
+    return guarded(h, [&]() -> int {
     if (!h || !buf || n < 2) return SDEMPC_EINVAL;
     buf[0] = 0;
     if (!h->last_fn) return SDEMPC_OK;
@@ -616,6 +684,7 @@ int sdempc_last_kernel_name(const sdempc_handle* h, char* buf, size_t n) {
     if (par != std::string::npos) name = name.substr(0, par);
     snprintf(buf, n, "%s", name.c_str());
     return SDEMPC_OK;
+    });
 }
 
 float sdempc_last_kernel_ms(const sdempc_handle* h) {
@@ -628,6 +697,7 @@ float sdempc_last_kernel_ms(const sdempc_handle* h) {
 
 int sdempc_rollout_batch(sdempc_handle* h, int32_t B, const float* x0, const float* u, const float* xref, const float* noise, float* cost,
                          float* traj, float* xmean) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!x0 || !u || !xref || !noise || !cost) return fail(h, SDEMPC_EINVAL, "NULL host pointer%s");
@@ -646,9 +716,11 @@ int sdempc_rollout_batch(sdempc_handle* h, int32_t B, const float* x0, const flo
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return SDEMPC_OK;
+    });
 }
 
 int sdempc_grad_batch(sdempc_handle* h, int32_t B, const float* x0, const float* u, const float* xref, const float* noise, float* cost, float* grad) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!x0 || !u || !xref || !noise || !cost || !grad) return fail(h, SDEMPC_EINVAL, "NULL host pointer%s");
@@ -660,10 +732,12 @@ int sdempc_grad_batch(sdempc_handle* h, int32_t B, const float* x0, const float*
     HIPCHK(h, hipMemcpyAsync(grad, h->d_grad.p, sizeof(float) * B * h->H * h->m, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return SDEMPC_OK;
+    });
 }
 
 int sdempc_solve_batch(sdempc_handle* h, int32_t B, const float* x0, const float* xref, const float* noise, const float* u_init,
                        const float* stepsize_in, float* uopt, float* xevol, sdempc_info* info) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!x0 || !xref || !noise || !u_init || !stepsize_in || !uopt || !xevol || !info) return fail(h, SDEMPC_EINVAL, "NULL host pointer%s");
@@ -671,10 +745,12 @@ int sdempc_solve_batch(sdempc_handle* h, int32_t B, const float* x0, const float
     if ((rc = stage_common(h, B, x0, u_init, xref, noise))) return rc;
     HIPCHK(h, hipMemcpyAsync(h->d_step.p, stepsize_in, sizeof(float) * B, hipMemcpyHostToDevice, h->stream));
     return solve_staged(h, B, uopt, xevol, info);
+    });
 }
 
 int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const float* xref, const uint32_t* keys, const float* u_init,
                             const float* stepsize_in, float* uopt, float* xevol, sdempc_info* info) {
+    return guarded(h, [&]() -> int {
     int rc = check_batch(h, B);
     if (rc) return rc;
     if (!x0 || !xref || !keys || !u_init || !stepsize_in || !uopt || !xevol || !info) return fail(h, SDEMPC_EINVAL, "NULL host pointer%s");
@@ -686,20 +762,25 @@ int sdempc_solve_batch_keys(sdempc_handle* h, int32_t B, const float* x0, const 
     HIPCHK(h, hipMemcpyAsync(h->d_step.p, stepsize_in, sizeof(float) * B, hipMemcpyHostToDevice, h->stream));
     if ((rc = noise_from_keys(h, B, keys, (float*)h->d_noise.p, h->stream))) return rc;
     return solve_staged(h, B, uopt, xevol, info);
+    });
 }
 
 int sdempc_solve_status(sdempc_handle* h) {
+    return guarded(h, [&]() -> int {
     if (!h) return SDEMPC_EINVAL;
     bool to = false;
     int rc = coop_timed_out(h, &to);
     if (rc) return rc;
+    if ((rc = tickets_consistent(h))) return rc;
     return to ? fail(h, SDEMPC_EDEVICE, "cooperative solve: a grid barrier timed out (workgroups not co-resident); results invalid, "
                                         "the handle now stays on the one-workgroup-per-instance layouts%s") : SDEMPC_OK;
+    });
 }
 
 int32_t sdempc_layout_fallbacks(const sdempc_handle* h) { return h ? h->layout_fallbacks : 0; }
 
 int sdempc_work_counters(sdempc_handle* h, uint64_t out[4], int32_t reset) {
+    return guarded(h, [&]() -> int {
     if (!h || !out) return SDEMPC_EINVAL;
     out[0] = out[1] = out[2] = out[3] = 0;
     if (!h->dev_ready) return SDEMPC_OK;
@@ -709,6 +790,7 @@ int sdempc_work_counters(sdempc_handle* h, uint64_t out[4], int32_t reset) {
     for (int i = 0; i < 4; ++i) out[i] = v[i];
     if (reset) HIPCHK(h, hipMemset(h->d_work.p, 0, sizeof v));
     return SDEMPC_OK;
+    });
 }
 
 }  // extern "C"
@@ -727,6 +809,7 @@ int solve_staged(sdempc_handle* h, int32_t B, float* uopt, float* xevol, sdempc_
         HIPCHK(h, hipStreamSynchronize(h->stream));
         bool to = false;
         if ((rc = coop_timed_out(h, &to))) return rc;
+        if ((rc = tickets_consistent(h))) return rc;
         if (!to) return SDEMPC_OK;
         if (attempt) return fail(h, SDEMPC_EDEVICE, "cooperative solve: a grid barrier timed out twice%s");
     }

@@ -93,14 +93,17 @@ DI void duo_noise_request(const float* nzb, unsigned nzo, int t, const float* st
     // so M0 advances by 128 per row beside the instruction offset's 128. (SALU write of M0 -> LDS-DMA needs a wait state: s_nop.)
     const float* rows = nzb + (size_t)t * (NN * 32);                                  // uniform: SGPR pair
     const unsigned m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(const __attribute__((address_space(3))) float*)stage);
+    unsigned m0_keep;        // M0 is saved and restored inside the block: whatever the compiler keeps there (movrel, readlane-by-M0) survives it
     asm volatile(
-        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1\n\t"
-        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:128\n\t"
-        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:256\n\t"
-        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:384\n\t"
-        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:512\n\t"
-        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:640"
-        :: "v"(nzo * 4u), "s"(rows), "s"(m0) : "memory", "scc");      // (M0 is a reserved register: the compiler keeps nothing live in it)
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\t"
+        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:128\n\t"
+        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:256\n\t"
+        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:384\n\t"
+        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:512\n\t"
+        "s_add_u32 m0, m0, 0x80\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:640\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(m0_keep) : "v"(nzo * 4u), "s"(rows), "s"(m0) : "memory", "scc");
 }
 template <int PENDING>
 DI void duo_noise_take(const float* stage, int lane, float* xi) {
@@ -111,7 +114,7 @@ DI void duo_noise_take(const float* stage, int lane, float* xi) {
 
 // NZS: noise from the staging rows (above); !NZS: from the caller's registers xi (instances whose LDS has no room for staging rows
 // without losing a workgroup per CU: long horizons)
-template <bool F16, bool CKPT, bool NZS>
+template <int F16, bool CKPT, bool NZS>
 DI void duo_step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, bool hasB, const float* x, const float* xi_reg, float* xn,
                      StepAux& A, float* acA, float* acB) {
     const float* ust = sm.ust + t * UST;
@@ -158,7 +161,7 @@ DI void duo_step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int
 // ------------------------------------------------------------------------------------------------
 // team-level rollout: expected cost of control sequence u (LDS). Same contract as block_rollout.
 // ------------------------------------------------------------------------------------------------
-template <class Team, bool F16, bool NZS>
+template <class Team, int F16, bool NZS>
 DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;
@@ -257,7 +260,7 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
 // team-level cost + gradient (forward sweep with trajectory / checkpoint store, adjoint sweep). Same contract as block_cost_grad;
 // no register prefetch buffer: built for three waves per SIMD, which hide the latency of the adjoint's loads.
 // ------------------------------------------------------------------------------------------------
-template <class Team, int M, bool F16, bool NZS>
+template <class Team, int M, int F16, bool NZS>
 DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const float* y, float* gout, int b, int tid) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;

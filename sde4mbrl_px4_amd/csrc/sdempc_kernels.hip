@@ -27,7 +27,7 @@
 //   * reductions over particles: v_permlane16/32_swap + DPP adds inside the 32-lane groups (bitwise equal
 //     to the xor butterflies of SPEC.md §6), fixed slot order across waves; no atomics anywhere, results are
 //     run-to-run deterministic and independent of the batch slot.
-//   * template <bool F16>: optional fp16-operand contractions on v_mfma_f32_32x32x16_f16 (SPEC.md §9).
+//   * template <int F16>: optional fp16-operand contractions on v_mfma_f32_32x32x16_f16 (SPEC.md §9).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -61,6 +61,8 @@ constexpr bool FAST = SDEMPC_FAST != 0;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 #define DI __device__ __forceinline__
 // phase fences for the instruction scheduler (SDEMPC_SB=0 lets hipcc interleave freely)
@@ -153,6 +155,7 @@ struct Smem {
     float *W3, *w3n, *b1n, *b2, *b1d, *W1zT, *W1uT;  // weights, row-major in hidden-unit index
     float *A2, *A2T;                                   // MFMA A operands of W2 / W2^T: [q][lane][4]
     float *A2h;                                        // f16 mode: A operands of W2, [half][lane][8 x fp16]
+    float *A2x, *A2xT;                                 // f32x3 mode (aliases the three regions above): bf16 limbs of W2 / W2^T, [limb][half][lane][8 x bf16]
     float *ust;                                        // [H][36]: c[32], Tz, tau[3]
     float *xref;                                       // [H+1][13]
     float *dt, *sdt, *disc;                            // [H], [H][6], [H+1]
@@ -174,10 +177,11 @@ DI Smem carve(float* base, int H, int m, int team, bool coop = false, bool ust_l
     s.b2 = p; p += HID;
     s.b1d = p; p += HID;
     s.W1zT = p; p += NN * 2 * HID;
-    s.W1uT = p; p += 8 * HID;
+    s.W1uT = p; p += m * HID;
     s.A2 = p; p += HID * HID;
     s.A2T = p; p += HID * HID;
-    s.A2h = p; p += 512;
+    s.A2h = p; p += 512 + 512;                 // (f32x3 mode: the same 3072 floats hold 2 x 3 limbs x 2 halves x 64 lanes x 16 bytes)
+    s.A2x = s.A2; s.A2xT = s.A2 + 3 * 2 * 64 * 4;
     s.dt = p; p += (H + 3) & ~3;
     s.sdt = p; p += (H * NN + 3) & ~3;
     s.disc = p; p += (H + 1 + 3) & ~3;
@@ -195,7 +199,7 @@ DI Smem carve(float* base, int H, int m, int team, bool coop = false, bool ust_l
     return s;
 }
 __host__ __device__ inline size_t smem_floats(int H, int m, int ipb, bool coop = false, bool ust_lds = true) {
-    size_t shared = 6 * HID + 4 * HID + NN * 2 * HID + 8 * HID + 2 * HID * HID + 512 + ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3);
+    size_t shared = 6 * HID + 4 * HID + NN * 2 * HID + (size_t)m * HID + 2 * HID * HID + 1024 + ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3);
     size_t per_team = (ust_lds ? (size_t)H * UST : 0) + (((H + 1) * NX + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
     return shared + ipb * per_team + (coop ? (size_t)((H * 12 + 3) & ~3) : 0);
 }
@@ -230,19 +234,40 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid, int BNT
         sm.b2[i] = w[OFF_B2 + i];
     }
     for (int i = tid; i < NN * 2 * HID; i += BNT) { int k = i / (2 * HID), r = i % (2 * HID); sm.W1zT[i] = w[OFF_W1Z + r * NN + k]; }
-    for (int i = tid; i < 8 * HID; i += BNT) { int j = i / HID, r = i % HID; sm.W1uT[i] = w[OFF_W1U + r * 8 + j]; }
+    for (int i = tid; i < a.m * HID; i += BNT) { int j = i / HID, r = i % HID; sm.W1uT[i] = w[OFF_W1U + r * 8 + j]; }
     for (int i = tid; i < a.H; i += BNT) sm.dt[i] = a.dt[i];
     for (int i = tid; i < a.H * NN; i += BNT) sm.sdt[i] = a.sdt[i];
     for (int i = tid; i <= a.H; i += BNT) sm.disc[i] = a.disc[i];
 #pragma unroll
     for (int s = 0; s < 3; ++s) { ww.w1d[s] = w[OFF_W1Z + j * NN + 2 * s + h]; ww.w1n[s] = w[OFF_W1Z + (HID + j) * NN + 2 * s + h]; }
+    if (a.f16 == 2) {
+        // SPEC.md §9b: three bf16 limbs of every W2 entry by truncation, w = w1 + w2 + w3 (+ less than 2^-24 |w|): limb l of k slot e
+        // of lane half hh in K-half hf is hidden unit rowmap(8 hf + e, hh) — forward A operand row jj, transpose A operand column jj
+        unsigned short* ax = reinterpret_cast<unsigned short*>(sm.A2x);
+        unsigned short* axt = reinterpret_cast<unsigned short*>(sm.A2xT);
+        for (int i = tid; i < 2 * 64 * 8; i += BNT) {
+            const int e = i & 7, l = (i >> 3) & 63, hf = i >> 9, jj = l & 31, hh = l >> 5, un = rowmap(8 * hf + e, hh);
+            float wv[2] = {w[OFF_W2 + jj * HID + un], w[OFF_W2 + un * HID + jj]};
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) {
+                unsigned short* dst = tr ? axt : ax;
+                float rem = wv[tr];
+#pragma unroll
+                for (int lb = 0; lb < 3; ++lb) {
+                    const unsigned hi = __float_as_uint(rem) & 0xFFFF0000u;
+                    dst[(lb * 2 + hf) * 512 + l * 8 + e] = (unsigned short)(hi >> 16);
+                    rem = rem - __uint_as_float(hi);
+                }
+            }
+        }
+    } else
     // A operand of k-step r for lane l: W2[j][rowmap(r,h)] (forward) / W2[rowmap(r,h)][j] (transpose)
     for (int i = tid; i < HID * HID; i += BNT) {
         int c = i & 3, l = (i >> 2) & 63, q = i >> 8, jj = l & 31, hh = l >> 5, r = 4 * q + c;
         sm.A2[i] = w[OFF_W2 + jj * HID + rowmap(r, hh)];
         sm.A2T[i] = w[OFF_W2 + rowmap(r, hh) * HID + jj];
     }
-    if (a.f16) {   // weights are already fp16-representable (quantised on the host): the casts are exact
+    if (a.f16 == 1) {   // weights are already fp16-representable (quantised on the host): the casts are exact
         _Float16* ah = reinterpret_cast<_Float16*>(sm.A2h);
         for (int i = tid; i < 2 * 64 * 8; i += BNT) {
             int e = i & 7, l = (i >> 3) & 63, hf = i >> 9, jj = l & 31, hh = l >> 5;
@@ -416,7 +441,7 @@ DI float group_ordered_sum(const float* rows, int G, int PS, int i) {
 // block-level rollout: expected cost of control sequence u (LDS). SPEC.md §5.3/§6/§7
 //   store_traj: stream x_t to a.traj; want_mean: particle mean trajectory -> xmean_out (global)
 // ------------------------------------------------------------------------------------------------
-template <class Team, bool F16, bool PK = false>
+template <class Team, int F16, bool PK = false>
 DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P;
@@ -493,7 +518,7 @@ DI float block_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 // ------------------------------------------------------------------------------------------------
 // PREF: software-prefetch the adjoint sweep's loads one step ahead through a register double buffer (40 VGPRs). Needed when a
 // SIMD holds one or two waves; the throughput instantiation drops it to fit three waves per SIMD, which hide the latency instead.
-template <class Team, int M, bool F16, bool PK = false, bool PREF = true>
+template <class Team, int M, int F16, bool PK = false, bool PREF = true>
 DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const float* y, float* gout, int b, int tid) {
     b = opaque_s(b); tid = opaque_v(tid);
     const int H = a.H, G = a.G, P = a.P, m = a.m;
@@ -648,7 +673,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 #pragma unroll
             for (int i = 0; i < 4; ++i) A.qn[i] = x[6 + i];   // q_{t+1}
             float ebc = dsc * ((2.0f * a.C.res_mult) * A.eta);
-            step_vjp<M>(a, sm, ww, t, h, lane, xt, xi, A, lam, ebc, lamn, gq);
+            step_vjp<M, F16 == 2 ? 2 : 0>(a, sm, ww, t, h, lane, xt, xi, A, lam, ebc, lamn, gq);
 #pragma unroll
             for (int i = 0; i < NX; ++i) { lam[i] = lamn[i]; x[i] = xt[i]; }
             // particle sums of the nq per-step adjoint outputs: both lane halves hold the same values, so the lower
@@ -700,14 +725,14 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 
 // MODE 0: tile layout (32 particles per wave); 1: single-particle lane layout (P == 1); 2: cooperative lane layout (one particle per
 // wave, one instance over several workgroups); 3: duo tile layout (64 particles per wave, throughput launches)
-template <class Team, bool F16, bool PK, int MODE>
+template <class Team, int F16, bool PK, int MODE>
 DI float team_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, CoopCtx& CC, const float* u, int b, int tid, bool store_traj, float* xmean_out) {
     if constexpr (MODE >= 3) return duo_rollout<Team, F16, MODE == 3>(a, sm, ww, u, b, tid, store_traj, xmean_out);
     else if constexpr (MODE == 2) return coop_rollout<Team>(a, sm, LW, CC, u, b, tid, xmean_out);
     else if constexpr (MODE == 1) return lane_rollout<Team>(a, sm, LW, u, b, tid, store_traj, xmean_out);
     else return block_rollout<Team, F16, PK>(a, sm, ww, u, b, tid, store_traj, xmean_out);
 }
-template <class Team, int M, bool F16, bool PK, bool PREF, int MODE>
+template <class Team, int M, int F16, bool PK, bool PREF, int MODE>
 DI float team_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, CoopCtx& CC, const float* y, float* gout, int b, int tid) {
     if constexpr (MODE >= 3) return duo_cost_grad<Team, M, F16, MODE == 3>(a, sm, ww, y, gout, b, tid);
     else if constexpr (MODE == 2) return coop_cost_grad<Team, M>(a, sm, LW, CC, y, gout, b, tid);
@@ -749,7 +774,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     if constexpr (MODE == 1 || MODE == 2) load_lane_weights(a, LW, threadIdx.x & 63); \
     load_common<Team>(a, sm, b, tid);
 
-template <class Team, bool F16, int MODE = 0>
+template <class Team, int F16, int MODE = 0>
 __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_rollout_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE(false);
     const int N = a.H * a.m;
@@ -758,7 +783,7 @@ __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_rollout_kern
     if (tid == 0) a.cost[b] = c;
 }
 
-template <class Team, int M, bool F16, int MODE = 0>
+template <class Team, int M, int F16, int MODE = 0>
 __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_grad_kernel(KArgs a) {
     SDEMPC_KERNEL_PROLOGUE(false);
     const int N = a.H * a.m;
@@ -778,7 +803,7 @@ template <class Team, bool PK> constexpr int solve_waves_per_simd() { return PK 
 // USTG: the per-step control table [H][36] lives in global memory (KArgs::ustg, L1/L2-resident) instead of LDS: long horizons keep three
 // workgroups per CU (C5: 79 KB -> 50 KB per instance)
 // One instance's solve (SPEC.md §8) on its team: everything after the LDS staging of the kernel prologue.
-template <class Team, int M, bool F16, bool PK, int MODE>
+template <class Team, int M, int F16, bool PK, int MODE>
 DI void solve_instance(const KArgs& a, const Smem& sm, const WaveW& ww, const LaneW& LW, CoopCtx& CC, const int b, const int tid) {
     const int m = a.m, N = a.H * m;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
@@ -896,7 +921,7 @@ DI void solve_instance(const KArgs& a, const Smem& sm, const WaveW& ww, const La
     }
 }
 
-template <class Team, int M, bool F16, bool PK = false, int MODE = 0, bool USTG = false>
+template <class Team, int M, int F16, bool PK = false, int MODE = 0, bool USTG = false>
 __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 || MODE == 2) ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
     if constexpr (MODE >= 3) {
         // Duo throughput launches (MODE 3: noise through LDS staging rows; 4: through registers) are PERSISTENT: the grid holds as many workgroups as are resident at once (launch_duo_m) and every
@@ -951,12 +976,12 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
 
 // duo solve kernels (MODE 3: noise staging rows, control table in LDS or global memory; MODE 4: neither in LDS), by team shape
 #define SDEMPC_DUO_M(X, TEAM, M)                                                                                   \
-    X(TEAM, M, false, 3, false) X(TEAM, M, true, 3, false) X(TEAM, M, false, 3, true) X(TEAM, M, true, 3, true)  \
-    X(TEAM, M, false, 4, true) X(TEAM, M, true, 4, true)
+    X(TEAM, M, 0, 3, false) X(TEAM, M, 1, 3, false) X(TEAM, M, 2, 3, false) X(TEAM, M, 0, 3, true) X(TEAM, M, 1, 3, true) X(TEAM, M, 2, 3, true)  \
+    X(TEAM, M, 0, 4, true) X(TEAM, M, 1, 4, true) X(TEAM, M, 2, 4, true)
 #define SDEMPC_DUO_TEAM(X, TEAM) SDEMPC_DUO_M(X, TEAM, 4) SDEMPC_DUO_M(X, TEAM, 6) SDEMPC_DUO_M(X, TEAM, 8)
 #define SDEMPC_DUO_PAIR(X)                                                                                          \
-    X(TeamPair, 4, false, 3, false) X(TeamPair, 4, true, 3, false) X(TeamPair, 6, false, 3, false) X(TeamPair, 6, true, 3, false) \
-    X(TeamPair, 8, false, 3, false) X(TeamPair, 8, true, 3, false)
+    X(TeamPair, 4, 0, 3, false) X(TeamPair, 4, 1, 3, false) X(TeamPair, 4, 2, 3, false) X(TeamPair, 6, 0, 3, false) X(TeamPair, 6, 1, 3, false) X(TeamPair, 6, 2, 3, false) \
+    X(TeamPair, 8, 0, 3, false) X(TeamPair, 8, 1, 3, false) X(TeamPair, 8, 2, 3, false)
 #define SDEMPC_DUO_DECL(TEAM, M, F16, MODE, USTG) extern template __global__ void sdempc_solve_kernel<TEAM, M, F16, false, MODE, USTG>(KArgs);
 #define SDEMPC_DUO_DEF(TEAM, M, F16, MODE, USTG) template __global__ void sdempc_solve_kernel<TEAM, M, F16, false, MODE, USTG>(KArgs);
 
@@ -997,9 +1022,10 @@ static hipError_t launch_k(Kern k, const KArgs& a, hipStream_t st, int ipb, int 
 }
 template <class Team>
 static hipError_t launch_rollout_team(const KArgs& a, hipStream_t st) {
-    return a.f16 ? launch_k(sdempc_rollout_kernel<Team, true>, a, st, Team::IPB) : launch_k(sdempc_rollout_kernel<Team, false>, a, st, Team::IPB);
+    if (a.f16 == 2) return launch_k(sdempc_rollout_kernel<Team, 2>, a, st, Team::IPB);
+    return a.f16 ? launch_k(sdempc_rollout_kernel<Team, 1>, a, st, Team::IPB) : launch_k(sdempc_rollout_kernel<Team, 0>, a, st, Team::IPB);
 }
-template <class Team, bool F16>
+template <class Team, int F16>
 static hipError_t launch_grad_team(const KArgs& a, hipStream_t st) {
     if (a.m == 4) return launch_k(sdempc_grad_kernel<Team, 4, F16>, a, st, Team::IPB);
     if (a.m == 6) return launch_k(sdempc_grad_kernel<Team, 6, F16>, a, st, Team::IPB);
@@ -1047,7 +1073,7 @@ static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int 
 }
 // Which of the three builds of a duo team shape: noise staging rows + control table in LDS, staging rows + table in global memory, or
 // neither in LDS (long horizons) — the first in that order of preference that keeps the most workgroups per CU.
-template <class TeamD, int M, bool F16>
+template <class TeamD, int M, int F16>
 static hipError_t launch_duo_m(const KArgs& a, hipStream_t st) {
     constexpr int W = TeamD::NWAVES;
     const size_t cap = 156 * 1024, by_regs = 12 / (size_t)W;
@@ -1064,13 +1090,13 @@ static hipError_t launch_duo_m(const KArgs& a, hipStream_t st) {
 }
 // up to four groups: two waves per instance, two instances per four-wave workgroup (TeamPair) when both fit with the control table in
 // LDS at three workgroups per CU; otherwise 128-thread workgroups (TeamBlock2)
-template <int M, bool F16>
+template <int M, int F16>
 static hipError_t launch_duo_small(const KArgs& a, hipStream_t st) {
     if (a.opt.ustg != 1 && smem_bytes(a.H, a.m, 2, false, true, 4) * 3 <= 156 * 1024)
         return launch_persistent(sdempc_solve_kernel<TeamPair, M, F16, false, 3, false>, a, st, 4, TeamPair::BNT, true, 2);
     return launch_duo_m<TeamBlock2, M, F16>(a, st);
 }
-template <bool F16>
+template <int F16>
 static hipError_t launch_duo(const KArgs& a, hipStream_t st) {
     if (a.G <= 4) {
         if (a.m == 4) return launch_duo_small<4, F16>(a, st);
@@ -1081,23 +1107,23 @@ static hipError_t launch_duo(const KArgs& a, hipStream_t st) {
     if (a.m == 6) return launch_duo_m<TeamBlock, 6, F16>(a, st);
     return launch_duo_m<TeamBlock, 8, F16>(a, st);
 }
-template <class Team, bool F16>
+template <class Team, int F16>
 static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
-    if constexpr (!F16 && !FAST) {
+    if constexpr (F16 == 0 && !FAST) {
         // small-batch (latency) launches: one workgroup per CU at most -> a lone wave per SIMD is issue-bound -> packed tanh
         const int wgs = (a.B + Team::IPB - 1) / Team::IPB;
         const bool pk = a.opt.pk >= 0 ? a.opt.pk == 1 : wgs <= a.opt.cus;     // SDEMPC_OPT_PK forces either instantiation (A/B, tests)
         if (pk) {
             if constexpr (Team::IPB == 1) {
                 if (a.G > 4) {   // more particle groups than the four waves of a workgroup: eight waves halve the sequential depth
-                    if (a.m == 4) return launch_k(sdempc_solve_kernel<TeamBlock8, 4, false, true>, a, st, 1, TeamBlock8::BNT);
-                    if (a.m == 6) return launch_k(sdempc_solve_kernel<TeamBlock8, 6, false, true>, a, st, 1, TeamBlock8::BNT);
-                    return launch_k(sdempc_solve_kernel<TeamBlock8, 8, false, true>, a, st, 1, TeamBlock8::BNT);
+                    if (a.m == 4) return launch_k(sdempc_solve_kernel<TeamBlock8, 4, 0, true>, a, st, 1, TeamBlock8::BNT);
+                    if (a.m == 6) return launch_k(sdempc_solve_kernel<TeamBlock8, 6, 0, true>, a, st, 1, TeamBlock8::BNT);
+                    return launch_k(sdempc_solve_kernel<TeamBlock8, 8, 0, true>, a, st, 1, TeamBlock8::BNT);
                 }
             }
-            if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, false, true>, a, st, Team::IPB);
-            if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, false, true>, a, st, Team::IPB);
-            return launch_k(sdempc_solve_kernel<Team, 8, false, true>, a, st, Team::IPB);
+            if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, 0, true>, a, st, Team::IPB);
+            if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, 0, true>, a, st, Team::IPB);
+            return launch_k(sdempc_solve_kernel<Team, 8, 0, true>, a, st, Team::IPB);
         }
     }
     if constexpr (Team::IPB == 1) {
@@ -1223,14 +1249,14 @@ hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) {
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B;
     if (use_lane(k)) return launch_lane_m(1, k, st);
-    if (use_wave_team(k.G, k.H, k.m)) return k.f16 ? launch_grad_team<TeamWave, true>(k, st) : launch_grad_team<TeamWave, false>(k, st);
-    return k.f16 ? launch_grad_team<TeamBlock, true>(k, st) : launch_grad_team<TeamBlock, false>(k, st);
+    if (use_wave_team(k.G, k.H, k.m)) return k.f16 == 2 ? launch_grad_team<TeamWave, 2>(k, st) : k.f16 ? launch_grad_team<TeamWave, 1>(k, st) : launch_grad_team<TeamWave, 0>(k, st);
+    return k.f16 == 2 ? launch_grad_team<TeamBlock, 2>(k, st) : k.f16 ? launch_grad_team<TeamBlock, 1>(k, st) : launch_grad_team<TeamBlock, 0>(k, st);
 }
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st) {
     KArgs k = a; k.B = B;
     if (use_lane(k)) return launch_lane_m(2, k, st);
-    if (use_wave_team(k.G, k.H, k.m)) return k.f16 ? launch_solve_team<TeamWave, true>(k, st) : launch_solve_team<TeamWave, false>(k, st);
-    return k.f16 ? launch_solve_team<TeamBlock, true>(k, st) : launch_solve_team<TeamBlock, false>(k, st);
+    if (use_wave_team(k.G, k.H, k.m)) return k.f16 == 2 ? launch_solve_team<TeamWave, 2>(k, st) : k.f16 ? launch_solve_team<TeamWave, 1>(k, st) : launch_solve_team<TeamWave, 0>(k, st);
+    return k.f16 == 2 ? launch_solve_team<TeamBlock, 2>(k, st) : k.f16 ? launch_solve_team<TeamBlock, 1>(k, st) : launch_solve_team<TeamBlock, 0>(k, st);
 }
 
 // ------------------------------------------------------------------------------------------------

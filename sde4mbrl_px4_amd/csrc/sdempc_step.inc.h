@@ -24,12 +24,53 @@ DI void fwd_head(const float* x, float* Rm, float* z) {
     z[3] = x[10]; z[4] = x[11]; z[5] = x[12];
 }
 
+// ---- SPEC.md §9b: three-limb bf16 split contraction on the matrix pipe (`mlp_dtype: f32x3`) ----
+// A 32-wide contraction out[i] = c[i] + sum_k W[i][k] v[k] with both operands split by truncation into three bf16 limbs
+// (x = x1 + x2 + x3 up to 2^-24 |x|) and the six leading limb products accumulated in f32 by v_mfma_f32_32x32x16_bf16, in the fixed order
+//     (W3,v1) (W2,v2) (W2,v1) (W1,v3) (W1,v2) (W1,v1),   each as two K = 16 instructions (K-half hf = 0, 1):
+// k slot 8 hh + e of K-half hf is hidden unit rowmap(8 hf + e, hh), i.e. accumulator register 8 hf + e of lane half hh. The dropped
+// products (W2,v3) (W3,v2) (W3,v3) are below 2^-23 of the leading one: f32-level accuracy, with all twelve instructions on the matrix
+// pipe. The instruction's own accumulation (two groups of eight products, fixed-point alignment, SPEC.md §9a) is reproduced by the oracle.
+struct Limbs3 { u32x4 l[3][2]; };      // [limb][K-half]: 8 bf16 per lane = this lane half's k slots
+DI void split3_tile(const f32x16& v, Limbs3& L) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const float x = v[8 * hf + 2 * pr], y = v[8 * hf + 2 * pr + 1];
+            const unsigned x1 = __float_as_uint(x) & 0xFFFF0000u, y1 = __float_as_uint(y) & 0xFFFF0000u;
+            const float xr = x - __uint_as_float(x1), yr = y - __uint_as_float(y1);
+            const unsigned x2 = __float_as_uint(xr) & 0xFFFF0000u, y2 = __float_as_uint(yr) & 0xFFFF0000u;
+            const float xs = xr - __uint_as_float(x2), ys = yr - __uint_as_float(y2);
+            // two bf16 per dword: the high halves of (x, y) -> {x.hi16, y.hi16}
+            L.l[0][hf][pr] = __builtin_amdgcn_perm(y1, x1, 0x07060302u);
+            L.l[1][hf][pr] = __builtin_amdgcn_perm(y2, x2, 0x07060302u);
+            L.l[2][hf][pr] = __builtin_amdgcn_perm(__float_as_uint(ys), __float_as_uint(xs), 0x07060302u);
+        }
+    }
+}
+// acc += sum of the six limb products; Aimg: this layer's A-operand image in LDS, [limb][K-half][lane][8 x bf16] (load_weights)
+DI void mfma_x3(const float* Aimg, int lane, const Limbs3& L, f32x16& acc) {
+    constexpr int WA[6] = {2, 1, 1, 0, 0, 0}, VB[6] = {0, 1, 0, 2, 1, 0};     // limb indices (0-based) of the six products, in order
+    u32x4 aw[2];
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6) {
+        if (s6 == 0 || WA[s6] != WA[s6 - 1]) {     // the weight limb changes three times: six 16-byte LDS reads per contraction
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) aw[hf] = *reinterpret_cast<const u32x4*>(Aimg + ((WA[s6] * 2 + hf) * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[hf]), __builtin_bit_cast(bf16x8, L.l[VB[s6]][hf]), acc, 0, 0, 0);
+    }
+}
+
 // ---- MLPs of a step in the MFMA tile layout (32 particles per wave) ----
 // fwd_mlp_partials: the hidden tiles (A.h1d, A.h1n, A.h2) and the per-half partial chains of the seven output-layer dot products
 // (Po[0..5]: residual force / torque, Po[6]: density pre-activation); fwd_mlp_tiles adds the halves: (P0 + P1) + bias (SPEC.md §5.2).
 // OB: how many of the seven output-layer weight quads of a quarter are requested from LDS together (7: all; the gradient's forward sweep,
 // which also carries the noise prefetch and the checkpoint stream, takes 4 + 3: with all seven in flight its noise prefetch spilled)
-template <bool F16, bool PK, int OB = 7>
+template <int F16, bool PK, int OB = 7>
 DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, StepAux& A, float* Po) {
     // layer 1: C operand = per-step offsets (drift) / bias (density); K = 6 -> 3 MFMAs per tile
     f32x16 accD, accN;
@@ -40,7 +81,7 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         accD[4 * q] = c4.x; accD[4 * q + 1] = c4.y; accD[4 * q + 2] = c4.z; accD[4 * q + 3] = c4.w;
         accN[4 * q] = n4.x; accN[4 * q + 1] = n4.y; accN[4 * q + 2] = n4.z; accN[4 * q + 3] = n4.w;
     }
-    if constexpr (F16) {
+    if constexpr (F16 == 1) {
         // fp16 operands (round toward zero), f32 accumulate: one v_mfma_f32_32x32x16_f16 per tile, k slots 0..5 live in lanes 0..31
         half8 bv;
 #pragma unroll
@@ -75,7 +116,7 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         float4 b4 = *reinterpret_cast<const float4*>(sm.b2 + 8 * q + 4 * h);
         acc2[4 * q] = b4.x; acc2[4 * q + 1] = b4.y; acc2[4 * q + 2] = b4.z; acc2[4 * q + 3] = b4.w;
     }
-    if constexpr (F16) {
+    if constexpr (F16 == 1) {
         // two K=16 MFMAs: k slot e of lane half h <-> accumulator register 8*hf + e, i.e. hidden unit rowmap(8*hf + e, h)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -88,6 +129,10 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
             }
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc2, 0, 0, 0);
         }
+    } else if constexpr (F16 == 2) {
+        Limbs3 L;
+        split3_tile(accD, L);
+        mfma_x3(sm.A2x, lane, L, acc2);
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -135,7 +180,7 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         }
     }
 }
-template <bool F16, bool PK>
+template <int F16, bool PK>
 DI void fwd_mlp_tiles(const KArgs& a, const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, StepAux& A, float* o, float& eta_out) {
     float Po[7];
     fwd_mlp_partials<F16, PK>(a, sm, ww, ust, h, lane, z, A, Po);
@@ -190,7 +235,7 @@ DI void fwd_tail(const KArgs& a, const Smem& sm, const float* ust, int t, const 
     for (int i = 0; i < 4; ++i) { A.qn[i] = qt[i] * A.rn; xn[6 + i] = A.qn[i]; }
 }
 
-template <bool F16, bool PK = false>
+template <int F16, bool PK = false>
 DI void step_fwd(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, float* xn, StepAux& A) {
     const float* ust = sm.ust + t * UST;
     float z[NN];
@@ -314,7 +359,7 @@ DI void vjp_head(const KArgs& a, const Smem& sm, int t, const float* x, const fl
 
 // ---- MLP part in the MFMA tile layout: zb[6] = adjoint of z, gq[0..M-1] = W1u^T abar1 (per particle) ----
 // vjp_mlp_partials leaves the per-half partial chains Pz[6], Pu[M]; vjp_mlp_tiles adds the halves.
-template <int M>
+template <int M, int F16 = 0>
 DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, float ebraw, const float* ob, float* Pz, float* Pu) {
     // MLP VJP. Order chosen to keep few tiles live: density tile first (frees h1n), then the drift
     // tile: abar2 on the VALU, W2^T abar2 by MFMA in the accumulator layout.
@@ -357,6 +402,11 @@ DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, floa
         f32x16 accB;
 #pragma unroll
         for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
+        if constexpr (F16 == 2) {       // SPEC.md §9b: W2^T abar2 as the three-limb bf16 split on the matrix pipe
+            Limbs3 L;
+            split3_tile(a2b, L);
+            mfma_x3(sm.A2xT, lane, L, accB);
+        } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 w4 = *reinterpret_cast<const float4*>(sm.A2T + (q * 64 + lane) * 4);
@@ -364,6 +414,7 @@ DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, floa
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, a2b[4 * q + 1], accB, 0, 0, 0);
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, a2b[4 * q + 2], accB, 0, 0, 0);
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, a2b[4 * q + 3], accB, 0, 0, 0);
+        }
         }
         SCHED_PHASE();
 #pragma unroll
@@ -388,14 +439,14 @@ DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, floa
 }
 // One layer-1 tile (3 f32 MFMAs, or one fp16 MFMA) on top of its C operand, then tanh: the drift tile (DRIFT: C = per-step control
 // terms c_t, A = W1z rows 0..31) or the density tile (C = b1 rows 32..63, A = W1z rows 32..63)
-template <bool F16, bool DRIFT>
+template <int F16, bool DRIFT>
 DI void layer1_tile(const Smem& sm, const WaveW& ww, const float* ust, int h, const float* z, f32x16& acc) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4 c4 = *reinterpret_cast<const float4*>((DRIFT ? ust : sm.b1n) + 8 * q + 4 * h);
         acc[4 * q] = c4.x; acc[4 * q + 1] = c4.y; acc[4 * q + 2] = c4.z; acc[4 * q + 3] = c4.w;
     }
-    if constexpr (F16) {
+    if constexpr (F16 == 1) {
         half8 bv;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
@@ -419,7 +470,7 @@ DI void layer1_tile(const Smem& sm, const WaveW& ww, const float* ust, int h, co
 // consumed, then abar2 from the checkpointed second layer (h2c: this lane's four float4 of the tile), W2^T abar2 by MFMA, and only
 // then the drift layer-1 tile recomputed and consumed. Same operations and the same chain order per value as step_fwd's layer 1 +
 // vjp_mlp_partials (density tile first, then the drift tile: SPEC.md §5.4), hence the same bits; peak 32 tile registers instead of 64.
-template <int M, bool F16>
+template <int M, int F16>
 DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, const float4* h2c,
                      float ebraw, const float* ob, float* Pz, float* Pu) {
 #pragma unroll
@@ -480,6 +531,11 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
+        if constexpr (F16 == 2) {       // SPEC.md §9b: W2^T abar2 as the three-limb bf16 split on the matrix pipe
+            Limbs3 L;
+            split3_tile(a2b, L);
+            mfma_x3(sm.A2xT, lane, L, accB);
+        } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 w4 = *reinterpret_cast<const float4*>(sm.A2T + (q * 64 + lane) * 4);
@@ -487,6 +543,7 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, a2b[4 * q + 1], accB, 0, 0, 0);
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, a2b[4 * q + 2], accB, 0, 0, 0);
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, a2b[4 * q + 3], accB, 0, 0, 0);
+        }
         }
         SCHED_PHASE();
     }
@@ -526,10 +583,10 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
     }
 }
 
-template <int M>
+template <int M, int F16 = 0>
 DI void vjp_mlp_tiles(const Smem& sm, int h, int lane, const StepAux& A, const VjpTmp& T, float* zb, float* gq) {
     float Pz[NN], Pu[M];
-    vjp_mlp_partials<M>(sm, h, lane, A, T.ebraw, T.ob, Pz, Pu);
+    vjp_mlp_partials<M, F16>(sm, h, lane, A, T.ebraw, T.ob, Pz, Pu);
 #pragma unroll
     for (int k = 0; k < NN; ++k) zb[k] = xor32_sum(Pz[k]);
 #pragma unroll
@@ -583,14 +640,14 @@ DI void vjp_tail(const Smem& sm, int t, const float* x, const StepAux& A, const 
     for (int i = 0; i < 4; ++i) lam[6 + i] = qb[i];
 }
 
-template <int M>
+template <int M, int F16 = 0>
 DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, int lane, const float* x, const float* xi, const StepAux& A,
                  const float* L, float etabar_cost, float* lam, float* gq) {
     VjpTmp T;
     vjp_head<M>(a, sm, t, x, xi, A, L, etabar_cost, T, gq);
     SCHED_PHASE();
     float zb[NN];
-    vjp_mlp_tiles<M>(sm, h, lane, A, T, zb, gq);
+    vjp_mlp_tiles<M, F16>(sm, h, lane, A, T, zb, gq);
     vjp_tail(sm, t, x, A, L, T, zb, lam);
 }
 

@@ -9,6 +9,7 @@ Nothing is traced or compiled here: the solver callables already dispatch to pre
 Keys follow JAX's threefry2x32 conventions (prng.py; pinned by public known-answer values)."""
 import logging
 import os
+import warnings
 
 import numpy as np
 
@@ -25,7 +26,7 @@ class _Compiled:
     it up and to learn the output shapes (sde_control.py:706-707, :717-719; the fork is :723-728). A real solve at that point would
     initialise HIP in the parent, and HIP state does not survive fork(). So the FIRST call of a compiled callable, when it is made by
     the process that compiled it, is answered by the callable's `shape_probe_*` twin: outputs of the right shapes and dtypes, no GPU
-    work (logged once). Every later call — in the forked `mpc_process`, or in the same process for in-process users — runs the real
+    work — announced by a RuntimeWarning and a WARNING-level log line, and marked in the returned opt_state (num_steps 0, NaN costs). Every later call — in the forked `mpc_process`, or in the same process for in-process users — runs the real
     solver. SDEMPC_PREFORK=solve switches the probe off (every call is real: only for parents that never fork)."""
 
     def __init__(self, f):
@@ -40,8 +41,13 @@ class _Compiled:
                 name = getattr(self._f, "__name__", "")
                 probe = getattr(getattr(self._f, "__self__", None), "shape_probe_" + name, None)
                 if probe is not None:
-                    _log.info("%s: first call in the compiling process answered by the shape probe (no GPU work; SDEMPC_PREFORK=solve "
-                              "makes it a real solve)", name)
+                    msg = (f"sde4mbrl_px4_amd: the first call of the compiled `{name}` in the process that compiled it is answered by a "
+                           "SHAPE PROBE, not a solve (no GPU work: HIP must not be initialised before the reference node forks its "
+                           "worker, sde_control.py:717-728). Its outputs have the right shapes only: uopt is the warm start, "
+                           "opt_state.num_steps is 0 and its costs are NaN. In-process users who want this call solved set "
+                           "SDEMPC_PREFORK=solve.")
+                    warnings.warn(msg, RuntimeWarning, stacklevel=2)
+                    _log.warning(msg)
                     return probe(*a, **k)
         return self._f(*a, **k)
 

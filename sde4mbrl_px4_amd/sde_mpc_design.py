@@ -115,7 +115,9 @@ class MpcProblem:
         """Outputs with the shapes/dtypes of m_mpc and no device work (see jax_shim._Compiled): the warm start as uopt,
         the current state repeated as xevol. Used only for the reference's pre-fork warm-up calls."""
         x = np.asarray(x, np.float32).reshape(13)
-        return _arr(np.asarray(opt_state.yk, np.float32)), opt_state, rng, _arr(np.tile(x, (self.cfg.horizon + 1, 1)))
+        nan = np.float32(np.nan)       # marks the state as "not the result of a solve": num_steps 0, costs NaN (jax_shim warns as well)
+        marked = opt_state._replace(num_steps=np.float32(0.0), init_cost=nan, opt_cost=nan)
+        return _arr(np.asarray(opt_state.yk, np.float32)), marked, rng, _arr(np.tile(x, (self.cfg.horizon + 1, 1)))
 
     def m_mpc(self, x, rng, opt_state: OptState, curr_t=0.0, xdes=None):
         x = np.asarray(x, np.float32).reshape(13)

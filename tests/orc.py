@@ -15,30 +15,32 @@ _LIB = None
 _LIB_FAST = None
 
 
+def _make(target=None):
+    """`make -C oracle [target]`: always invoked — the Makefile knows every dependency (sources, include/sdempc.h whose sdempc_cfg
+    layout the oracle shares, itself) and is a no-op when the library is current."""
+    cmd = ["make", "-C", ORC_DIR, "-s"] + ([target] if target else [])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{' '.join(cmd)} failed:\n{r.stdout}")
+
+
 def build():
-    so = os.path.join(ORC_DIR, "liborc.so")
-    src = os.path.join(ORC_DIR, "sde_mpc_oracle.c")
-    hdr = os.path.join(ROOT, "include", "sdempc.h")
-    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(["make", "-C", ORC_DIR, "-s"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return so
+    _make("liborc.so")
+    return os.path.join(ORC_DIR, "liborc.so")
 
 
 def _native_lib(name):
     """A -march=native build of oracle/sde_mpc_oracle.c (oracle/Makefile), for bench.py's CPU timing leg only. Rebuilt when missing,
     stale, or built for another CPU model (the GPU box's host is not the build container's)."""
     so = os.path.join(ORC_DIR, name + ".so")
-    src = os.path.join(ORC_DIR, "sde_mpc_oracle.c")
     tag = os.path.join(ORC_DIR, name + ".cpu")
     try:
         here = next(l for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except Exception:
         here = ""
-    stale = (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src) or (not os.path.exists(tag)) or open(tag).read() != here
-    if stale:
-        if os.path.exists(so):
-            os.remove(so)
-        subprocess.check_call(["make", "-C", ORC_DIR, "-s", name + ".so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if os.path.exists(so) and ((not os.path.exists(tag)) or open(tag).read() != here):
+        os.remove(so)                    # built for another CPU model: force the rebuild; staleness otherwise is make's business
+    _make(name + ".so")
     return C.CDLL(so)
 
 

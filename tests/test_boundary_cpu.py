@@ -88,9 +88,12 @@ def test_prefork_shape_probe_touches_no_device(monkeypatch):
     st = reset_c(x=x0, rng=rng, xdes=x0)
     st.yk.block_until_ready()
     mpc_c = jax_shim.jit(m_mpc).lower(x0, rng, st, curr_t=0.01, xdes=x0).compile()
-    uopt, st2, rng2, xevol = mpc_c(x0, rng, st, curr_t=0.01, xdes=x0)
+    with pytest.warns(RuntimeWarning, match="SHAPE PROBE"):               # loud: an in-process user must not mistake it for a solve
+        uopt, st2, rng2, xevol = mpc_c(x0, rng, st, curr_t=0.01, xdes=x0)
     uopt.block_until_ready()
-    assert np.array(uopt).shape == (20, 4) and xevol.shape == (21, 13) and st2 is st
+    assert np.array(uopt).shape == (20, 4) and xevol.shape == (21, 13)
+    assert float(st2.num_steps) == 0.0 and np.isnan(float(st2.opt_cost)) and np.isnan(float(st2.init_cost))     # marked as unsolved
+    np.testing.assert_array_equal(np.array(st2.yk), np.array(st.yk))
     assert prob._solver is None                                           # nothing touched the GPU library
     if not _has_gpu():
         with pytest.raises(SdempcError, match="no HIP device|HIP"):      # second call: the real path, no CPU fallback

@@ -98,7 +98,8 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(_abi.EXPORTED_SYMBOLS)
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.sdempc_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "sdempc.h")).read()
+    assert lib.sdempc_abi_version() == _abi.ABI_VERSION == int(re.search(r"#define SDEMPC_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_handle_lifecycle_and_errors_without_gpu():
@@ -150,6 +151,46 @@ def test_handle_lifecycle_and_errors_without_gpu():
     corrupted[0] ^= 0xFF
     cb = C.create_string_buffer(bytes(corrupted), len(corrupted))
     assert lib.sdempc_create(C.byref(cfg), cb, len(blob), 1, C.byref(h2)) == -2
+
+
+def test_no_exception_crosses_the_c_abi():
+    """include/sdempc.h promises "never aborts or throws" (an exception would end the reference's mpc_process silently,
+    sde_control.py:365-419): arguments that make the host tables unallocatable come back as a code with a message."""
+    lib = _abi.load_library()
+    cfg_py = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml"))
+    blob = synthetic_iris().to_blob()
+    buf = C.create_string_buffer(blob, len(blob))
+    h = C.c_void_p()
+    # the largest horizon the LDS check lets through, the largest batch an int32 can name: creation itself is host-only and must succeed
+    # or fail with a code; the first device call then has to refuse the workspace (no GPU here: EDEVICE either way), never crash
+    cl, keep = cfg_py.replace(horizon=450, num_short_dt=450).to_cfg()
+    rc = lib.sdempc_create(C.byref(cl), buf, len(blob), 2**31 - 1, C.byref(h))
+    assert rc in (0, -4), (rc, lib.sdempc_last_error(None))
+    if rc == 0:
+        fp = C.POINTER(C.c_float)
+        dummy = np.zeros(8, np.float32).ctypes.data_as(fp)
+        assert lib.sdempc_rollout_batch(h, 1, dummy, dummy, dummy, dummy, dummy, None, None) in (-3, -4)
+        assert lib.sdempc_last_error(h)
+        lib.sdempc_destroy(h)
+    # a momentum table of 2^31 + 1 entries: std::length_error / bad_alloc inside the library -> SDEMPC_EINVAL / SDEMPC_ENOMEM, not a crash
+    for max_iter in (2**31 - 1, 2**31 - 2, 10**7 + 1):
+        bad = _abi.SdempcCfg.from_buffer_copy(cl)
+        bad.max_iter = max_iter
+        h2 = C.c_void_p()
+        rc = lib.sdempc_create(C.byref(bad), buf, len(blob), 1, C.byref(h2))
+        assert rc in (-1, -4) and not h2.value, (max_iter, rc)
+        assert lib.sdempc_last_error(None)
+    # 10^7 iterations is the documented limit and must still be accepted (40 MB of momentum table)
+    ok = _abi.SdempcCfg.from_buffer_copy(cl)
+    ok.max_iter = 10**7
+    h3 = C.c_void_p()
+    assert lib.sdempc_create(C.byref(ok), buf, len(blob), 1, C.byref(h3)) == 0
+    lib.sdempc_destroy(h3)
+    # the guard is in every entry point: the source has no extern "C" function returning a code whose body is not inside guarded()
+    src = open(os.path.join(ROOT, "sde4mbrl_px4_amd", "csrc", "sdempc_api.cpp")).read()
+    bodies = re.findall(r"\n(?:int|int32_t) (sdempc_\w+)\([^{]*\{\n(.*?)\n", src, re.S)
+    unguarded = [n for n, first in bodies if "guarded(" not in first and n not in ("sdempc_abi_version", "sdempc_device_ready", "sdempc_layout_fallbacks")]
+    assert not unguarded, unguarded
 
 
 def test_no_cpu_fallback_compute_fails_loudly_without_gpu():

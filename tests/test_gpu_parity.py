@@ -373,47 +373,79 @@ def test_c5_long_horizon_shape_runs():
     S.close()
 
 
-# ---- fp16-operand MLP mode (SPEC.md §9, BASELINE config C5): tolerance parity -------------------------------
-# v_mfma_f32_32x32x16_f16 accumulates its 16 exact products in a hardware-specific order (tools/mfma_f16_probe.hip),
-# so this mode is compared with the oracle's emulation (same RTZ quantisation, sequential f32 accumulation) within
-# tolerances instead of bit for bit.
-def test_f16_mode_matches_oracle_emulation():
-    cfg = MPCConfig(horizon=24, num_short_dt=24, num_particles=70, u_slew_coeff=1.0, max_iter=8, max_no_improvement_iter=8, mlp_dtype="f16")
-    model = synthetic_iris()
-    B = 4
-    x0, xref, noise, u = _problem(cfg, B, seed=61)
-    S, O = _solver(cfg, model, B), orc.Oracle(cfg, model)
+# ---- the matrix-pipe modes: fp16 operands (SPEC.md §9, BASELINE config C5) and the three-limb bf16 split (§9b) ----------------------
+# v_mfma_f32_32x32x16_{f16,bf16} accumulate their 16 products in a hardware-specific way that the oracle models exactly (SPEC.md §9a,
+# oracle/mfma16_model.c, fitted to 7.0 million hardware experiments): both modes are compared with the oracle BIT FOR BIT, like the f32 path.
+def _check_bit_exact(cfg, model, B, seed, **options):
+    x0, xref, noise, u = _problem(cfg, B, seed=seed)
+    S, O = _solver(cfg, model, B, **options), orc.Oracle(cfg, model)
     cost, traj, xmean = S.rollout(x0, u, xref, noise, True, True)
-    cost_again, _, _ = S.rollout(x0, u, xref, noise, False, False)
-    assert bits_differ(cost, cost_again) == 0                            # deterministic
     gc, grad = S.grad(x0, u, xref, noise)
-    assert bits_differ(gc, cost) == 0
     u0 = np.tile(np.asarray(cfg.uref, np.float32), (B, cfg.horizon, 1))
-    uopt, xevol, info = S.solve(x0, xref, noise, u0, np.full(B, 0.01, np.float32))
+    s0 = np.full(B, 0.01, np.float32)
+    uopt, xevol, info = S.solve(x0, xref, noise, u0, s0)
     assert uopt.min() >= 1e-4 and uopt.max() <= 1.0 and np.all(info[:, 6] <= info[:, 5])
     for b in range(B):
         c, t, xm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True)
-        np.testing.assert_allclose(cost[b], c, rtol=2e-6)
-        np.testing.assert_allclose(traj[b], t, rtol=1e-4, atol=2e-5)
-        np.testing.assert_allclose(xmean[b], xm, rtol=1e-4, atol=2e-5)
+        _close(cost[b], c, "cost")
+        assert cost[b] == np.float32(c) and bits_differ(traj[b], t) == 0 and bits_differ(xmean[b], xm) == 0, ("rollout", b)
         c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
-        np.testing.assert_allclose(grad[b], g2, rtol=1e-4, atol=1e-5 * np.abs(g2).max())
-        uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u0[b], 0.01)
-        np.testing.assert_allclose(info[b, 5], inf[5], rtol=2e-6)        # initial cost
-        np.testing.assert_allclose(info[b, 6], inf[6], rtol=1e-3)        # optimised cost (decisions may differ by rounding)
+        assert gc[b] == np.float32(c2) and bits_differ(grad[b], g2.astype(np.float32)) == 0, ("grad", b)
+        uo, xe, io, _ = O.solve(x0[b], xref[b], noise[b], u0[b], 0.01)
+        _close(uopt[b], uo, "uopt")
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0, ("solve", b)
     S.close()
+    return cost
+
+
+@pytest.mark.parametrize("mlp", ["f16", "f32x3"])
+@pytest.mark.parametrize("H,P,m,opts", [
+    (24, 70, 4, dict()),                       # three groups: a duo pair without a group B; small batch -> packed-tanh / latency instantiation is f32-only, tile layout here
+    (12, 128, 4, dict(pk=0)),                  # C2 geometry: TeamPair duo throughput instantiation
+    (12, 128, 4, dict(pk=0, duo=0)),           # one group per wave
+    (9, 33, 6, dict(pk=0)),                    # six rotors, ragged second group
+    (7, 300, 4, dict(pk=0, ustg=1)),           # ten groups on four waves, control table in global memory
+    (16, 32, 4, dict()),                       # one group: one wave per instance (TeamWave)
+])
+def test_matrix_pipe_modes_match_oracle_bit_for_bit(mlp, H, P, m, opts):
+    kw = dict(horizon=H, num_short_dt=max(1, H // 2), long_step_dt=0.1, num_particles=P, u_slew_coeff=1.0, max_iter=6, max_no_improvement_iter=6, mlp_dtype=mlp)
+    if m != 4:
+        kw.update(input_id=list(range(m)), input_bound=[[1e-4, 1.0]] * m, uref=[0.42] * m)
+    cfg = MPCConfig(**kw)
+    model = synthetic_iris() if m == 4 else synthetic_hexa()
+    cost = _check_bit_exact(cfg, model, 3, 61, coop=0, **opts)
+    # and genuinely another arithmetic than the f32 chain (f16: always; f32x3: in the last bits of most rollouts)
+    if mlp == "f16":
+        x0, xref, noise, u = _problem(cfg, 3, seed=61)
+        S32 = _solver(cfg.replace(mlp_dtype="f32"), model, 3, coop=0, **opts)
+        c32, _, _ = S32.rollout(x0, u, xref, noise)
+        S32.close()
+        assert bits_differ(cost, c32) > 0
+
+
+def test_f32x3_differs_from_the_f32_chain_in_the_last_bits_only():
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml"))
+    model = synthetic_iris()
+    x0, xref, noise, u = _problem(cfg, 2, seed=9)
+    out = {}
+    for mlp in ("f32", "f32x3"):
+        S = _solver(cfg.replace(mlp_dtype=mlp), model, 2, coop=0, pk=0)
+        out[mlp] = S.rollout(x0, u, xref, noise, True, True)
+        S.close()
+    assert bits_differ(out["f32"][1], out["f32x3"][1]) > 0
+    np.testing.assert_allclose(out["f32x3"][1], out["f32"][1], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["f32x3"][0], out["f32"][0], rtol=1e-6)
 
 
 def test_c5_f16_mlp_path():
-    """BASELINE config C5: H=200, P=1024 with the fp16 drift-MLP MFMA path; gradient against the oracle emulation."""
+    """BASELINE config C5: H=200, P=1024 with the fp16 drift-MLP MFMA path; cost and gradient against the oracle, bit for bit."""
     cfg = load_mpc_config(os.path.join(CDIR, "c5_iris_traj_h200_p1024.yaml")).replace(mlp_dtype="f16")
     model = synthetic_iris()
     x0, xref, noise, u = _problem(cfg, 1, seed=78)
     S, O = _solver(cfg, model, 1), orc.Oracle(cfg, model)
     gc, grad = S.grad(x0, u, xref, noise)
     c2, g2 = O.grad(x0[0], u[0], xref[0], noise[0])
-    np.testing.assert_allclose(gc[0], c2, rtol=1e-5)
-    np.testing.assert_allclose(grad[0], g2, rtol=1e-3, atol=1e-4 * np.abs(g2).max())
+    assert gc[0] == np.float32(c2) and bits_differ(grad[0], g2.astype(np.float32)) == 0
     S.close()
 
 
@@ -620,7 +652,8 @@ def _full_size_case(cfg_name, B, iters, mlp="f32", sample=(0, 1), seed=0, stepsi
     assert S.get_option("device_cus") < B                                 # grid > CUs: the throughput instantiation ran
     kname = S.last_kernel_name()
     ns = "exact" if math == "exact" else "fastm"
-    assert kname.startswith(f"sdempc::{ns}::sdempc_solve_kernel<sdempc::{ns}::Team") and (", true, " in kname) == (mlp == "f16"), kname
+    mode = {"f32": 0, "f16": 1, "f32x3": 2}[mlp]
+    assert kname.startswith(f"sdempc::{ns}::sdempc_solve_kernel<sdempc::{ns}::Team") and f", {cfg.num_motors}, {mode}, false" in kname, kname
     if P > 32:                                                            # scalar-tanh (throughput) instantiation of the duo layout: MODE 3 (noise
         assert ", false, 3, " in kname or ", false, 4, " in kname, kname  # through LDS staging rows) or, when LDS has no room for them (C5), MODE 4
     assert np.all(info[:, 2] == iters) and np.all(info[:, 6] <= info[:, 5]) and uopt.min() >= 1e-4 and uopt.max() <= 1.0
@@ -687,23 +720,28 @@ def test_ticketed_persistent_launch_matches_striped_launches_bit_for_bit():
     S.close()
 
 
-def test_c5_full_size_solve_f32_bit_exact_and_f16_within_tolerance():
-    """BASELINE config C5 (H=200, P=1024: 32 particle groups per instance, control table in global memory) as a SOLVE at full size, B > CUs:
-    f32 bit for bit against the oracle; fp16-operand MLP mode (the mode C5 names) against the oracle's emulation within the north star's
-    1e-4 on the controls (few iterations: the decisions coincide; drift over full-length solves: DESIGN.md §2, tools/mode_drift.py).
+@pytest.mark.parametrize("mlp", ["f32", "f16", "f32x3"])
+def test_c5_full_size_solve_bit_exact(mlp):
+    """BASELINE config C5 (H=200, P=1024: 32 particle groups per instance, control table in global memory) as a SOLVE at full size, B > CUs,
+    bit for bit against the oracle in all three contraction modes — f32, the fp16-operand MLP mode C5 names (SPEC.md §9), and the three-limb
+    bf16 split (§9b); the two matrix-pipe modes through the oracle's model of the instruction (§9a).
     The 10 s open-loop horizon from a random initial state is violently ill-conditioned (|g|^2 ~ 1e16): the solve starts from a step size of
     1e-11 so that its three iterations all take steps (from the YAML's 0.01 the line search only shrinks the step for the first dozens)."""
-    kw = dict(sample=(259,), stepsize=1e-11)
-    uopt, xevol, info, res = _full_size_case("c5_iris_traj_h200_p1024.yaml", 260, 3, **kw)
+    uopt, xevol, info, res = _full_size_case("c5_iris_traj_h200_p1024.yaml", 260, 3, mlp=mlp, sample=(259,), stepsize=1e-11)
     for b, (uo, xe, io) in res:
         assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0
     assert info[259, 6] < 0.7 * info[259, 5] and np.abs(uopt[259] - 0.71).max() > 1e-4      # the iterations moved the controls
-    uh, xh, ih, resh = _full_size_case("c5_iris_traj_h200_p1024.yaml", 260, 3, mlp="f16", **kw)
-    for b, (uo, xe, io) in resh:
-        np.testing.assert_allclose(uh[b], uo, rtol=RTOL, atol=1e-6)
-        np.testing.assert_allclose(ih[b, 5:7], io[5:7], rtol=2e-5)
-        assert ih[b, 7] == io[7]                                          # same line-search decisions
-    assert bits_differ(uh[259], uopt[259]) > 0                            # and genuinely another arithmetic than f32
+
+
+@pytest.mark.parametrize("cfg_name,B,iters,sample", [
+    ("c2_iris_traj_h50_p128.yaml", 512, 10, (0, 257, 511)),                     # C2: the bench workload in the f32x3 mode bench.py reports
+    ("c3_hexa_traj_h50_p256.yaml", 320, 4, (319,)),
+])
+def test_baseline_configs_full_size_f32x3_bit_exact(cfg_name, B, iters, sample):
+    uopt, xevol, info, res = _full_size_case(cfg_name, B, iters, mlp="f32x3", sample=sample)
+    for b, (uo, xe, io) in res:
+        _close(uopt[b], uo, "uopt")
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0, b
 
 
 # ---- duo tile layout (64 particles per wave) against the one-group-per-wave layout and the oracle -------------------------------------

@@ -13,7 +13,7 @@ ap.add_argument("--max-iter", type=int, default=0)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--mode", default="solve", choices=["solve", "rollout", "grad"])
 ap.add_argument("--math-mode", default="exact", choices=["exact", "fast"])
-ap.add_argument("--mlp-dtype", default="f32", choices=["f32", "f16"])
+ap.add_argument("--mlp-dtype", default="f32", choices=["f32", "f16", "f32x3"])
 a = ap.parse_args()
 cfg = load_mpc_config(a.config).replace(math_mode=a.math_mode, mlp_dtype=a.mlp_dtype)
 if a.max_iter: cfg = cfg.replace(max_iter=a.max_iter, max_no_improvement_iter=a.max_iter)

@@ -75,32 +75,19 @@ def cpu_oracle():
     return orc
 
 
-def cpu_solve_instances(cfg, model, n_threads, x0, xref, keys, u0, s0, fast=False):
-    """CPU leg, kind 'port': the C oracle (CPU restatement of SPEC.md) solves the given instances — the first ones of the GPU
-    batch, noise derived from the same threefry keys — one solve at a time per thread, all usable host cores. fast=False: the
-    bit-exact -O2 build the parity tests use (its outputs are what the GPU results are compared with); fast=True: the same source
-    built as the particle-vectorised timing build (oracle/Makefile: liborc_vec.so, 16 particles per call through GCC vector
-    extensions, -O3 -march=native, contraction allowed: tolerance parity), the credible CPU timing. Returns (solves/s, wall s, outputs)."""
+def cpu_solve_instances(cfg, model, n_threads, x0, xref, keys, u0, s0, fast=False, native=False):
+    """CPU leg, kind 'port': the C oracle (CPU restatement of SPEC.md) solves the given instances — instances of the GPU batch, noise
+    derived from the same threefry keys — one solve at a time per thread. fast=False: the bit-exact checker (what the GPU results are
+    compared with; native=True takes its -O3 -march=native build, same source and same bits); fast=True: the same source built as the
+    particle-vectorised timing build (oracle/Makefile: liborc_vec.so, 16 particles per call through GCC vector extensions, contraction
+    allowed: tolerance parity), the credible CPU timing. Returns (solves/s, wall s, outputs)."""
     orc = cpu_oracle()
     n = len(x0)
-    O = [orc.Oracle(cfg, model, vec=fast) for _ in range(n_threads)]
+    O = [orc.Oracle(cfg, model, vec=fast, fast=native and not fast) for _ in range(n_threads)]
     P, H = cfg.num_particles, cfg.horizon
-    noise = [None] * n
     out = [None] * n
     nxt = [0]
     lock = threading.Lock()
-
-    def draw(i):
-        while True:
-            with lock:
-                j = nxt[0]; nxt[0] += 1
-            if j >= n:
-                return
-            noise[j] = orc.noise_from_key(keys[j], P, H)
-
-    th = [threading.Thread(target=draw, args=(i,)) for i in range(n_threads)]
-    [t.start() for t in th]; [t.join() for t in th]
-    nxt[0] = 0
 
     def work(i):
         while True:
@@ -108,13 +95,81 @@ def cpu_solve_instances(cfg, model, n_threads, x0, xref, keys, u0, s0, fast=Fals
                 j = nxt[0]; nxt[0] += 1
             if j >= n:
                 return
-            out[j] = O[i].solve(x0[j], xref[j], noise[j], u0[j], s0)[:3]
+            noise = orc.noise_from_key(keys[j], P, H)
+            out[j] = O[i].solve(x0[j], xref[j], noise, u0[j], s0)[:3]
 
     t0 = time.time()
     th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
     [t.start() for t in th]; [t.join() for t in th]
     dt = time.time() - t0
     return n / dt, dt, out
+
+
+class Verifier:
+    """Background checker of timed launches: worker threads solve sampled instances with the CPU oracle (ctypes releases the GIL) while
+    the main thread goes on with the GPU legs; results are collected at the end. Test infrastructure on the checker side only."""
+
+    def __init__(self, n_threads):
+        self.jobs, self.results, self.lock = [], {}, threading.Lock()
+        self.n_threads, self.threads, self.t0 = max(1, n_threads), [], None
+
+    def add(self, leg, cfg, blob, idx, x0, xref, keys, u0, s0, got):
+        """got: (uopt, xevol, info) host arrays of the WHOLE batch; idx: instances to check"""
+        for i in idx:
+            self.jobs.append((leg, cfg, blob, int(i), x0[i], xref[i], keys[i], u0[i], s0, got[0][i].copy(), got[1][i].copy(), got[2][i].copy()))
+        self.results.setdefault(leg, {"idx": [int(i) for i in idx], "bad_words": 0, "done": 0, "cpu_s": 0.0})
+
+    def start(self):
+        orc = cpu_oracle()
+        self.t0 = time.time()
+        jobs = list(self.jobs)
+        nxt = [0]
+        oracles = {}
+
+        def work(tid):
+            while True:
+                with self.lock:
+                    j = nxt[0]; nxt[0] += 1
+                if j >= len(jobs):
+                    return
+                leg, cfg, blob, i, x0, xref, key, u0, s0, gu, gx, gi = jobs[j]
+                with self.lock:
+                    O = oracles.get((tid, leg))
+                if O is None:
+                    O = orc.Oracle(cfg, blob)                  # the bit-exact checker build the parity tests use
+                    with self.lock:
+                        oracles[(tid, leg)] = O
+                t = time.time()
+                noise = orc.noise_from_key(key, cfg.num_particles, cfg.horizon)
+                uo, xe, io = O.solve(x0, xref, noise, u0, s0)[:3]
+                bad = words_differ(gu, uo) + words_differ(gx, xe) + words_differ(gi, io)
+                with self.lock:
+                    r = self.results[leg]; r["bad_words"] += bad; r["done"] += 1; r["cpu_s"] += time.time() - t
+
+        self.threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(self.n_threads)]
+        [t.start() for t in self.threads]
+
+    def join(self):
+        [t.join() for t in self.threads]
+        return time.time() - self.t0 if self.t0 else 0.0
+
+
+def sample_indices(B, slots, n_initial=4, n_drawn=6):
+    """Instances of a launch to verify: some of the teams' initial assignments, some that a persistent launch hands out by ticket
+    (b >= slots; evenly spread), and the last one."""
+    idx = list(range(min(n_initial, B)))
+    if B > slots + 1:
+        idx += [int(v) for v in np.linspace(slots, B - 2, n_drawn)]
+    if B - 1 not in idx:
+        idx.append(B - 1)
+    return sorted(set(idx))
+
+
+def lib_hash():
+    """sha256 (first 16 hex digits) of the library the solver loaded: ties profiles/pmc_traffic.json to the build it was measured on"""
+    import hashlib
+    from sde4mbrl_px4_amd import _abi
+    return hashlib.sha256(open(_abi.lib_path(), "rb").read()).hexdigest()[:16]
 
 
 def words_differ(a, b):
@@ -188,6 +243,84 @@ def spawn_ranks(n, argv):
     return failed or max(abs(rc) for rc in rcs)
 
 
+DEFAULT_MLP = "f32x3"      # the reported arithmetic: f32 operands and accumulation, layer-2 contractions as three-limb bf16 splits (SPEC.md 9b)
+
+DTYPE_NOTE = {
+    "f32": "f32",
+    "f32x3": "f32 (state, accumulation and every operand f32; the two 32x32 MLP contractions per step evaluated as three-limb bf16 splits of "
+             "both f32 operands on v_mfma_f32_32x32x16_bf16: error against float64 not larger than the f32 fma chain's, bit-identical to the CPU oracle)",
+    "f16": "f16 MLP operands / f32 accumulate and state",
+}
+
+
+class Leg:
+    """One workload on this rank's GPU: solver + device-resident inputs and outputs."""
+
+    def __init__(self, cfg, blob, B, dev_ord, rank=0, world=1, pos=False):
+        import torch
+        from sde4mbrl_px4_amd import prng
+        from sde4mbrl_px4_amd import workload as W
+        from sde4mbrl_px4_amd.solver import SdeMpcSolver
+        self.cfg, self.blob, self.B = cfg, blob, B
+        H, P, m = cfg.horizon, cfg.num_particles, cfg.num_motors
+        dev = torch.device("cuda", dev_ord)
+        self.solver = SdeMpcSolver(cfg, blob, max_batch=B, device=dev_ord)
+        self.x0_h = W.random_initial_states(B, rank * B)
+        self.xref_h = np.stack([W.constant_reference(W.HOVER, H) if pos else W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(B)])
+        # noise: drawn on the device from per-instance threefry keys (SPEC.md 7; the m_mpc path), launch seed 10 (iris_sdectrl.launch:8)
+        self.keys = prng.split(prng.PRNGKey(10), world * B)[rank * B:(rank + 1) * B]
+        yk, info0 = self.solver.reset()
+        self.u0_h = np.tile(yk[None], (B, 1, 1))
+        self.s0 = float(info0["stepsize"])
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.x0 = torch.from_numpy(self.x0_h).to(dev)
+        self.xref = torch.from_numpy(self.xref_h).to(dev)
+        self.noise = torch.empty(self.solver.lib.sdempc_noise_dev_floats(self.solver._h, B), dtype=torch.float32, device=dev)
+        self.solver.noise_from_keys_dev(self.keys, self.noise.data_ptr(), self.stream)
+        self.u0 = torch.from_numpy(self.u0_h).to(dev)
+        self.step_in = torch.full((B,), self.s0, dtype=torch.float32, device=dev)
+        self.uopt = torch.empty((B, H, m), dtype=torch.float32, device=dev)
+        self.xevol = torch.empty((B, H + 1, 13), dtype=torch.float32, device=dev)
+        self.info = torch.empty((B, 8), dtype=torch.float32, device=dev)
+
+    def step(self, solver=None, out=None):
+        u, x, i = out or (self.uopt, self.xevol, self.info)
+        (solver or self.solver).solve_dev(self.B, self.x0.data_ptr(), self.xref.data_ptr(), self.noise.data_ptr(), self.u0.data_ptr(),
+                                          self.step_in.data_ptr(), u.data_ptr(), x.data_ptr(), i.data_ptr(), self.stream)
+
+    def timed_events(self, reps):
+        """reps launches timed one by one with HIP events on the launch stream; returns (ms list, work counters per solve)"""
+        import torch
+        torch.cuda.synchronize()
+        self.solver.work_counters(reset=True)
+        ms = []
+        for _ in range(reps):
+            self.step()
+            ms.append(self.solver.last_kernel_ms())
+        torch.cuda.synchronize()
+        self.solver.solve_status()
+        w_solves, w_grads, w_fwd = self.solver.work_counters()
+        if w_solves != self.B * reps:
+            raise SystemExit(f"bench.py: {w_solves} solves counted on the device for {reps} launches of {self.B} instances")
+        return ms, w_grads / max(w_solves, 1), w_fwd / max(w_solves, 1)
+
+    def host_outputs(self):
+        return self.uopt.cpu().numpy(), self.xevol.cpu().numpy(), self.info.cpu().numpy()
+
+    def slots(self):
+        return 6 * self.solver.get_option("device_cus")
+
+    def close(self):
+        self.solver.close()
+
+
+def roofline_of(cfg, B, k_ms, n_grad, n_fwd, kernel_name):
+    bytes_solve, flops_solve, b_grad, b_ls = algorithmic_counts(cfg, n_grad, n_fwd - 2)
+    ach_gbs = bytes_solve * B / (k_ms * 1e-3) / 1e9
+    ach_tf = flops_solve * B / (k_ms * 1e-3) / 1e12
+    return ach_tf, ach_gbs, bytes_solve, b_grad, b_ls
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,12 +333,14 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--latency-reps", type=int, default=1000)
     ap.add_argument("--latency-warmup", type=int, default=20)
-    ap.add_argument("--mlp-dtype", default="f32", choices=["f32", "f16"],
-                    help="f32: bit-reproducible path (default, the reported metric); f16: fp16-operand MLP contractions (SPEC.md 9)")
+    ap.add_argument("--mlp-dtype", default=DEFAULT_MLP, choices=["f32", "f16", "f32x3"],
+                    help="f32x3 (default, the reported metric): f32 arithmetic with the layer-2 contractions as three-limb bf16 splits on the matrix pipe "
+                         "(SPEC.md 9b), bit-identical to the oracle; f32: every contraction an f32 fma chain; f16: fp16-operand MLP contractions (SPEC.md 9)")
     ap.add_argument("--max-iter", type=int, default=0, help="override the YAML's apg_mpc.max_iter (0: keep; profiling runs of the long-horizon config)")
-    ap.add_argument("--no-tolerance-modes", action="store_true", help="skip the extra launches in the tolerance-parity modes (math_mode: fast, mlp_dtype: f16)")
+    ap.add_argument("--no-tolerance-modes", action="store_true", help="skip the extra launches in the tolerance-parity mode (math_mode: fast)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary legs (C2 f32 chain, C3, C5 f32 / f16)")
     ap.add_argument("--verify", type=int, default=-1, help="instances of the timed launch checked bit for bit against the CPU oracle "
-                    "(-1: as many as the cpu_baseline leg solves, or 4 with --no-cpu-baseline; 0: none)")
+                    "(-1: a sample across the batch incl. ticket-drawn instances; 0: none)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -215,8 +350,6 @@ def main():
     import torch
     import torch.distributed as dist
     from sde4mbrl_px4_amd import load_mpc_config, synthetic_hexa, synthetic_iris
-    from sde4mbrl_px4_amd import workload as W
-    from sde4mbrl_px4_amd.solver import SdeMpcSolver
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,214 +358,192 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    # test hooks (single-GPU boxes): SDEMPC_BENCH_DEVICE pins every rank to one ordinal, SDEMPC_BENCH_BACKEND=gloo
-    # replaces RCCL; the driver's multi-GPU runs use neither (one GPU per rank, backend nccl = RCCL over xGMI)
+    # test hooks (single-GPU boxes): SDEMPC_BENCH_DEVICE pins every rank to one ordinal, SDEMPC_BENCH_BACKEND=gloo replaces RCCL,
+    # SDEMPC_BENCH_FORCE_DIST=1 initialises the process group even for one rank (the RCCL branch — init, device-tensor broadcast, all-reduce,
+    # barrier, destroy — then runs on a one-GPU box); the driver's multi-GPU runs use none of them (one GPU per rank, backend nccl = RCCL over xGMI)
     dev_ord = int(os.environ.get("SDEMPC_BENCH_DEVICE", local_rank))
     backend = os.environ.get("SDEMPC_BENCH_BACKEND", "nccl")
+    force_dist = os.environ.get("SDEMPC_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(dev_ord)
     dev = torch.device("cuda", dev_ord)
-    if world > 1:
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    cfg = load_mpc_config(args.config).replace(mlp_dtype=args.mlp_dtype)
+    def cfg_of(path, mlp, **kw):
+        return load_mpc_config(path).replace(mlp_dtype=mlp, **kw)
+
+    cfg = cfg_of(args.config, args.mlp_dtype)
     if args.max_iter:
         cfg = cfg.replace(max_iter=args.max_iter, max_no_improvement_iter=args.max_iter)
     H, P, m, B = cfg.horizon, cfg.num_particles, cfg.num_motors, args.batch
     # shared model: rank 0 builds it, RCCL broadcast over xGMI (read-only weights are the only shared data)
     from sde4mbrl_px4_amd.dist import broadcast_blob, max_over_ranks
     blob = (synthetic_iris() if m == 4 else synthetic_hexa()).to_blob() if rank == 0 else b""
-    blob = broadcast_blob(blob, src=0, device=dev)
+    blob = broadcast_blob(blob, src=0, device=dev, force=force_dist)
 
-    solver = SdeMpcSolver(cfg, blob, max_batch=B, device=dev_ord)
-    # synthetic inputs, distinct per rank, resident in HBM before timing
-    seed0 = rank * B
-    x0_h = W.random_initial_states(B, seed0)
-    xref_h = np.stack([W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(B)])
-    # noise: drawn on the device from per-instance threefry keys (SPEC.md §7; the m_mpc path), launch seed 10
-    # (iris_sdectrl.launch:8) split into one key per instance of the whole job
-    from sde4mbrl_px4_amd import prng
-    keys = prng.split(prng.PRNGKey(10), world * B)[rank * B:(rank + 1) * B]
-    nd = solver.lib.sdempc_noise_dev_floats(solver._h, B)
-    yk, info0 = solver.reset()
-    u0_h = np.tile(yk[None], (B, 1, 1))
-    s0 = float(info0["stepsize"])
-    x0 = torch.from_numpy(x0_h).to(dev)
-    xref = torch.from_numpy(xref_h).to(dev)
-    noise = torch.empty(nd, dtype=torch.float32, device=dev)
-    solver.noise_from_keys_dev(keys, noise.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    u0 = torch.from_numpy(u0_h).to(dev)
-    step_in = torch.full((B,), s0, dtype=torch.float32, device=dev)
-    uopt = torch.empty((B, H, m), dtype=torch.float32, device=dev)
-    xevol = torch.empty((B, H + 1, 13), dtype=torch.float32, device=dev)
-    info = torch.empty((B, 8), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        solver.solve_dev(B, x0.data_ptr(), xref.data_ptr(), noise.data_ptr(), u0.data_ptr(), step_in.data_ptr(),
-                         uopt.data_ptr(), xevol.data_ptr(), info.data_ptr(), stream)
+    L = Leg(cfg, blob, B, dev_ord, rank, world, pos="posctrl" in os.path.basename(args.config))
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        L.step()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        L.step()
     sync_all()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    elapsed = max_over_ranks(elapsed, device=dev)
+    elapsed = max_over_ranks(t1 - t0, device=dev, force=force_dist)
     # per-launch kernel duration from HIP events, measured live on the launch stream (separate launches)
-    ev_ms = []
-    torch.cuda.synchronize()
-    solver.work_counters(reset=True)
-    for _ in range(min(args.steps, 3)):
-        step()
-        ev_ms.append(solver.last_kernel_ms())
-    torch.cuda.synchronize()
-    w_solves, w_grads, w_fwd = solver.work_counters()
-    if w_solves != B * len(ev_ms):
-        raise SystemExit(f"bench.py: {w_solves} solves counted on the device for {len(ev_ms)} launches of {B} instances")
-    kernel_name = solver.last_kernel_name()       # the instantiation the timed launches ran, as rocprofv3 names it
-    info_h = info.cpu().numpy()
+    ev_ms, n_grad, n_fwd = L.timed_events(min(args.steps, 3))
+    kernel_name = L.solver.last_kernel_name()       # the instantiation the timed launches ran, as rocprofv3 names it
+    uopt_h, xevol_h, info_h = L.host_outputs()        # outputs of the timed configuration (same inputs, deterministic kernel)
     n_it = float(info_h[:, 2].mean())
     n_ls = float(info_h[:, 7].mean())
-    # work actually performed per solve (sdempc_work_counters): an iteration whose extrapolation point did not move re-uses its
-    # gradient, so fewer gradients are evaluated than iterations are counted; the roofline counts only what was evaluated
-    n_grad = w_grads / max(w_solves, 1)
-    n_fwd = w_fwd / max(w_solves, 1)            # line-search trials + initial-cost + final mean-trajectory rollouts
-
-    # outputs of the timed configuration (last launch: same inputs, deterministic kernel), kept for the verification below
-    uopt_h, xevol_h = uopt.cpu().numpy(), xevol.cpu().numpy()
 
     if rank == 0:
         solves = world * B * args.steps
         value = solves / elapsed
-        bytes_solve, flops_solve, b_grad, b_ls = algorithmic_counts(cfg, n_grad, n_fwd - 2)
         k_ms = float(np.mean(ev_ms))
-        ach_gbs = bytes_solve * B / (k_ms * 1e-3) / 1e9
-        ach_tf = flops_solve * B / (k_ms * 1e-3) / 1e12
+        ach_tf, ach_gbs, bytes_solve, b_grad, b_ls = roofline_of(cfg, B, k_ms, n_grad, n_fwd, kernel_name)
         # HBM bytes per launch from the PMC counters: they need rocprofv3 around the process (separate --pmc passes for FETCH_SIZE and
-        # WRITE_SIZE, MI355X_MICROARCH.md), so the figure comes from the committed summary of those passes for this config and batch
-        # (tools/profile_round.sh -> profiles/pmc_traffic.json, which names its source file); null when none was collected
-        traffic, traffic_src = None, None
+        # WRITE_SIZE, MI355X_MICROARCH.md), so the figure comes from the committed summary of those passes for this config, batch, arithmetic
+        # and BUILD (tools/profile_round.sh -> profiles/pmc_traffic.json records the sha256 of the library it measured): null when the
+        # loaded library is another build than the one the counters were taken on
+        traffic, traffic_src, traffic_build = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        build = lib_hash()
         if os.path.exists(pmc):
             try:
-                rec = json.load(open(pmc)).get(f"{os.path.basename(args.config)}:B{B}", {})
-                traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
+                rec = json.load(open(pmc)).get(f"{os.path.basename(args.config)}:B{B}:{args.mlp_dtype}", {})
+                traffic_build = rec.get("traffic_build")
+                if traffic_build == build:
+                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
+                else:
+                    traffic_src = f"stale: counters were taken on build {traffic_build}, this run loaded {build}"
             except Exception:
                 traffic, traffic_src = None, None
         # p50 / p95 latency of a single solve (B=1 launches), outside the timed region: SURVEY.md §8(d) protocol, >= 20 warm-up
         # and >= 1000 timed solves by default, one problem instance after the other (host timestamps around a device sync)
         lat = []
-        nv = noise.view(B, -1)
+        nv = L.noise.view(B, -1)
         for r in range(-args.latency_warmup if args.latency_reps > 0 else 0, args.latency_reps):
             i = r % B
             torch.cuda.synchronize()
             t = time.perf_counter()
-            solver.solve_dev(1, x0[i:].data_ptr(), xref[i:].data_ptr(), nv[i:].data_ptr(), u0[i:].data_ptr(), step_in[i:].data_ptr(),
-                             uopt[i:].data_ptr(), xevol[i:].data_ptr(), info[i:].data_ptr(), stream)
+            L.solver.solve_dev(1, L.x0[i:].data_ptr(), L.xref[i:].data_ptr(), nv[i:].data_ptr(), L.u0[i:].data_ptr(), L.step_in[i:].data_ptr(),
+                               L.uopt[i:].data_ptr(), L.xevol[i:].data_ptr(), L.info[i:].data_ptr(), L.stream)
             torch.cuda.synchronize()
             if r >= 0:
                 lat.append((time.perf_counter() - t) * 1e3)
-            solver.solve_status()     # raises if a grid barrier of the cooperative layout gave up (results would be invalid)
+            L.solver.solve_status()     # raises if a grid barrier of the cooperative layout gave up (results would be invalid)
+        single_kernel = L.solver.last_kernel_name() if lat else None
         out = {
             "metric": "MPC solves/sec, Iris H=50 P=128 (p50 solve latency in p50_solve_latency_ms)" if os.path.basename(args.config).startswith("c2_")
                       else f"MPC solves/sec, {os.path.basename(args.config)}",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.mlp_dtype == "f32" else "f16 MLP operands / f32 accumulate and state", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_NOTE[args.mlp_dtype], "mlp_dtype": args.mlp_dtype, "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.config)}: H={H} P={P} m={m}, {B} independent MPC instances per GPU per step, "
                                    f"cold-start solves from the hover guess, max_iter={cfg.max_iter} maxls={cfg.ls_maxls}",
                        "instances_per_gpu": B, "noise": "threefry2x32 keys (seed 10 split per instance), normal draws generated on the device", "N_it_mean": n_it, "N_ls_mean": n_ls, "N_grad_evaluated_mean": n_grad, "N_forward_rollouts_mean": n_fwd, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "p50_solve_latency_ms": float(np.median(lat)) if lat else None,
             "p95_solve_latency_ms": float(np.percentile(lat, 95)) if lat else None,
-            "latency_reps": len(lat), "latency_layout_fallbacks": solver.layout_fallbacks(),
-            "p50_solve_latency_note": "one instance alone on the GPU (B = 1 launch of the same C-ABI entry point): the library spreads it over ceil(P/4) x 7 workgroups "
-                                      "(one particle per wave; three line-search trials and the candidate gradients of the next iteration evaluated at once); bit-identical results",
+            "latency_reps": len(lat), "latency_layout_fallbacks": L.solver.layout_fallbacks(), "latency_kernel": single_kernel,
+            "p50_solve_latency_note": "one instance alone on the GPU (B = 1 launch of the same C-ABI entry point): in the f32 mode the library spreads it over ceil(P/4) x 7 workgroups "
+                                      "(one particle per wave; three line-search trials and the candidate gradients of the next iteration evaluated at once); "
+                                      "the matrix-pipe modes run it in the tile layout on one workgroup; bit-identical to the oracle either way",
             "p50_batch_latency_ms": float(np.median(ev_ms)),
+            "library_build": build,
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name, "kernel_ms": k_ms,
-                         "note": "f32-exact path: MLP contractions on v_mfma_f32_32x32x2_f32 (157.3 TF dense peak = f32 vector peak); "
-                                 "algorithmic flops = SURVEY §8d MLP formula x P*H*(2*N_grad+N_ls+2), N_grad = gradient evaluations actually performed "
-                                 "(sdempc_work_counters; identical re-evaluations at an unchanged point are skipped and not counted)"},
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_build": traffic_build, "kernel": kernel_name, "kernel_ms": k_ms,
+                         "note": "algorithmic flops = SURVEY 8d MLP formula x P*H*(2*N_grad+N_ls+2) (N_grad = gradient evaluations actually performed: sdempc_work_counters), "
+                                 "against the 157.3 TFLOP/s f32 peak (f32 vector peak = f32-input MFMA peak): every operand and every accumulation of the path is f32. "
+                                 "In the f32x3 mode 74 % of those flops (the two 32x32 contractions) are executed as 6 bf16 limb products each on the matrix pipe (2.5 PFLOP/s dense): "
+                                 "the kernel is bound by the f32 vector work beside them (tanh, rigid body, adjoint algebra), not by either matrix peak"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "traffic": traffic, "bytes_per_solve": bytes_solve, "B_grad": b_grad, "B_ls": b_ls,
                              "checkpoint_bytes_per_solve": checkpoint_bytes(cfg, n_grad),
                              "note": "achieved = SURVEY 8d algorithmic bytes / kernel time; measured traffic additionally contains the activation-checkpoint stream"},
         }
-        if args.mlp_dtype == "f16":
-            # BASELINE config 5 names the fp16 drift-MLP MFMA path: flops that run on v_mfma_f32_32x32x16_f16 (layer-1 state inputs of both
-            # nets + layer 2 of the drift net, forward sweeps; the adjoint's layer-1 recompute) against the dense f16 MFMA peak
-            f16_fwd = 2 * (6 * 64 + 32 * 32)
-            f16_l1 = 2 * (6 * 64)
-            f16_flops = (f16_fwd * (n_grad + n_fwd) + f16_l1 * n_grad) * P * H
-            ach16 = f16_flops * B / (k_ms * 1e-3) / 1e12
-            out["roofline_mfma_f16"] = {"bound": "mfma", "achieved": ach16, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach16 / 2500.0,
-                                        "note": "algorithmic flops of the contractions that run on v_mfma_f32_32x32x16_f16 (fp16 operands, f32 accumulate) / kernel time, against "
-                                                "the 2.5 PFLOP/s dense f16 peak: the matrix pipe is nearly idle by design — K = 6 and K = 32 contractions of a 32-wide MLP; the "
-                                                "kernel stays bound by the f32 vector work (tanh, rigid body, adjoint algebra). MFMA busy cycles: profiles/"}
-        # ---- CPU legs (rank 0): verification of the timed launch + the reported CPU baseline ------------------------------------
+        if world > 1:
+            out["cpu_baseline"] = "skipped (n_gpus > 1): reported by the single-GPU run"
+        # ---- verification of the timed launch (background threads) + the secondary legs on the GPU meanwhile -------------------------
         nthr = args.cpu_threads or min(effective_cores(), 64)
-        do_cpu = not args.no_cpu_baseline and world == 1
-        n_ver = args.verify if args.verify >= 0 else (nthr if do_cpu else 4)
-        n_ver = min(n_ver, B)
-        if n_ver > 0 and args.mlp_dtype == "f32":
-            # the SAME instances the GPU solved (first n_ver of rank 0's batch: same x0 / xref / keys / warm start), bit-exact oracle build
-            v_exact, dt_exact, outs = cpu_solve_instances(cfg, blob, min(nthr, n_ver), x0_h[:n_ver], xref_h[:n_ver], keys[:n_ver], u0_h[:n_ver], s0)
-            bad = 0
-            for i, (uo, xe, io) in enumerate(outs):
-                bad += words_differ(uopt_h[i], uo) + words_differ(xevol_h[i], xe) + words_differ(info_h[i], io)
-            out["verified_instances"] = n_ver
-            out["verified_bit_exact"] = bad == 0
-            out["verified_note"] = ("uopt, xevol and the 8 telemetry words of the first %d instances of the timed launch compared bit for bit with the "
-                                    "CPU oracle (oracle/sde_mpc_oracle.c, -O2 build) solving the same instances from the same keys; %d words differ" % (n_ver, bad))
-            if bad:
-                print(json.dumps(out))
-                raise SystemExit(f"bench.py: the timed launch's outputs differ from the oracle in {bad} words")
-        else:
-            out["verified_instances"] = 0
-            out["verified_bit_exact"] = None
-        if do_cpu:
-            # reported baseline: the particle-vectorised build, one solve at a time per thread on every usable core, on 40 instances per
-            # thread of the same workload (first instances of the GPU batch; ~10 s of wall time)
-            n_cpu = min(40 * nthr, B)
-            v, dt, outs_f = cpu_solve_instances(cfg, blob, nthr, x0_h[:n_cpu], xref_h[:n_cpu], keys[:n_cpu], u0_h[:n_cpu], s0, fast=True)
-            dev = np.array([float(np.max(np.abs(outs_f[i][0] - uopt_h[i]))) for i in range(n_cpu)])
-            md, mmed = float(dev.max()), float(np.median(dev))
-            c1, c1cfg = cpu_c1_single_solve_ms(blob)
-            out["cpu_baseline"] = {"value": v, "unit": "solves/s", "cores": nthr, "kind": "port",
-                                   "threads_used": nthr, "os_cpu_count": os.cpu_count(), "usable_cores": effective_cores(),
-                                   "sample": f"{n_cpu} solves of the same workload (the first {n_cpu} instances of the GPU batch, one solve at a time per thread, "
-                                             f"{nthr} threads = usable host cores: os.cpu_count {os.cpu_count()}, cgroup/affinity limit {effective_cores()}; {dt:.1f} s wall) "
-                                             "by the particle-vectorised build of the C oracle (oracle/sde_mpc_oracle.c -DORC_VEC: 16 particles per call, -O3 -march=native, "
-                                             "contraction allowed; CPU restatement of SPEC.md, not the reference JAX path: that cannot run here); "
-                                             f"|uopt - GPU uopt| over the sample (200-iteration solves; timing build, not the checker): median {mmed:.1e}, max {md:.1e}",
-                                   "value_bit_exact_build": (n_ver / dt_exact) if n_ver > 0 and args.mlp_dtype == "f32" else None,
-                                   "cpu_c1_single_solve_ms": c1["vec"][0], "cpu_c1_single_solve_ms_scalar_build": c1["scalar"][0],
-                                   "cpu_c1_note": f"BASELINE config 1: c1_iris_posctrl_h20_p32.yaml H={c1cfg.horizon} P={c1cfg.num_particles}, one cold-start solve "
-                                                  f"(N_it {c1['vec'][1]:.0f}) on ONE thread, median of 3: particle-vectorised build / bit-exact scalar -O2 build"}
-        if world == 1 and args.mlp_dtype == "f32" and cfg.math_mode == "exact" and not args.no_tolerance_modes and os.path.basename(args.config).startswith("c2_"):
-            # The optional tolerance-parity modes on the same instances (a warm-up and a timed launch each: ~20 s in all), never the reported value:
-            # solves/s and how far their controls are from the exact path's (north star: 1e-4). SPEC.md 9 / 10, DESIGN.md 2.
+        V = Verifier(max(1, nthr - 1))
+        if args.verify != 0:
+            idx = sample_indices(B, L.slots()) if args.verify < 0 else list(range(min(args.verify, B)))
+            V.add("main", cfg, blob, idx, L.x0_h, L.xref_h, L.keys, L.u0_h, L.s0, (uopt_h, xevol_h, info_h))
+        others = {}
+        if world == 1 and not args.no_other_configs and os.path.basename(args.config).startswith("c2_") and not args.max_iter:
+            cdir = os.path.join(ROOT, "configs")
+            legs = [("c2_f32_chain", os.path.join(cdir, "c2_iris_traj_h50_p128.yaml"), "f32", B, 2, {}),
+                    ("c3", os.path.join(cdir, "c3_hexa_traj_h50_p256.yaml"), args.mlp_dtype, 6144, 2, {}),
+                    ("c5_f32x3" if args.mlp_dtype == "f32x3" else "c5_f32", os.path.join(cdir, "c5_iris_traj_h200_p1024.yaml"), args.mlp_dtype, 768, 1, {}),
+                    ("c5_f16", os.path.join(cdir, "c5_iris_traj_h200_p1024.yaml"), "f16", 768, 1, {})]
+            if args.mlp_dtype == "f32":
+                legs = legs[1:]
+            iris_blob, hexa_blob = synthetic_iris().to_blob(), synthetic_hexa().to_blob()
+            for name, path, mlp, Bl, reps, kw in legs:
+                c2 = cfg_of(path, mlp, **kw)
+                bl = iris_blob if c2.num_motors == 4 else hexa_blob
+                Lg = Leg(c2, bl, Bl, dev_ord)
+                Lg.step(); torch.cuda.synchronize()                       # warm-up launch
+                ms, ng, nf = Lg.timed_events(reps)
+                kn = Lg.solver.last_kernel_name()
+                km = float(np.mean(ms))
+                tf, gbs, _, _, _ = roofline_of(c2, Bl, km, ng, nf, kn)
+                uo, xo, io = Lg.host_outputs()
+                rec = {"config": os.path.basename(path), "mlp_dtype": mlp, "instances": Bl, "launches_timed": reps, "value": Bl / (km * 1e-3), "unit": "solves/s",
+                       "kernel_ms": km, "kernel": kn, "roofline_frac": tf / F32_MFMA_PEAK_TF, "roofline_hbm_frac": gbs / HBM_PEAK_GBS,
+                       "N_it_mean": float(io[:, 2].mean()), "N_grad_evaluated_mean": ng, "N_forward_rollouts_mean": nf}
+                if mlp == "f16":
+                    f16_flops = (2 * (6 * 64 + 32 * 32) * (ng + nf) + 2 * (6 * 64) * ng) * c2.num_particles * c2.horizon
+                    rec["roofline_mfma_f16"] = {"achieved": f16_flops * Bl / (km * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                                "frac": f16_flops * Bl / (km * 1e-3) / 1e12 / 2500.0,
+                                                "note": "flops of the contractions on v_mfma_f32_32x32x16_f16 against the 2.5 PFLOP/s dense f16 peak: K = 6 and K = 32 contractions of a "
+                                                        "32-wide MLP leave the matrix pipe nearly idle by design; the kernel is bound by the f32 vector work"}
+                if args.verify != 0:
+                    if name.startswith("c5"):
+                        # a full-length C5 solve takes the scalar oracle minutes: the SAME instances are solved once more with three iterations from a
+                        # step size at which all three take steps (tests/test_gpu_parity.py::test_c5_full_size_solve_bit_exact) and that launch is checked
+                        c3it = c2.replace(max_iter=3, max_no_improvement_iter=3)
+                        from sde4mbrl_px4_amd.solver import SdeMpcSolver
+                        s3 = SdeMpcSolver(c3it, bl, max_batch=Bl, device=dev_ord)
+                        u3, x3, i3 = torch.empty_like(Lg.uopt), torch.empty_like(Lg.xevol), torch.empty_like(Lg.info)
+                        st3 = torch.full((Bl,), 1e-11, dtype=torch.float32, device=dev)
+                        s3.solve_dev(Bl, Lg.x0.data_ptr(), Lg.xref.data_ptr(), Lg.noise.data_ptr(), Lg.u0.data_ptr(), st3.data_ptr(), u3.data_ptr(), x3.data_ptr(), i3.data_ptr(), Lg.stream)
+                        torch.cuda.synchronize()
+                        V.add(name, c3it, bl, [Bl - 1], Lg.x0_h, Lg.xref_h, Lg.keys, Lg.u0_h, 1e-11, (u3.cpu().numpy(), x3.cpu().numpy(), i3.cpu().numpy()))
+                        rec["verified_how"] = "3-iteration launch of the same instances (same kernel instantiation, step size 1e-11), last instance, bit for bit"
+                        s3.close()
+                    else:
+                        vi = sample_indices(Bl, Lg.slots(), n_initial=1, n_drawn=1)
+                        V.add(name, c2, bl, vi, Lg.x0_h, Lg.xref_h, Lg.keys, Lg.u0_h, Lg.s0, (uo, xo, io))
+                        rec["verified_how"] = "the timed full-length launch, bit for bit"
+                others[name] = rec
+                Lg.close()
+        V.start()
+        if world == 1 and cfg.math_mode == "exact" and not args.no_tolerance_modes and os.path.basename(args.config).startswith("c2_") and not args.max_iter:
+            # The optional tolerance-parity mode on the same instances (a warm-up and a timed launch), never the reported value: solves/s and how
+            # far its controls are from this run's bit-reproducible path (north star: 1e-4). SPEC.md 10, DESIGN.md 2.
+            from sde4mbrl_px4_amd.solver import SdeMpcSolver
             modes = {}
-            u2 = torch.empty_like(uopt); x2 = torch.empty_like(xevol); i2 = torch.empty_like(info)
-            for name, kw in (("math_mode_fast", dict(math_mode="fast")), ("mlp_dtype_f16", dict(mlp_dtype="f16")),
-                             ("math_mode_fast+mlp_dtype_f16", dict(math_mode="fast", mlp_dtype="f16"))):
+            u2 = torch.empty_like(L.uopt); x2 = torch.empty_like(L.xevol); i2 = torch.empty_like(L.info)
+            for name, kw in (("math_mode_fast", dict(math_mode="fast")),):
                 s2 = SdeMpcSolver(cfg.replace(**kw), blob, max_batch=B, device=dev_ord)
                 for _ in range(2):                  # (a first launch of these kernels measured 7 % slow)
-                    s2.solve_dev(B, x0.data_ptr(), xref.data_ptr(), noise.data_ptr(), u0.data_ptr(), step_in.data_ptr(),
-                                 u2.data_ptr(), x2.data_ptr(), i2.data_ptr(), stream)
+                    L.step(s2, (u2, x2, i2))
                     ms2 = s2.last_kernel_ms()
                 torch.cuda.synchronize()
                 du = np.abs(u2.cpu().numpy() - uopt_h).reshape(B, -1)
@@ -441,13 +552,58 @@ def main():
                                "max_abs_du_vs_exact_median": float(np.median(du.max(axis=1))), "max_abs_du_vs_exact_worst": float(du.max()),
                                "instances_within_1e-4_of_exact": float(ok.mean())}
                 s2.close()
-            out["tolerance_modes"] = dict(modes, note="same instances, cold-start 200-iteration solves; controls against the exact f32 path of this run "
-                                                       "(abs + rel 1e-4, the north star's tolerance); optional modes, not the reported metric")
+            out["tolerance_modes"] = dict(modes, note="same instances, cold-start 200-iteration solves; controls against the bit-reproducible path of this run "
+                                                       "(abs + rel 1e-4, the north star's tolerance); optional mode without a CPU oracle, not the reported metric")
+        ver_wall = V.join()
+        bad_total = 0
+        for leg, r in V.results.items():
+            ok = r["bad_words"] == 0 and r["done"] == len(r["idx"])
+            bad_total += r["bad_words"]
+            tgt = out if leg == "main" else others[leg]
+            tgt["verified_instances"] = r["done"]
+            tgt["verified_indices"] = r["idx"]
+            tgt["verified_bit_exact"] = ok
+        if "main" in V.results:
+            r = V.results["main"]
+            out["verified_note"] = ("uopt, xevol and the 8 telemetry words of instances %s of the timed launch (the teams' initial assignments are b < %d; the others were handed "
+                                    "out by ticket) compared bit for bit with the CPU oracle (oracle/sde_mpc_oracle.c, mlp_dtype %s through oracle/mfma16_model.c) solving the "
+                                    "same instances from the same keys; %d words differ; oracle time %.0f s on %d threads beside the GPU legs"
+                                    % (r["idx"], L.slots(), args.mlp_dtype, r["bad_words"], r["cpu_s"], V.n_threads))
+        else:
+            out["verified_instances"], out["verified_bit_exact"] = 0, None
+        if others:
+            out["other_configs"] = others
+        if bad_total:
+            print(json.dumps(out))
+            raise SystemExit(f"bench.py: outputs of a timed launch differ from the oracle in {bad_total} words")
+        do_cpu = not args.no_cpu_baseline and world == 1
+        if do_cpu:
+            # reported baseline: the particle-vectorised build (f32 fma-chain arithmetic), one solve at a time per thread on every usable core, on
+            # 40 instances per thread of the same workload (first instances of the GPU batch; ~10 s of wall time)
+            n_cpu = min(40 * nthr, B)
+            cfg32 = cfg.replace(mlp_dtype="f32")
+            v, dt, outs_f = cpu_solve_instances(cfg32, blob, nthr, L.x0_h[:n_cpu], L.xref_h[:n_cpu], L.keys[:n_cpu], L.u0_h[:n_cpu], L.s0, fast=True)
+            devs = np.array([float(np.max(np.abs(outs_f[i][0] - uopt_h[i]))) for i in range(n_cpu)])
+            md, mmed = float(devs.max()), float(np.median(devs))
+            c1, c1cfg = cpu_c1_single_solve_ms(blob)
+            rmain = V.results.get("main")
+            out["cpu_baseline"] = {"value": v, "unit": "solves/s", "cores": nthr, "kind": "port",
+                                   "threads_used": nthr, "os_cpu_count": os.cpu_count(), "usable_cores": effective_cores(),
+                                   "sample": f"{n_cpu} solves of the same workload (the first {n_cpu} instances of the GPU batch, one solve at a time per thread, "
+                                             f"{nthr} threads = usable host cores: os.cpu_count {os.cpu_count()}, cgroup/affinity limit {effective_cores()}; {dt:.1f} s wall) "
+                                             "by the particle-vectorised build of the C oracle (oracle/sde_mpc_oracle.c -DORC_VEC: 16 particles per call, -O3 -march=native, "
+                                             "contraction allowed, f32 fma-chain contractions; CPU restatement of SPEC.md, not the reference JAX path: that cannot run here); "
+                                             f"|uopt - GPU uopt| over the sample (200-iteration solves; timing build, not the checker): median {mmed:.1e}, max {md:.1e}",
+                                   "value_bit_exact_build": (rmain["done"] / rmain["cpu_s"] * 1.0) if rmain and rmain["cpu_s"] > 0 else None,
+                                   "value_bit_exact_build_note": "solves per second PER THREAD of the bit-exact checker in the arithmetic of this run (scalar; the matrix-instruction model is integer code)",
+                                   "cpu_c1_single_solve_ms": c1["vec"][0], "cpu_c1_single_solve_ms_scalar_build": c1["scalar"][0],
+                                   "cpu_c1_note": f"BASELINE config 1: c1_iris_posctrl_h20_p32.yaml H={c1cfg.horizon} P={c1cfg.num_particles}, one cold-start solve "
+                                                  f"(N_it {c1['vec'][1]:.0f}) on ONE thread, median of 3: particle-vectorised build / bit-exact scalar -O2 build"}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    solver.close()
+    L.close()
 
 
 if __name__ == "__main__":

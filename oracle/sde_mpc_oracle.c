@@ -30,7 +30,7 @@
 #include <string.h>
 #include "../include/sdempc.h"
 #if !defined(ORC_DOUBLE) && !defined(ORC_VEC)
-#include "mfma16_model.h"      /* SPEC.md §9a: the 16-bit-operand matrix instruction, as the checker models it */
+#include "mfma16_model.c"      /* SPEC.md §9a: the 16-bit-operand matrix instruction, as the checker models it (same translation unit: the group addition inlines) */
 #define ORC_MFMA16 1
 #endif
 
@@ -166,7 +166,7 @@ typedef struct {
     /* operands of the matrix instruction, decoded once, in k-slot order: slot k of K-half hf is hidden unit u(hf,k) = rowmap(8 hf + (k & 7), k >> 3) */
     orc_op16 h1[2 * HID][16];            /* f16 mode, layer 1: row r, slots 0..5 = W1z[r][k], the rest zero */
     orc_op16 h2[HID][2][16];             /* f16 mode, layer 2: row i, K-half hf */
-    orc_op16 x2[2][3][HID][2][16];       /* f32x3 mode: [0 = W2 rows, 1 = W2^T rows][limb][row][K-half][slot] */
+    int32_t x2m[2][3][HID][2][16], x2x[2][3][HID][2][16];       /* f32x3 mode: significands / exponents of the bf16 limbs, [0 = W2 rows, 1 = W2^T rows][limb][row][K-half][slot] */
 #endif
     real inv_mass, grav, J[3], iJ[3], ct2, ct1, ct0, cm2, cm1;
     real rx[MAXM], ry[MAXM], dir[MAXM];
@@ -198,15 +198,15 @@ static void bf16_limbs(float x, uint16_t* lb) {
         x = x - h;
     }
 }
-/* out[i] = c[i] + sum_k W[i][k] v[k] as the twelve instructions of SPEC.md §9b; W: M->x2[tr] */
-static void x3_contract(const orc_op16 (*W)[HID][2][16], const float* v, const float* c, float* out) {
+/* out[i] = c[i] + sum_k W[i][k] v[k] as the twelve instructions of SPEC.md §9b; Wm / Wx: M->x2m[tr], M->x2x[tr] */
+static void x3_contract(const int32_t (*Wm)[HID][2][16], const int32_t (*Wx)[HID][2][16], const float* v, const float* c, float* out) {
     static const int WA[6] = {2, 1, 1, 0, 0, 0}, VB[6] = {0, 1, 0, 2, 1, 0};
-    orc_op16 vb[3][2][16];
+    int32_t vm[3][2][16], vx[3][2][16];
     int special = 0;
     for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k) {
         uint16_t lb[3];
         bf16_limbs(v[slot_unit(hf, k)], lb);
-        for (int l = 0; l < 3; ++l) { orc_mfma16_decode(1, lb[l], &vb[l][hf][k]); special |= vb[l][hf][k].kind; }
+        for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); vm[l][hf][k] = o.m; vx[l][hf][k] = o.ex; special |= o.kind; }
     }
     for (int i = 0; i < HID; ++i) {
         float acc = c ? c[i] : 0.0f;
@@ -215,8 +215,9 @@ static void x3_contract(const orc_op16 (*W)[HID][2][16], const float* v, const f
         } else if (!isfinite(acc)) {          /* finite products on a non-finite start value leave it as it is */
         } else {
             for (int s6 = 0; s6 < 6; ++s6) for (int hf = 0; hf < 2; ++hf) {
-                acc = orc_mfma16_group(W[WA[s6]][i][hf], vb[VB[s6]][hf], 8, acc);
-                acc = orc_mfma16_group(W[WA[s6]][i][hf] + 8, vb[VB[s6]][hf] + 8, 8, acc);
+                const int32_t *wm = Wm[WA[s6]][i][hf], *wx = Wx[WA[s6]][i][hf], *am = vm[VB[s6]][hf], *ax = vx[VB[s6]][hf];
+                acc = orc_mfma16_group8_bf16(wm, wx, am, ax, acc);
+                acc = orc_mfma16_group8_bf16(wm + 8, wx + 8, am + 8, ax + 8, acc);
             }
         }
         out[i] = acc;
@@ -273,7 +274,7 @@ static int parse_blob(const void* blob, model_t* M, int f16) {
             const int un = slot_unit(hf, k);
             uint16_t lb[3];
             bf16_limbs(tr ? M->W2[un][i] : M->W2[i][un], lb);
-            for (int l = 0; l < 3; ++l) orc_mfma16_decode(1, lb[l], &M->x2[tr][l][i][hf][k]);
+            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); M->x2m[tr][l][i][hf][k] = o.m; M->x2x[tr][l][i][hf][k] = o.ex; }
         }
     }
 #endif
@@ -398,7 +399,7 @@ static void step_fwd(const model_t* M, const ustep_t* U, const preal* x, const p
             pre_2[i] = acc;
         }
     } else if (M->f16 == 2) {
-        x3_contract(M->x2[0], A->h1d, M->b2, pre_2);
+        x3_contract(M->x2m[0], M->x2x[0], A->h1d, M->b2, pre_2);
     } else
 #endif
     for (int i = 0; i < HID; ++i) {
@@ -548,7 +549,7 @@ static void step_vjp(const model_t* M, const preal* x, const preal* xi, real dt,
     }
 #ifdef ORC_MFMA16
     float hb_x3[HID];
-    if (M->f16 == 2) x3_contract(M->x2[1], a2b, NULL, hb_x3);       /* SPEC.md §9b: W2^T abar2 as the three-limb split */
+    if (M->f16 == 2) x3_contract(M->x2m[1], M->x2x[1], a2b, NULL, hb_x3);       /* SPEC.md §9b: W2^T abar2 as the three-limb split */
 #endif
     for (int k = 0; k < HID; ++k) {
         preal hb = pbroadcast(R(0));

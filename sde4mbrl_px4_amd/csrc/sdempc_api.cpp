@@ -59,6 +59,7 @@ struct sdempc_handle {
     mutable std::string err;
     KArgs base;
     unsigned ticket_total = 0;   // running value of the device ticket word (KArgs::ticket_host points here; sdempc_kernels.hip, launch_persistent)
+    int ws_rows = 0;             // rows (instances or team slots) the trajectory / checkpoint / partial-sum / control-table workspaces hold
     bool last_ticketed = false;  // the last solve launch handed its instances out by ticket: sdempc_solve_status compares the word with the mirror
     // host tables
     std::vector<float> h_sdt, h_disc, h_beta;
@@ -208,11 +209,6 @@ int ensure_device_impl(sdempc_handle* h) {
         h->base.C.sc_n = h->cfg.num_state_constr;
         h->base.C.sc_tab = (const CostK::StateBound*)h->d_sctab.p;
     }
-    if ((rc = dev_alloc(h, h->d_traj, sizeof(float) * traj_floats(h, B)))) return rc;
-    HIPCHK(h, hipMemset(h->d_traj.p, 0, h->d_traj.bytes));
-    if ((rc = dev_alloc(h, h->d_act, sizeof(float) * (size_t)B * h->G * H * ACT_STRIDE))) return rc;
-    if ((rc = dev_alloc(h, h->d_part, sizeof(float) * (size_t)B * h->G * part_stride(H)))) return rc;
-    if ((rc = dev_alloc(h, h->d_ustg, sizeof(float) * (size_t)B * H * 36))) return rc;
     if ((rc = dev_alloc(h, h->d_x0, sizeof(float) * B * SDEMPC_NX))) return rc;
     if ((rc = dev_alloc(h, h->d_u, sizeof(float) * B * H * m))) return rc;
     if ((rc = dev_alloc(h, h->d_xref, sizeof(float) * B * (H + 1) * SDEMPC_NX))) return rc;
@@ -233,11 +229,32 @@ int ensure_device_impl(sdempc_handle* h) {
     h->base.disc = (const float*)h->d_disc.p;
     h->base.beta = (const float*)h->d_beta.p;
     h->base.wts = (const float*)h->d_wts.p;
+    h->dev_ready = true;
+    return 0;
+}
+
+// The kernels' own workspaces — particle x horizon tensor, activation checkpoint, per-group partial sums, control table in global memory —
+// hold `rows` instances: one row per instance for the one-workgroup-per-instance layouts, one per TEAM SLOT for the persistent throughput
+// launches, which is what keeps a large batch small (C2: 1.5 MB per row; 1,536 slots = 2.3 GB whatever the batch). Allocated on the first
+// launch that needs them and grown when a later launch needs more rows (never shrunk).
+int ensure_workspace(sdempc_handle* h, int rows) {
+    if (rows <= h->ws_rows) return 0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));          // nothing may still be using the old rows (caller streams: the caller's business, as for every _dev entry point)
+    for (DevBuf* b : {&h->d_traj, &h->d_act, &h->d_part, &h->d_ustg}) dev_free(*b);
+    h->ws_rows = 0;
+    h->base.traj = h->base.act = h->base.part = h->base.ustg = nullptr;
+    const int H = h->H;
+    int rc;
+    if ((rc = dev_alloc(h, h->d_traj, sizeof(float) * traj_floats(h, rows)))) return rc;
+    HIPCHK(h, hipMemset(h->d_traj.p, 0, h->d_traj.bytes));
+    if ((rc = dev_alloc(h, h->d_act, sizeof(float) * (size_t)rows * h->G * H * ACT_STRIDE))) return rc;
+    if ((rc = dev_alloc(h, h->d_part, sizeof(float) * (size_t)rows * h->G * part_stride(H)))) return rc;
+    if ((rc = dev_alloc(h, h->d_ustg, sizeof(float) * (size_t)rows * H * 36))) return rc;
     h->base.traj = (float*)h->d_traj.p;
     h->base.act = (float*)h->d_act.p;
     h->base.part = (float*)h->d_part.p;
     h->base.ustg = (float*)h->d_ustg.p;
-    h->dev_ready = true;
+    h->ws_rows = rows;
     return 0;
 }
 
@@ -456,7 +473,7 @@ void release_device(sdempc_handle* h) {
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
         if (h->stream) (void)hipStreamDestroy(h->stream);
-        h->ev0 = h->ev1 = nullptr; h->stream = nullptr; h->coop_cap = 0;
+        h->ev0 = h->ev1 = nullptr; h->stream = nullptr; h->coop_cap = 0; h->ws_rows = 0;
     }
     h->dev_ready = false; h->timed = false;
 }
@@ -562,6 +579,7 @@ int sdempc_traj_to_canonical_dev(sdempc_handle* h, int32_t B, void* traj_out_dev
     if (rc) return rc;
     if (!traj_out_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
     if ((rc = ensure_device(h))) return rc;
+    if (B > h->ws_rows) return fail(h, SDEMPC_EINVAL, "no rollout with store_traj of this batch size has run on this handle%s");
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     HIPCHK(h, launch_relayout(false, (const float*)h->d_traj.p, (float*)traj_out_dev, B, h->P, h->G, (h->H + 1) * SDEMPC_NX, st));
     return SDEMPC_OK;
@@ -575,6 +593,7 @@ int sdempc_rollout_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, co
     if (rc) return rc;
     if (!x0_dev || !u_dev || !xref_dev || !noise_dev || !cost_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
     if ((rc = ensure_device(h))) return rc;
+    if ((rc = ensure_workspace(h, B))) return rc;
     KArgs a = h->base;
     a.x0 = (const float*)x0_dev; a.u = (const float*)u_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
     a.cost = (float*)cost_dev; a.xmean = (float*)xmean_dev; a.store_traj = store_traj;
@@ -590,6 +609,7 @@ int sdempc_grad_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const
     if (rc) return rc;
     if (!x0_dev || !u_dev || !xref_dev || !noise_dev || !cost_dev || !grad_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
     if ((rc = ensure_device(h))) return rc;
+    if ((rc = ensure_workspace(h, B))) return rc;
     KArgs a = h->base;
     a.x0 = (const float*)x0_dev; a.u = (const float*)u_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
     a.cost = (float*)cost_dev; a.grad = (float*)grad_dev;
@@ -606,6 +626,10 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
     if (!x0_dev || !xref_dev || !noise_dev || !u_init_dev || !stepsize_dev || !uopt_dev || !xevol_dev || !info_dev)
         return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
     if ((rc = ensure_device(h))) return rc;
+    {   // workspace rows of this launch: the batch, or the team slots of a persistent throughput launch
+        KArgs probe = h->base; probe.B = B;
+        if ((rc = ensure_workspace(h, probe.fast ? solve_workspace_rows_fast(probe, B) : solve_workspace_rows(probe, B)))) return rc;
+    }
     KArgs a = h->base;
     a.x0 = (const float*)x0_dev; a.u = (const float*)u_init_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
     a.stepsize_in = (const float*)stepsize_dev; a.uopt = (float*)uopt_dev; a.xmean = (float*)xevol_dev; a.info = (float*)info_dev;

@@ -29,6 +29,13 @@ DI float half_join_sum(float pa, float pb) {
     return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
 }
 
+// The duo layout only runs in persistent launches (launch_persistent): a team walks many instances, one at a time, so its workspaces — the
+// particle x horizon tensor, the activation checkpoint, the per-group partial sums, the control table when that lives in global memory —
+// are indexed by the team's SLOT (workgroup x teams per workgroup), not by the instance: 1,536 rows on an MI355X whatever the batch size
+// (C2 at 12,288 instances: 2.3 GB instead of 18.8 GB; a 98,304-instance launch fits one GPU).
+template <class Team>
+DI int duo_workspace_slot() { return __builtin_amdgcn_readfirstlane((int)(blockIdx.x * Team::IPB) + Team::team()); }
+
 // Which groups a wave's halves own in pair gp of an instance with G groups. Odd G: the last pair has no group B; its upper half then
 // shadows group A (same inputs, so it stays finite) and neither stores nor contributes to a sum, and pass B is skipped.
 struct DuoPair {
@@ -172,7 +179,8 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
     Team::sync();
     block_prepass<Team>(a, sm, u, tid);
     const int PS = part_stride(H);
-    float* prows = a.part + (size_t)b * G * PS;
+    const int ws = duo_workspace_slot<Team>();         // workspaces (trajectory, checkpoint, partial sums) belong to the team's SLOT, not to the instance
+    float* prows = a.part + (size_t)ws * G * PS;
     float cu = block_ucost<Team>(a, sm, u, tid);
     Team::sync();                                      // prepass table visible to every wave of the team
     const int NPAIR = (G + 1) >> 1;
@@ -182,7 +190,7 @@ DI float duo_rollout(const KArgs& a, const Smem& sm, const WaveW& ww, const floa
         // uniform base of the pair (group 2 gp) + a 32-bit per-lane offset (this lane's group and column): scalar-base addressing
         const unsigned gofs = (unsigned)(pr.g - 2 * gp);
         const float* nzb = a.noise + ((size_t)(b * G + 2 * gp) * H) * NN * 32;         // uniform (SGPR) bases of the pair ...
-        float* tjb = a.traj + ((size_t)(b * G + 2 * gp) * (H + 1)) * NX * 32;
+        float* tjb = a.traj + ((size_t)(ws * G + 2 * gp) * (H + 1)) * NX * 32;
         const unsigned nzo = gofs * (unsigned)(H * NN * 32) + (unsigned)j;              // ... + 32-bit per-lane offsets (group, column)
         const unsigned tjo = gofs * (unsigned)((H + 1) * NX * 32) + (unsigned)j;
         float* xm = prows + (size_t)pr.g * PS;          // this group's row of per-step particle sums (SPEC.md §6.1/§6.3)
@@ -271,7 +279,8 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
     Team::sync();
     block_prepass<Team>(a, sm, y, tid);
     const int PS = part_stride(H);
-    float* prows = a.part + (size_t)b * G * PS;
+    const int ws = duo_workspace_slot<Team>();
+    float* prows = a.part + (size_t)ws * G * PS;
     float cu = block_ucost<Team>(a, sm, y, tid);
     Team::sync();
     const int NPAIR = (G + 1) >> 1;
@@ -281,11 +290,11 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
         const int gA = 2 * gp, gB = pr.hasB ? 2 * gp + 1 : gA;
         const unsigned gofs = (unsigned)(pr.g - gA);
         const float* nzb = a.noise + ((size_t)(b * G + gA) * H) * NN * 32;             // uniform (SGPR) bases of the pair ...
-        float* tjb = a.traj + ((size_t)(b * G + gA) * (H + 1)) * NX * 32;
+        float* tjb = a.traj + ((size_t)(ws * G + gA) * (H + 1)) * NX * 32;
         const unsigned nzo = gofs * (unsigned)(H * NN * 32) + (unsigned)j;              // ... + 32-bit per-lane offsets (group, column)
         const unsigned tjo = gofs * (unsigned)((H + 1) * NX * 32) + (unsigned)j;
-        float* acA = a.act + ((size_t)(b * G + gA) * H) * ACT_STRIDE;       // checkpoint rows of the two groups (tiles: whole wave)
-        float* acB = a.act + ((size_t)(b * G + gB) * H) * ACT_STRIDE;
+        float* acA = a.act + ((size_t)(ws * G + gA) * H) * ACT_STRIDE;      // checkpoint rows of the two groups (tiles: whole wave)
+        float* acB = a.act + ((size_t)(ws * G + gB) * H) * ACT_STRIDE;
         const unsigned aso = gofs * (unsigned)(H * ACT_STRIDE) + 1024u + (unsigned)j * 8u;   // this lane's particle: step scalars, relative to acA
         float* Sq = prows + (size_t)pr.g * PS;                               // this group's row of per-step adjoint sums (SPEC.md §6.1)
         float x[NX], xn[NX], xi[NN];

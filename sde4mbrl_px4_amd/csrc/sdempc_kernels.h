@@ -112,6 +112,9 @@ int team_ipb(int G, int H, int m);            // 4 when one wave owns an instanc
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_grad(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_solve(const KArgs& a, int B, hipStream_t st);
+// rows of KArgs::traj / act / part / ustg a solve launch of B instances indexes (B, or the team slots of a persistent launch)
+int solve_workspace_rows(const KArgs& a, int B);
+int solve_workspace_rows_fast(const KArgs& a, int B);
 // math_mode fast (SPEC.md §10): the same kernels built with hardware transcendentals (second translation unit)
 hipError_t launch_rollout_fast(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_grad_fast(const KArgs& a, int B, hipStream_t st);

@@ -15,15 +15,16 @@ def _dist():
     return dist
 
 
-def is_distributed() -> bool:
+def is_distributed(force: bool = False) -> bool:
+    """force: treat an initialised one-rank group as distributed (exercises the collectives on a single GPU)"""
     d = _dist()
-    return d.is_available() and d.is_initialized() and d.get_world_size() > 1
+    return d.is_available() and d.is_initialized() and (d.get_world_size() > 1 or force)
 
 
-def broadcast_blob(blob, src: int = 0, device=None) -> bytes:
+def broadcast_blob(blob, src: int = 0, device=None, force: bool = False) -> bytes:
     """Rank `src` supplies the model blob (bytes); every rank returns the same bytes."""
     import torch
-    if not is_distributed():
+    if not is_distributed(force):
         return bytes(blob)
     d = _dist()
     n = torch.tensor([len(blob) if d.get_rank() == src else 0], dtype=torch.int64, device=device)
@@ -42,9 +43,9 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def max_over_ranks(value: float, device=None) -> float:
+def max_over_ranks(value: float, device=None, force: bool = False) -> float:
     import torch
-    if not is_distributed():
+    if not is_distributed(force):
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
     _dist().all_reduce(t, op=_dist().ReduceOp.MAX)

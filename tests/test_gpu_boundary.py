@@ -135,7 +135,7 @@ def test_bench_two_ranks_self_started_on_one_gpu():
     env = dict(os.environ, SDEMPC_BENCH_DEVICE="0", SDEMPC_BENCH_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "64",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "64", "--max-iter", "12",
                           "--latency-reps", "2", "--latency-warmup", "1", "--no-cpu-baseline", "--verify", "2"],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -146,6 +146,33 @@ def test_bench_two_ranks_self_started_on_one_gpu():
     assert rec["config"]["instances_per_gpu"] == 64
     assert rec["verified_instances"] == 2 and rec["verified_bit_exact"] is True
     assert rec["roofline"]["frac"] > 0 and rec["roofline"]["kernel_ms"] > 0
+    assert rec["cpu_baseline"].startswith("skipped")                      # stated, not silently absent, in N > 1 lines
+
+
+def test_bench_rccl_branch_on_one_gpu():
+    """The RCCL code path of bench.py / dist.py on the one GPU a test box has: SDEMPC_BENCH_FORCE_DIST=1 makes a single rank initialise the
+    process group with backend nccl (= RCCL on ROCm) and run the device-tensor broadcast of the model blob, the all-reduce behind
+    max_over_ranks, the barriers and destroy_process_group. It proves that the library loads and that the collectives run on device tensors —
+    not scaling, which needs the driver's 8-GPU node."""
+    import json
+    import subprocess
+    import sys
+    from cases import ROOT
+    env = dict(os.environ, SDEMPC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("SDEMPC_BENCH_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--batch", "64", "--max-iter", "12",
+                          "--latency-reps", "2", "--latency-warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-tolerance-modes", "--verify", "2"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["verified_bit_exact"] is True
+    # the process really loaded RCCL and ran collectives on it
+    chk = subprocess.run([sys.executable, "-c", "import torch, torch.distributed as d, os; d.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0)); "
+                          "t = torch.ones(4, device='cuda'); d.all_reduce(t); d.broadcast(t, src=0); d.barrier(); print(d.get_backend(), float(t.sum())); d.destroy_process_group()"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    last = chk.stdout.strip().splitlines()[-1].split()                     # (RCCL prints its own banner lines before ours)
+    assert chk.returncode == 0 and last[0] == "nccl" and float(last[1]) == 4.0, (chk.stdout[-500:], chk.stderr[-2000:])
 
 
 def test_hold_mode_tracks_the_current_state_in_the_right_frame():
@@ -192,7 +219,8 @@ def test_in_process_worker_solves_with_prefork_variable_set(monkeypatch):
     x0 = W.HOVER.copy(); rng = jax_shim.random.PRNGKey(1)
     st0 = pos.m_reset(x=x0, rng=rng, xdes=x0)
     mpc_c = jax_shim.jit(pos.m_mpc).lower(x0, rng, st0, curr_t=0.0, xdes=x0).compile()
-    u1, s1, _, _ = mpc_c(x, rng, st0, curr_t=0.0, xdes=W.HOVER)          # first call: probe (warm start returned, no iterations)
+    with pytest.warns(RuntimeWarning, match="SHAPE PROBE"):
+        u1, s1, _, _ = mpc_c(x, rng, st0, curr_t=0.0, xdes=W.HOVER)      # first call: probe (warm start returned, no iterations, marked as unsolved)
     u2, s2, _, _ = mpc_c(x, rng, st0, curr_t=0.0, xdes=W.HOVER)          # second call: a real solve
-    assert s1 is st0 and np.all(np.array(u1) == np.float32(0.71))
+    assert float(s1.num_steps) == 0 and np.isnan(float(s1.opt_cost)) and np.all(np.array(u1) == np.float32(0.71))
     assert float(s2.num_steps) > 0 and np.abs(np.array(u2) - 0.71).max() > 1e-6

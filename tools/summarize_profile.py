@@ -13,6 +13,7 @@ ap.add_argument("src"); ap.add_argument("tag")
 ap.add_argument("--batch", type=int, default=2048)
 ap.add_argument("--config", default="c2_iris_traj_h50_p128.yaml")
 ap.add_argument("--mfma-per-eval", type=float, default=0.0, help="f32 MFMAs of one forward sweep of one instance (C2: 2 pairs x 50 steps x 44 = 4400); enables the SQ sum check")
+ap.add_argument("--mlp-dtype", default="f32x3", help="arithmetic of the profiled launches (key of profiles/pmc_traffic.json)")
 ap.add_argument("--sq-batch", type=int, default=0, help="batch of the SQ_* / GRBM passes (pmc_3, pmc_4) when it differs from --batch (tools/profile_round.sh)")
 a = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,7 +52,11 @@ if "FETCH_SIZE" in solve and "WRITE_SIZE" in solve:
     res["hbm_bytes_per_launch"] = {"read_corrected": rd, "write": wr, "total": rd + wr, "per_solve": (rd + wr) / a.batch}
     tf = os.path.join(out, "pmc_traffic.json")
     rec = json.load(open(tf)) if os.path.exists(tf) else {}
-    rec[f"{a.config}:B{a.batch}"] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "source": f"profiles/{a.tag}_pmc.json"}
+    sha = os.path.join(a.src, "lib_sha.txt")          # written by tools/profile_round.sh on the GPU box: sha256 of the library the counters were taken on
+    build = open(sha).read().split()[0][:16] if os.path.exists(sha) else None
+    res["library_build"] = build
+    rec[f"{a.config}:B{a.batch}:{a.mlp_dtype}"] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "source": f"profiles/{a.tag}_pmc.json",
+                                                  "traffic_build": build}
     json.dump(rec, open(tf, "w"), indent=1)
 if cal_r:
     res["calibration"] = {"rollout_kernel_FETCH_SIZE_KiB": cal_r.get("FETCH_SIZE"), "rollout_kernel_WRITE_SIZE_KiB": cal_r.get("WRITE_SIZE"),

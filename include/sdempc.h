@@ -88,9 +88,11 @@ typedef struct sdempc_cfg {
     float ls_init_stepsize, ls_max_stepsize, ls_coef, ls_decrease_factor, ls_increase_factor;
     int32_t ls_reset_option;          /* 0 conservative, 1 increase */
     int32_t ls_maxls;
-    /* extension (not a reference YAML key): arithmetic of the MLP contractions in the forward rollout.
-     * 0 = f32 (v_mfma_f32_32x32x2_f32, bit-reproducible; default), 1 = fp16 operands rounded toward zero,
-     * f32 accumulate (v_mfma_f32_32x32x16_f16; BASELINE config C5). SPEC.md §9. */
+    /* extension (not a reference YAML key): arithmetic of the MLP contractions. All three are reproduced bit for bit by the CPU oracle.
+     * 0 = f32 fma chains (v_mfma_f32_32x32x2_f32; default);
+     * 1 = fp16 operands rounded toward zero, f32 accumulate, in the forward rollout (v_mfma_f32_32x32x16_f16; BASELINE config C5; SPEC.md §9);
+     * 2 = f32x3: f32 operands, the two 32x32 contractions of a step (layer 2 of the drift net and its transpose in the adjoint) evaluated as
+     *     three-limb bf16 splits of both operands on v_mfma_f32_32x32x16_bf16 — f32-level accuracy on the matrix pipe (SPEC.md §9b). */
     int32_t mlp_dtype;
     /* extension (not a reference YAML key): 0 = exact (default): tanh / sigmoid / reciprocal square root in the bit-reproducible
      * software forms of SPEC.md §3, results identical to the CPU oracle bit for bit. 1 = fast: the same kernels with the

@@ -241,7 +241,7 @@ int ensure_workspace(sdempc_handle* h, int rows) {
     if (rows <= h->ws_rows) return 0;
     HIPCHK(h, hipStreamSynchronize(h->stream));          // nothing may still be using the old rows (caller streams: the caller's business, as for every _dev entry point)
     for (DevBuf* b : {&h->d_traj, &h->d_act, &h->d_part, &h->d_ustg}) dev_free(*b);
-    h->ws_rows = 0;
+    h->ws_rows = 0; h->base.ws_rows = 0;
     h->base.traj = h->base.act = h->base.part = h->base.ustg = nullptr;
     const int H = h->H;
     int rc;
@@ -255,6 +255,7 @@ int ensure_workspace(sdempc_handle* h, int rows) {
     h->base.part = (float*)h->d_part.p;
     h->base.ustg = (float*)h->d_ustg.p;
     h->ws_rows = rows;
+    h->base.ws_rows = rows;
     return 0;
 }
 

@@ -66,6 +66,7 @@ struct KArgs {
     float* uopt;               // [B][H][m]
     float* info;               // [B][8] raw: sum_ls, stepsize, nit, grad_sqr, sum_s, c_init, c_opt, nls_total
     int store_traj;
+    int ws_rows;               // rows (instances or team slots) of traj / act / part / ustg the handle has allocated (launchers refuse a grid that needs more)
     int f16;                   // mlp_dtype: 0 f32; 1 fp16-operand MLP contractions in the forward step (SPEC.md §9); 2 layer-2 / W2^T contractions as three-limb bf16 splits (§9b)
     // cooperative latency path (one instance over coop_nwg workgroups; workspace owned by the handle, see sdempc_api.cpp)
     int coop_nwg;

@@ -798,9 +798,6 @@ __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_grad_kernel(
 // Occupancy: the throughput instantiation of the workgroup-wide team is built for three waves per SIMD (168 VGPRs: the hot loops
 // fit, the compiler spills only solver state around them; +6 % at C2 over two waves per SIMD with the prefetch buffer). The
 // latency instantiation (PK) and the one-wave teams (LDS allows two workgroups per CU anyway) keep two.
-#ifndef SDEMPC_W4
-#define SDEMPC_W4 0        // build experiment: the TeamPair duo kernel at FOUR waves per SIMD (128 registers), control table in global memory (LDS: four workgroups per CU)
-#endif
 template <class Team, bool PK> constexpr int solve_waves_per_simd() { return PK ? 2 : 3; }
 // MODE 1 / 2: lane layouts (weights in VGPRs, two waves per SIMD; MODE 2 with PK: one workgroup per CU, spills go to AGPRs)
 // USTG: the per-step control table [H][36] lives in global memory (KArgs::ustg, L1/L2-resident) instead of LDS: long horizons keep three
@@ -925,7 +922,7 @@ DI void solve_instance(const KArgs& a, const Smem& sm, const WaveW& ww, const La
 }
 
 template <class Team, int M, int F16, bool PK = false, int MODE = 0, bool USTG = false>
-__global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 || MODE == 2) ? 2 : (SDEMPC_W4 && MODE == 3 && USTG && Team::IPB == 2) ? 4 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
+__global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 || MODE == 2) ? 2 : solve_waves_per_simd<Team, PK>())) sdempc_solve_kernel(KArgs a) {
     if constexpr (MODE >= 3) {
         // Duo throughput launches (MODE 3: noise through LDS staging rows; 4: through registers) are PERSISTENT: the grid holds as many workgroups as are resident at once (launch_duo_m) and every
         // workgroup walks the instances b = blockIdx.x, + gridDim.x, ... With only two rounds of six small workgroups per CU the
@@ -985,10 +982,6 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
 #define SDEMPC_DUO_PAIR(X)                                                                                          \
     X(TeamPair, 4, 0, 3, false) X(TeamPair, 4, 1, 3, false) X(TeamPair, 4, 2, 3, false) X(TeamPair, 6, 0, 3, false) X(TeamPair, 6, 1, 3, false) X(TeamPair, 6, 2, 3, false) \
     X(TeamPair, 8, 0, 3, false) X(TeamPair, 8, 1, 3, false) X(TeamPair, 8, 2, 3, false)
-#if SDEMPC_W4
-#undef SDEMPC_DUO_PAIR
-#define SDEMPC_DUO_PAIR(X) X(TeamPair, 4, 0, 3, false) X(TeamPair, 4, 2, 3, false) X(TeamPair, 4, 0, 3, true) X(TeamPair, 4, 2, 3, true)
-#endif
 #define SDEMPC_DUO_DECL(TEAM, M, F16, MODE, USTG) extern template __global__ void sdempc_solve_kernel<TEAM, M, F16, false, MODE, USTG>(KArgs);
 #define SDEMPC_DUO_DEF(TEAM, M, F16, MODE, USTG) template __global__ void sdempc_solve_kernel<TEAM, M, F16, false, MODE, USTG>(KArgs);
 
@@ -1055,17 +1048,18 @@ bool use_global_ust(int H, int m, const LaunchOpts& o, int nwaves = 4) {
 // persistent grid: as many workgroups as the device holds at once (registers: twelve waves per CU; LDS: 156 KB usable per CU, measured
 // with tools/occ_probe.hip — three 52 KB workgroups fit, three 53 KB ones do not), each walking its share of the instances
 template <class Kern>
-static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int wg_waves, int bnt, bool ust_lds, int ipb = 1, bool stage = true, int waves_per_cu = 12) {
+static hipError_t launch_persistent(Kern k, const KArgs& a, hipStream_t st, int wg_waves, int bnt, bool ust_lds, int ipb = 1, bool stage = true) {
     const size_t sb = smem_bytes(a.H, a.m, ipb, false, ust_lds, stage ? wg_waves : 0);      // + one noise staging area per wave
     hipError_t e = set_smem_attr((const void*)k, sb);
     if (e != hipSuccess) return e;
-    size_t per_cu = (size_t)waves_per_cu / (size_t)wg_waves;
+    size_t per_cu = 12 / (size_t)wg_waves;
     const size_t by_lds = (156 * 1024) / (sb ? sb : 1);
     if (by_lds < per_cu) per_cu = by_lds;
     if (per_cu < 1) per_cu = 1;
     size_t grid = per_cu * (size_t)(a.opt.cus > 0 ? a.opt.cus : 256);
     const size_t need = ((size_t)a.B + ipb - 1) / ipb;
     if (grid > need) grid = need;
+    if (a.ws_rows > 0 && grid * (size_t)ipb > (size_t)a.ws_rows) return hipErrorInvalidValue;      // team slots beyond the workspace rows: never launch (sdempc_api.cpp sizes them from solve_workspace_rows)
     KArgs ka = a;
     ka.tickets = a.work != nullptr && a.ticket_host != nullptr && (size_t)a.B >= 3 * grid * (size_t)ipb;
 #if SDEMPC_VAR_STATIC       // diagnostic builds: striped assignment at every batch size (tools/phase_clock.py)
@@ -1099,11 +1093,6 @@ static hipError_t launch_duo_m(const KArgs& a, hipStream_t st) {
 // LDS at three workgroups per CU; otherwise 128-thread workgroups (TeamBlock2)
 template <int M, int F16>
 static hipError_t launch_duo_small(const KArgs& a, hipStream_t st) {
-#if SDEMPC_W4
-    if constexpr (M == 4 && F16 != 1) {
-        if (a.ustg && a.opt.ustg != 0) return launch_persistent(sdempc_solve_kernel<TeamPair, M, F16, false, 3, true>, a, st, 4, TeamPair::BNT, false, 2, true, 16);
-    }
-#endif
     if (a.opt.ustg != 1 && smem_bytes(a.H, a.m, 2, false, true, 4) * 3 <= 156 * 1024)
         return launch_persistent(sdempc_solve_kernel<TeamPair, M, F16, false, 3, false>, a, st, 4, TeamPair::BNT, true, 2);
     return launch_duo_m<TeamBlock2, M, F16>(a, st);

@@ -65,50 +65,13 @@ DI void mfma_x3(const float* Aimg, int lane, const Limbs3& L, f32x16& acc) {
     }
 }
 
-// The same twelve instructions issued BESIDE independent vector work of the wave: `other` is a tile whose tanh does not depend on the
-// contraction (forward: the density net's layer-1 tile; adjoint: the recomputed drift layer-1 tile). A wave issues in order, so a dependent
-// MFMA chain on its own stalls it for 12 x 32 cycles; with three waves per SIMD the vector pipe then starves ("per-wave serial
-// time"). One scheduling region, pipelined by sched_group_barrier: one matrix instruction, then a slice of the tanh. Same values, other order.
-#ifndef SDEMPC_X3_OVERLAP
-#define SDEMPC_X3_OVERLAP 0      // measured (C2, 12,288 instances, same box): plain 3,383 solves/s; chain beside the tanh in the forward sweeps only 3,387;
-#endif                           // in the adjoint too 3,067 (the second live tile spills 25 registers per step): kept as a build switch, off
-#ifndef SDEMPC_X3_OVERLAP_ADJ
-#define SDEMPC_X3_OVERLAP_ADJ SDEMPC_X3_OVERLAP
-#endif
-#ifndef SDEMPC_X3_SLICE
-#define SDEMPC_X3_SLICE 20
-#endif
-template <bool PK>
-DI void mfma_x3_beside_tanh(const float* Aimg, int lane, const Limbs3& L, f32x16& acc, f32x16& other) {
-    u32x4 a3[2], a2[2], a1[2];
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        a3[hf] = *reinterpret_cast<const u32x4*>(Aimg + ((2 * 2 + hf) * 64 + lane) * 4);
-        a2[hf] = *reinterpret_cast<const u32x4*>(Aimg + ((1 * 2 + hf) * 64 + lane) * 4);
-        a1[hf] = *reinterpret_cast<const u32x4*>(Aimg + ((0 * 2 + hf) * 64 + lane) * 4);
-    }
-#define SDEMPC_X3_MFMA(AW, VL) \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AW[0]), __builtin_bit_cast(bf16x8, L.l[VL][0]), acc, 0, 0, 0); \
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, AW[1]), __builtin_bit_cast(bf16x8, L.l[VL][1]), acc, 0, 0, 0);
-    SDEMPC_X3_MFMA(a3, 0) SDEMPC_X3_MFMA(a2, 1) SDEMPC_X3_MFMA(a2, 0) SDEMPC_X3_MFMA(a1, 2) SDEMPC_X3_MFMA(a1, 1) SDEMPC_X3_MFMA(a1, 0)
-#undef SDEMPC_X3_MFMA
-    tanh_tile<PK>(other);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);                       // one matrix instruction
-        __builtin_amdgcn_sched_group_barrier(0x2, SDEMPC_X3_SLICE, 0);         // a slice of the other tile's tanh
-    }
-}
-
 // ---- MLPs of a step in the MFMA tile layout (32 particles per wave) ----
 // fwd_mlp_partials: the hidden tiles (A.h1d, A.h1n, A.h2) and the per-half partial chains of the seven output-layer dot products
 // (Po[0..5]: residual force / torque, Po[6]: density pre-activation); fwd_mlp_tiles adds the halves: (P0 + P1) + bias (SPEC.md §5.2).
 // OB: how many of the seven output-layer weight quads of a quarter are requested from LDS together (7: all; the gradient's forward sweep,
 // which also carries the noise prefetch and the checkpoint stream, takes 4 + 3: with all seven in flight its noise prefetch spilled)
-template <int F16, bool PK, int OB = 7>
-DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, StepAux& A, float* Po) {
-    // layer 1: C operand = per-step offsets (drift) / bias (density); K = 6 -> 3 MFMAs per tile
-    f32x16 accD, accN;
+// layer-1 C operands: per-step offsets (drift tile), bias (density tile)
+DI void load_l1_c(const Smem& sm, const float* ust, int h, f32x16& accD, f32x16& accN) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4 c4 = *reinterpret_cast<const float4*>(ust + 8 * q + 4 * h);
@@ -116,6 +79,12 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         accD[4 * q] = c4.x; accD[4 * q + 1] = c4.y; accD[4 * q + 2] = c4.z; accD[4 * q + 3] = c4.w;
         accN[4 * q] = n4.x; accN[4 * q + 1] = n4.y; accN[4 * q + 2] = n4.z; accN[4 * q + 3] = n4.w;
     }
+}
+template <int F16, bool PK, int OB = 7>
+DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, StepAux& A, float* Po) {
+    // layer 1: C operand = per-step offsets (drift) / bias (density); K = 6 -> 3 MFMAs per tile
+    f32x16 accD, accN;
+    load_l1_c(sm, ust, h, accD, accN);
     if constexpr (F16 == 1) {
         // fp16 operands (round toward zero), f32 accumulate: one v_mfma_f32_32x32x16_f16 per tile, k slots 0..5 live in lanes 0..31
         half8 bv;
@@ -140,12 +109,9 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     tanh_tile<PK>(accD);
     SCHED_PHASE();
 
-    constexpr bool X3O = F16 == 2 && SDEMPC_X3_OVERLAP != 0;
-    if constexpr (!X3O) {
-        tanh_tile<PK>(accN);
-        A.h1d = accD; A.h1n = accN;
-        SCHED_PHASE();
-    }
+    tanh_tile<PK>(accN);
+    A.h1d = accD; A.h1n = accN;
+    SCHED_PHASE();
 
     // layer 2 (drift): B operand of k-step r is accumulator register r of layer 1
     f32x16 acc2;
@@ -154,13 +120,6 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         float4 b4 = *reinterpret_cast<const float4*>(sm.b2 + 8 * q + 4 * h);
         acc2[4 * q] = b4.x; acc2[4 * q + 1] = b4.y; acc2[4 * q + 2] = b4.z; acc2[4 * q + 3] = b4.w;
     }
-    if constexpr (X3O) {       // the matrix-pipe chain runs beside the density tile's tanh
-        Limbs3 L;
-        split3_tile(accD, L);
-        SCHED_PHASE();
-        mfma_x3_beside_tanh<PK>(sm.A2x, lane, L, acc2, accN);
-        A.h1d = accD; A.h1n = accN;
-    } else
     if constexpr (F16 == 1) {
         // two K=16 MFMAs: k slot e of lane half h <-> accumulator register 8*hf + e, i.e. hidden unit rowmap(8*hf + e, h)
 #pragma unroll
@@ -484,7 +443,7 @@ DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, floa
 }
 // One layer-1 tile (3 f32 MFMAs, or one fp16 MFMA) on top of its C operand, then tanh: the drift tile (DRIFT: C = per-step control
 // terms c_t, A = W1z rows 0..31) or the density tile (C = b1 rows 32..63, A = W1z rows 32..63)
-template <int F16, bool DRIFT, bool TANH = true>
+template <int F16, bool DRIFT>
 DI void layer1_tile(const Smem& sm, const WaveW& ww, const float* ust, int h, const float* z, f32x16& acc) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -508,10 +467,8 @@ DI void layer1_tile(const Smem& sm, const WaveW& ww, const float* ust, int h, co
         }
     }
     SCHED_PHASE();
-    if constexpr (TANH) tanh_tile<false>(acc);
+    tanh_tile<false>(acc);
 }
-template <int F16, bool DRIFT>
-DI void layer1_pre(const Smem& sm, const WaveW& ww, const float* ust, int h, const float* z, f32x16& acc) { layer1_tile<F16, DRIFT, false>(sm, ww, ust, h, z, acc); }
 
 // The adjoint's MLP work of one 32-particle pass with short live ranges (one hidden tile at a time): density tile recomputed and
 // consumed, then abar2 from the checkpointed second layer (h2c: this lane's four float4 of the tile), W2^T abar2 by MFMA, and only
@@ -553,7 +510,6 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
         }
     }
     f32x16 accB;
-    [[maybe_unused]] f32x16 x3_hd;
     {   // drift net, second layer: abar2 = (W3^T obar) * (1 - h2^2) on the VALU, W2^T abar2 by MFMA in the accumulator layout
         f32x16 a2b;
 #pragma unroll
@@ -579,13 +535,10 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
-        if constexpr (F16 == 2 && SDEMPC_X3_OVERLAP_ADJ == 0) {       // SPEC.md §9b: W2^T abar2 as the three-limb bf16 split on the matrix pipe
+        if constexpr (F16 == 2) {       // SPEC.md §9b: W2^T abar2 as the three-limb bf16 split on the matrix pipe
             Limbs3 L;
             split3_tile(a2b, L);
             mfma_x3(sm.A2xT, lane, L, accB);
-        } else if constexpr (F16 == 2) {
-            // (the chain is issued below, beside the tanh of the recomputed drift tile: the f32 MFMAs of that tile go first, the matrix
-            // pipe is one per SIMD)
         } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -597,21 +550,10 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
         }
         }
         SCHED_PHASE();
-        if constexpr (F16 == 2 && SDEMPC_X3_OVERLAP_ADJ != 0) {
-            Limbs3 L;
-            split3_tile(a2b, L);
-            f32x16 hd0;
-            layer1_pre<F16, true>(sm, ww, ust, h, z, hd0);          // C operand + the three f32 MFMAs of the drift tile, no tanh yet
-            SCHED_PHASE();
-            mfma_x3_beside_tanh<false>(sm.A2xT, lane, L, accB, hd0);
-            SCHED_PHASE();
-            x3_hd = hd0;
-        }
     }
     {   // drift net, first layer: recomputed only now
         f32x16 hd;
-        if constexpr (F16 == 2 && SDEMPC_X3_OVERLAP_ADJ != 0) hd = x3_hd;
-        else layer1_tile<F16, true>(sm, ww, ust, h, z, hd);
+        layer1_tile<F16, true>(sm, ww, ust, h, z, hd);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float ad0 = accB[4 * q] * FMA(-hd[4 * q], hd[4 * q], 1.0f);

@@ -720,6 +720,37 @@ def test_ticketed_persistent_launch_matches_striped_launches_bit_for_bit():
     S.close()
 
 
+def test_workspaces_scale_with_team_slots_not_with_the_batch():
+    """A persistent throughput launch indexes its trajectory / checkpoint / partial-sum workspaces by team slot (1,536 on an MI355X), not by
+    instance: a C2 launch of 98,304 instances (64 rounds of the grid) takes the device memory of its inputs and outputs (15 GB of noise)
+    plus 2.3 GB of workspace — per-instance workspaces would add 150 GB — and every instance is solved exactly once, bit for bit."""
+    import torch
+    from sde4mbrl_px4_amd import prng
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(max_iter=1, max_no_improvement_iter=1, mlp_dtype="f32x3")
+    model = synthetic_iris()
+    B, H, P = 98304, cfg.horizon, cfg.num_particles
+    x0 = W.random_initial_states(B, 7)
+    xr1 = np.stack([W.reference_window(0.05 * b, cfg.time_steps) for b in range(160)])
+    xref = xr1[np.arange(B) % 160]
+    keys = prng.split(prng.PRNGKey(10), B)
+    free0, _ = torch.cuda.mem_get_info(0)
+    S = _solver(cfg, model, B)
+    yk, i0 = S.reset()
+    u0 = np.tile(yk[None], (B, 1, 1))
+    s0 = np.full(B, i0["stepsize"], np.float32)
+    S.work_counters(reset=True)
+    uopt, xevol, info = S.solve_keys(x0, xref, keys, u0, s0)
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert S.work_counters()[0] == B
+    used = (free0 - free1) / 2**30
+    assert used < 26.0, f"{used:.1f} GiB of device memory for a {B}-instance launch"
+    O = orc.Oracle(cfg, model)
+    for b in (0, 1535, 1536, 50000, B - 1):
+        uo, xe, io = O.solve(x0[b], xref[b], orc.noise_from_key(keys[b], P, H), u0[b], float(s0[b]))[:3]
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0, b
+    S.close()
+
+
 @pytest.mark.parametrize("mlp", ["f32", "f16", "f32x3"])
 def test_c5_full_size_solve_bit_exact(mlp):
     """BASELINE config C5 (H=200, P=1024: 32 particle groups per instance, control table in global memory) as a SOLVE at full size, B > CUs,

@@ -1251,7 +1251,10 @@ int solve_workspace_rows(const KArgs& k, int B) {
         const bool pk = k.opt.pk >= 0 ? k.opt.pk == 1 : B <= k.opt.cus;
         if (pk) return B;
     }
-    if (k.G >= 2 && k.opt.duo != 0) { const int slots = 6 * (k.opt.cus > 0 ? k.opt.cus : 256); return B < slots ? B : slots; }
+    if (k.G >= 2 && k.opt.duo != 0) {       // (team slots come in workgroups of up to two teams: an odd batch leaves the last slot idle but counted)
+        const int slots = 6 * (k.opt.cus > 0 ? k.opt.cus : 256), even = (B + 1) & ~1;
+        return even < slots ? even : slots;
+    }
     return B;
 }
 hipError_t launch_rollout(const KArgs& a, int B, hipStream_t st) {

@@ -14,6 +14,7 @@ bad = 0; nonfinite = 0; t0 = time.time()
 LAYOUTS = [("auto", {}), ("coop", {"spec": 0}), ("coop-rt", {"coop_launch": 1}), ("auto-fence", {"coop_fence": 1}), ("coop-fence", {"spec": 0, "coop_fence": 1}),
            ("tile-pk", {"coop": 0, "pk": 1}), ("tile", {"coop": 0, "pk": 0}), ("tile-gtab", {"coop": 0, "pk": 0, "ustg": 1}),
            ("tile-nolane", {"coop": 0, "lane": 0, "pk": 0}), ("tile-noduo", {"coop": 0, "pk": 0, "duo": 0}), ("tile-noduo-gtab", {"coop": 0, "pk": 0, "duo": 0, "ustg": 1})]
+MLPS = (sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32", "f32", "f16", "f32x3", "f32x3"])     # contraction modes to draw from (SPEC.md 9, 9b): all bit-exact
 used = {}
 for it in range(n):
     rng = np.random.default_rng(seed0 + it)
@@ -25,7 +26,7 @@ for it in range(n):
               beta_init=float(rng.uniform(0, 0.9)), rtol=float(rng.choice([1e-6, 1e-3])), ls_init_stepsize=float(rng.choice([0.01, 1e-4])),
               ls_max_stepsize=float(rng.choice([1.0, 1e-3])), ls_coef=float(rng.choice([0.01, 0.3])), ls_decrease_factor=float(rng.uniform(0.2, 0.9)),
               ls_increase_factor=float(rng.uniform(1.0, 3.0)), ls_maxls=int(rng.integers(0, 6)), stepsize=1e-4, ls_reset_option=str(rng.choice(["increase", "conservative"])),
-              enforce_ubound=bool(rng.random() < 0.85))
+              enforce_ubound=bool(rng.random() < 0.85), mlp_dtype=str(rng.choice(MLPS)))
     if rng.random() < 0.4: kw.update(u_slew_constr=[[-float(rng.uniform(0.01, 0.1)), float(rng.uniform(0.01, 0.1))]] * m, u_slew_constr_coeff=float(rng.uniform(1, 20)))
     if rng.random() < 0.3: kw.update(moment_scale=float(rng.uniform(0.1, 1.0)))
     if rng.random() < 0.3:
@@ -34,6 +35,8 @@ for it in range(n):
                   state_bound=[[-float(rng.uniform(0.05, 1.0)), float(rng.uniform(0.05, 1.0))] for _ in ids])
     cfg = MPCConfig(**kw); model = synthetic_multirotor(m, seed=it)
     lname, lopts = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
+    if cfg.mlp_dtype != "f32":
+        lname += "/" + cfg.mlp_dtype          # (the lane / cooperative layouts and the packed-tanh instantiation exist for the f32 chain: the library falls back to tiles by itself)
     used[lname] = used.get(lname, 0) + 1
     B = int(rng.integers(1, 6))
     x0 = W.random_initial_states(B, 1000 + it); xref = np.stack([W.reference_window(0.2 * b, cfg.time_steps) for b in range(B)]); noise = W.make_noise(B, P, H, it)
@@ -53,7 +56,8 @@ for it in range(n):
         nzo = orc.noise_from_key(keys[b], P, H)
         uo2, xo2, io2, _ = O.solve(x0[b], xref[b], nzo, u[b], float(cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize))
         nb += bits_differ(nk[b], nzo) + bits_differ(uk[b], uo2) + bits_differ(xk[b], xo2) + bits_differ(ik[b], io2)
-    if nb: print(f"MISMATCH case {seed0+it} [{lname}]: m={m} H={H} P={P} B={B} words={nb} cfg={kw}"); bad += 1
+    if nb: print(f"MISMATCH case {seed0+it} [{lname}]: m={m} H={H} P={P} B={B} words={nb} cfg={kw}", flush=True); bad += 1
+    if it % 50 == 49: print(f"  ... {it + 1} configurations, {bad} with mismatches, {time.time()-t0:.0f} s", flush=True)
     S.close()
 print(f"soak: {n} configurations ({nonfinite} with non-finite trajectories), {bad} with mismatches, {time.time()-t0:.1f} s; layouts {used}")
 sys.exit(1 if bad else 0)

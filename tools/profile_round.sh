@@ -1,12 +1,12 @@
 #!/bin/bash
 # One round of profiling evidence on the GPU box: tools/profile_round.sh <tag> [batch] [mlp_dtype]
-# kernel trace of bench.py + separate PMC passes (HBM bytes: FETCH_SIZE / WRITE_SIZE in their own passes, MI355X_MICROARCH.md) +
+# kernel trace of bench.py (no single-instance latency launches: they run the same kernel and would mix into its average) + separate PMC passes (HBM bytes: FETCH_SIZE / WRITE_SIZE in their own passes, MI355X_MICROARCH.md) +
 # counter calibration on the rollout / gradient kernels whose traffic is known. Summarise with tools/summarize_profile.py.
 tag=${1:-r03}; B=${2:-12288}; MLP=${3:-f32x3}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
 sha256sum sde4mbrl_px4_amd/csrc/libsdempc.so > $out/lib_sha.txt
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --mlp-dtype $MLP --no-cpu-baseline --no-tolerance-modes --no-other-configs --verify 0 --latency-reps 40 > $out/bench_trace.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --mlp-dtype $MLP --no-cpu-baseline --no-tolerance-modes --no-other-configs --verify 0 --latency-reps 0 > $out/bench_trace.log 2>&1
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" \

@@ -209,6 +209,30 @@ def test_diverging_rollout_non_finite_parity(P, layout):
     S.close()
 
 
+@pytest.mark.parametrize("mlp", ["f16", "f32x3"])
+@pytest.mark.parametrize("P", [32, 100])
+def test_diverging_rollout_non_finite_parity_in_the_matrix_pipe_modes(P, mlp):
+    """The same overflowing rollout through the matrix instruction: infinities entering a limb split turn into NaN (inf - inf) on both sides, NaN
+    operands give NaN accumulators; positions of infinities and NaNs agree with the oracle word for word (SPEC.md §3.7, §9a 'special values')."""
+    from cases import diverging_single_rotor_case
+    cfg, model, x0, xref, noise, u = diverging_single_rotor_case(P=P)
+    cfg = cfg.replace(mlp_dtype=mlp)
+    B = len(x0)
+    S, O = _solver(cfg, model, B, coop=0), orc.Oracle(cfg, model)
+    cost, traj, xm = S.rollout(x0, u, xref, noise, True, True)
+    gc, grad = S.grad(x0, u, xref, noise)
+    uopt, xevol, info = S.solve(x0, xref, noise, u, np.full(B, 0.01, np.float32))
+    assert not np.isfinite(gc[1])
+    for b in range(B):
+        c, t, mm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True)
+        c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
+        uo, xe, inf, _ = O.solve(x0[b], xref[b], noise[b], u[b], 0.01)
+        assert bits_differ(cost[b], c) == 0 and bits_differ(traj[b], t) == 0 and bits_differ(xm[b], mm) == 0, b
+        assert bits_differ(gc[b], c2) == 0 and bits_differ(grad[b], g2.astype(np.float32)) == 0, b
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], inf) == 0, b
+    S.close()
+
+
 def test_saturating_activations_and_violent_states_bit_exact():
     """Weights scaled up so that tanh / sigmoid arguments exceed their clamp ranges (|x| > 9, > 30), fast tumbling initial
     states and strong diffusion: exercises the clamped branches of SPEC.md §3 and large-magnitude arithmetic."""

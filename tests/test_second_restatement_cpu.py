@@ -122,3 +122,43 @@ def test_adjoint_against_reverse_mode_autodiff(name):
     np.testing.assert_allclose(g64, g_ad, rtol=0, atol=1e-6 * scale)
     np.testing.assert_allclose(g32, g_ad, rtol=0, atol=2e-4 * scale)
     assert abs(c32 - Jv) <= 2e-5 * abs(Jv)
+
+
+# ---- the matrix-pipe modes (SPEC.md §9, §9a, §9b) written a second time: Python-integer model of the instruction, NumPy around it ------------------
+@pytest.mark.parametrize("dtn", ["f16", "bf16"])
+def test_second_model_of_the_matrix_instruction_reproduces_the_hardware(dtn):
+    """oracle/sde_mpc_numpy.py: mfma16_dot (exact Python integers, no fast paths) against the recorded hardware answers — every fifth one of the
+    committed sample — and therefore against oracle/mfma16_model.c on the same inputs."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"mfma16_{dtn}.npz"))
+    bad = []
+    for n in range(0, len(g["d"]), 5):
+        c = g["c"][n:n + 1].view(np.float32)[0]
+        if not np.isfinite(c):
+            continue
+        got = np.asarray(R2.mfma16_dot(dtn == "bf16", g["a"][n], g["b"][n], c), np.float32).view(np.uint32)
+        if got != g["d"][n]:
+            bad.append(n)
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("mlp", ["f32x3", "f16"])
+def test_matrix_pipe_modes_bit_identical_to_the_c_oracle(mlp):
+    """Rollout, gradient and a short full solve of a tiny problem (2 particles, 3 steps) in the two matrix-pipe modes: the second restatement
+    (limb split / fp16 rounding in NumPy, the instruction in Python integers) equals the C oracle bit for bit."""
+    cfg = MPCConfig(horizon=3, num_short_dt=2, long_step_dt=0.1, num_particles=2, u_slew_coeff=1.0, max_iter=2, max_no_improvement_iter=2, mlp_dtype=mlp)
+    model = synthetic_iris()
+    x0 = W.random_initial_states(1, 3)[0]
+    xref = W.reference_window(0.1, cfg.time_steps)
+    noise = W.make_noise(1, 2, 3, 2)[0]
+    u = np.clip(0.71 + 0.1 * np.random.default_rng(1).standard_normal((3, 4)), 1e-4, 1).astype(np.float32)
+    O, N = orc.Oracle(cfg, model), R2.Restatement(cfg, model)
+    c_o, traj_o, mean_o = O.rollout(x0, u, xref, noise, want_traj=True, want_mean=True)
+    c_n, traj_n, mean_n = N.rollout(x0, u, xref, noise)
+    assert np.float32(c_o) == c_n and bits_differ(traj_n, traj_o) == 0 and bits_differ(mean_n, mean_o) == 0
+    c_o, g_o = O.grad(x0, u, xref, noise)
+    c_n, g_n = N.cost_grad(x0, u, xref, noise)
+    assert np.float32(c_o) == c_n and bits_differ(g_n, g_o.astype(np.float32)) == 0
+    uo, _, info_o, _ = O.solve(x0, xref, noise, u, 0.01)
+    un, info_n = N.solve_own(x0, xref, noise, u, 0.01)
+    assert bits_differ(un, uo) == 0 and bits_differ(info_n, info_o) == 0

@@ -24,19 +24,6 @@ DI void fwd_head(const float* x, float* Rm, float* z) {
     z[3] = x[10]; z[4] = x[11]; z[5] = x[12];
 }
 
-// Timing-only diagnostic builds (tools/build_variant.sh NAME "-DSDEMPC_VAR_NOLDS=1" / "-DSDEMPC_VAR_NOMFMA=1"; run with tools/prof_solve.py --fixed-work):
-// NOLDS takes every MLP weight operand from a constant instead of LDS (what would perfect hiding of the LDS latency buy?), NOMFMA skips the
-// matrix instructions (what do their chains cost the wave?). Results are meaningless; never part of the product build.
-#ifndef SDEMPC_VAR_NOLDS
-#define SDEMPC_VAR_NOLDS 0
-#endif
-#ifndef SDEMPC_VAR_NOMFMA
-#define SDEMPC_VAR_NOMFMA 0
-#endif
-DI float4 lds4(const float* p) {
-    if constexpr (SDEMPC_VAR_NOLDS != 0) { (void)p; return make_float4(0.011f, -0.012f, 0.013f, -0.014f); }
-    else return *reinterpret_cast<const float4*>(p);
-}
 // ---- SPEC.md §9b: three-limb bf16 split contraction on the matrix pipe (`mlp_dtype: f32x3`) ----
 // A 32-wide contraction out[i] = c[i] + sum_k W[i][k] v[k] with both operands split by truncation into three bf16 limbs
 // (x = x1 + x2 + x3 up to 2^-24 |x|) and the six leading limb products accumulated in f32 by v_mfma_f32_32x32x16_bf16, in the fixed order
@@ -70,16 +57,11 @@ DI void mfma_x3(const float* Aimg, int lane, const Limbs3& L, f32x16& acc) {
     for (int s6 = 0; s6 < 6; ++s6) {
         if (s6 == 0 || WA[s6] != WA[s6 - 1]) {     // the weight limb changes three times: six 16-byte LDS reads per contraction
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                if constexpr (SDEMPC_VAR_NOLDS != 0) aw[hf] = u32x4{0x3c003c10u, 0xbc003c20u, 0x3c00bc30u, 0x3c003c40u};
-                else aw[hf] = *reinterpret_cast<const u32x4*>(Aimg + ((WA[s6] * 2 + hf) * 64 + lane) * 4);
-            }
+            for (int hf = 0; hf < 2; ++hf) aw[hf] = *reinterpret_cast<const u32x4*>(Aimg + ((WA[s6] * 2 + hf) * 64 + lane) * 4);
         }
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            if constexpr (SDEMPC_VAR_NOMFMA != 0) acc[hf] += __uint_as_float(aw[hf][0] ^ L.l[VB[s6]][hf][0]) * 1e-30f;      // (keeps the operands alive)
-            else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[hf]), __builtin_bit_cast(bf16x8, L.l[VB[s6]][hf]), acc, 0, 0, 0);
-        }
+        for (int hf = 0; hf < 2; ++hf)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aw[hf]), __builtin_bit_cast(bf16x8, L.l[VB[s6]][hf]), acc, 0, 0, 0);
     }
 }
 
@@ -92,8 +74,8 @@ DI void mfma_x3(const float* Aimg, int lane, const Limbs3& L, f32x16& acc) {
 DI void load_l1_c(const Smem& sm, const float* ust, int h, f32x16& accD, f32x16& accN) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float4 c4 = lds4(ust + 8 * q + 4 * h);
-        float4 n4 = lds4(sm.b1n + 8 * q + 4 * h);
+        float4 c4 = *reinterpret_cast<const float4*>(ust + 8 * q + 4 * h);
+        float4 n4 = *reinterpret_cast<const float4*>(sm.b1n + 8 * q + 4 * h);
         accD[4 * q] = c4.x; accD[4 * q + 1] = c4.y; accD[4 * q + 2] = c4.z; accD[4 * q + 3] = c4.w;
         accN[4 * q] = n4.x; accN[4 * q + 1] = n4.y; accN[4 * q + 2] = n4.z; accN[4 * q + 3] = n4.w;
     }
@@ -118,11 +100,8 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             float b = h ? z[2 * s + 1] : z[2 * s];
-            if constexpr (SDEMPC_VAR_NOMFMA != 0) { accD[s] += ww.w1d[s] * b; accN[s] += ww.w1n[s] * b; }
-            else {
             accD = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1d[s], b, accD, 0, 0, 0);
             accN = __builtin_amdgcn_mfma_f32_32x32x2f32(ww.w1n[s], b, accN, 0, 0, 0);
-            }
         }
     }
     SCHED_PHASE();
@@ -138,7 +117,7 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     f32x16 acc2;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float4 b4 = lds4(sm.b2 + 8 * q + 4 * h);
+        float4 b4 = *reinterpret_cast<const float4*>(sm.b2 + 8 * q + 4 * h);
         acc2[4 * q] = b4.x; acc2[4 * q + 1] = b4.y; acc2[4 * q + 2] = b4.z; acc2[4 * q + 3] = b4.w;
     }
     if constexpr (F16 == 1) {
@@ -187,8 +166,8 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
                 float4 w[OB];
 #pragma unroll
                 for (int i = 0; i < OB; ++i) {
-                    if (i0 + i < 6) w[i] = lds4(sm.W3 + (i0 + i) * HID + 8 * q + 4 * h);
-                    else if (i0 + i == 6) w[i] = lds4(sm.w3n + 8 * q + 4 * h);
+                    if (i0 + i < 6) w[i] = *reinterpret_cast<const float4*>(sm.W3 + (i0 + i) * HID + 8 * q + 4 * h);
+                    else if (i0 + i == 6) w[i] = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
                 }
                 SCHED_PHASE();
 #pragma unroll
@@ -484,8 +463,7 @@ DI void layer1_tile(const Smem& sm, const WaveW& ww, const float* ust, int h, co
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             float bb = h ? z[2 * s + 1] : z[2 * s];
-            if constexpr (SDEMPC_VAR_NOMFMA != 0) acc[s] += (DRIFT ? ww.w1d[s] : ww.w1n[s]) * bb;
-            else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(DRIFT ? ww.w1d[s] : ww.w1n[s], bb, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(DRIFT ? ww.w1d[s] : ww.w1n[s], bb, acc, 0, 0, 0);
         }
     }
     SCHED_PHASE();
@@ -509,13 +487,13 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
         // (weight quads of a quarter are requested from LDS together, then consumed: one exposed LDS round trip per quarter, see fwd_mlp_partials)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 wn4 = lds4(sm.w3n + 8 * q + 4 * h);
+            float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
             float an0, an1, an2, an3;
 #pragma unroll
             for (int k0 = 0; k0 < NN; k0 += 3) {       // three weight quads in flight at a time (the adjoint has no registers for six)
                 float4 wz[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) wz[k] = lds4(sm.W1zT + (k0 + k) * 2 * HID + HID + 8 * q + 4 * h);
+                for (int k = 0; k < 3; ++k) wz[k] = *reinterpret_cast<const float4*>(sm.W1zT + (k0 + k) * 2 * HID + HID + 8 * q + 4 * h);
                 SCHED_PHASE();
                 if (k0 == 0) {
                     an0 = (wn4.x * ebraw) * FMA(-hn[4 * q], hn[4 * q], 1.0f);
@@ -541,7 +519,7 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
             for (int i0 = 0; i0 < 6; i0 += 3) {
                 float4 w3[3];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) w3[i] = lds4(sm.W3 + (i0 + i) * HID + 8 * q + 4 * h);
+                for (int i = 0; i < 3; ++i) w3[i] = *reinterpret_cast<const float4*>(sm.W3 + (i0 + i) * HID + 8 * q + 4 * h);
                 SCHED_PHASE();
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -586,7 +564,7 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
             for (int k0 = 0; k0 < NN; k0 += 3) {
                 float4 wz[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) wz[k] = lds4(sm.W1zT + (k0 + k) * 2 * HID + 8 * q + 4 * h);
+                for (int k = 0; k < 3; ++k) wz[k] = *reinterpret_cast<const float4*>(sm.W1zT + (k0 + k) * 2 * HID + 8 * q + 4 * h);
                 SCHED_PHASE();
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -597,7 +575,7 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
             for (int j0 = 0; j0 < M; j0 += 2) {
                 float4 wu[2];
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) wu[jj] = lds4(sm.W1uT + (j0 + jj) * HID + 8 * q + 4 * h);
+                for (int jj = 0; jj < 2; ++jj) wu[jj] = *reinterpret_cast<const float4*>(sm.W1uT + (j0 + jj) * HID + 8 * q + 4 * h);
                 SCHED_PHASE();
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {

@@ -150,6 +150,8 @@ int sdempc_device_ready(const sdempc_handle* h);
  *   SDEMPC_OPT_PK             -1 auto / 0 / 1                -1       SDEMPC_PK            packed-f32 tanh instantiation of the tile layout (auto: grid <= CUs)
  *   SDEMPC_OPT_USTG           -1 auto / 0 / 1                -1       SDEMPC_USTG          per-step control table in global memory instead of LDS (auto: long horizons)
  *   SDEMPC_OPT_DUO            -1 auto / 0 / 1                -1       SDEMPC_DUO           throughput launches: 64 particles per wave (two 32-particle groups; auto = on for P > 32)
+ *   SDEMPC_OPT_HEX            0 / 1                          1        SDEMPC_HEX           launches that fill every two-wave team slot of the device: one six-team
+ *                                                                                          workgroup per CU (weights staged once per CU) instead of three two-team ones
  *   SDEMPC_OPT_COOP_LAUNCH    0 / 1                          0        SDEMPC_COOP_LAUNCH   hipLaunchCooperativeKernel for the cooperative layouts
  *   SDEMPC_OPT_COOP_FENCE     0 / 1                          0        SDEMPC_COOP_FENCE    agent-scope release / acquire fences around the grid barrier
  *   SDEMPC_OPT_COOP_SPIN_US   -1 derived / >= 0 microseconds -1       SDEMPC_COOP_SPIN_US  how long one grid barrier of a cooperative layout may wait
@@ -167,6 +169,7 @@ int sdempc_device_ready(const sdempc_handle* h);
 #define SDEMPC_OPT_COOP_SPIN_US 8
 #define SDEMPC_OPT_DEVICE_CUS 9
 #define SDEMPC_OPT_DUO 10
+#define SDEMPC_OPT_HEX 11
 int sdempc_set_option(sdempc_handle* h, int32_t key, int32_t value);
 int sdempc_get_option(const sdempc_handle* h, int32_t key, int32_t* value);
 

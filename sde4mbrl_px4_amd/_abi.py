@@ -59,7 +59,7 @@ class SdempcInfo(C.Structure):
 INFO_FIELDS = [f[0] for f in SdempcInfo._fields_]
 
 # execution options of a handle (include/sdempc.h, SDEMPC_OPT_*)
-OPTIONS = {"lane": 1, "coop": 2, "spec": 3, "pk": 4, "ustg": 5, "coop_launch": 6, "coop_fence": 7, "coop_spin_us": 8, "device_cus": 9, "duo": 10}
+OPTIONS = {"lane": 1, "coop": 2, "spec": 3, "pk": 4, "ustg": 5, "coop_launch": 6, "coop_fence": 7, "coop_spin_us": 8, "device_cus": 9, "duo": 10, "hex": 11}
 
 ABI_VERSION = 2          # include/sdempc.h: SDEMPC_ABI_VERSION (the layout of SdempcCfg / SdempcInfo below)
 

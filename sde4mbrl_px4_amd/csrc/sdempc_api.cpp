@@ -141,6 +141,7 @@ void default_options(sdempc_handle* h) {
     o.duo = env_int("SDEMPC_DUO", -1, -1, 1);
     o.coop_launch = env_int("SDEMPC_COOP_LAUNCH", 0, 0, 1);
     o.coop_fence = env_int("SDEMPC_COOP_FENCE", 0, 0, 1);
+    o.hex = env_int("SDEMPC_HEX", 1, 0, 1);
     h->spin_us = env_int("SDEMPC_COOP_SPIN_US", -1, -1, 10 * 1000 * 1000);
 }
 // Budget of one grid barrier of the cooperative layouts, in 10 ns ticks (KArgs::coop_spin). A barrier is passed ~780 times per C2
@@ -509,6 +510,7 @@ int sdempc_set_option(sdempc_handle* h, int32_t key, int32_t value) {
         case SDEMPC_OPT_DUO: return tri(o.duo);
         case SDEMPC_OPT_COOP_LAUNCH: return flag(o.coop_launch);
         case SDEMPC_OPT_COOP_FENCE: return flag(o.coop_fence);
+        case SDEMPC_OPT_HEX: return flag(o.hex);
         case SDEMPC_OPT_COOP_SPIN_US:
             if (value < -1) return fail(h, SDEMPC_EINVAL, "spin budget must be -1 (derived) or >= 0 microseconds%s");
             h->spin_us = value;
@@ -531,6 +533,7 @@ int sdempc_get_option(const sdempc_handle* h, int32_t key, int32_t* value) {
         case SDEMPC_OPT_DUO: *value = o.duo; break;
         case SDEMPC_OPT_COOP_LAUNCH: *value = o.coop_launch; break;
         case SDEMPC_OPT_COOP_FENCE: *value = o.coop_fence; break;
+        case SDEMPC_OPT_HEX: *value = o.hex; break;
         case SDEMPC_OPT_COOP_SPIN_US: *value = h->spin_us >= 0 ? h->spin_us : (int32_t)(coop_spin_ticks(h) / 100u); break;
         case SDEMPC_OPT_DEVICE_CUS: *value = o.cus; break;
         default: return SDEMPC_EINVAL;

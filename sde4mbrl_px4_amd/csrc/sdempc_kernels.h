@@ -37,6 +37,7 @@ struct LaunchOpts {
     int coop_launch;   // 1: hipLaunchCooperativeKernel for the cooperative layouts, 0: plain launch of a grid sized to be resident (default)
     int duo;           // throughput launches in the duo tile layout (64 particles per wave): -1 auto (= on for multi-group instances), 0 off, 1 on
     int coop_fence;    // 1: agent-scope release / acquire fences around the grid barrier, 0: sc1 write-through hand-off only (default)
+    int hex;           // 1: launches that fill every two-wave team slot of the device run one six-team workgroup per CU (default), 0: two-team workgroups always
 };
 struct KArgs {
     int H, P, m, G;

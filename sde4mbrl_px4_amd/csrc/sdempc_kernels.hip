@@ -40,10 +40,10 @@
 #ifndef SDEMPC_FAST
 #define SDEMPC_FAST 0
 #endif
-// Each arithmetic mode's build is spread over three translation units so that `make -j` compiles them side by side (one hipcc process per
+// Each arithmetic mode's build is spread over four translation units so that `make -j` compiles them side by side (one hipcc process per
 // unit; the solve kernel has ~90 instantiations of ~25k instructions each): SDEMPC_TU = 0 — every kernel except the duo solve
 // kernels, and all launchers; 1 — the duo solve kernels of the two-wave teams (TeamPair, TeamBlock2); 2 — those of the four-wave
-// team (TeamBlock). Units 1 and 2 hold nothing but explicit instantiations (list macros below), unit 0 declares them `extern template`.
+// team (TeamBlock); 3 — those of the six-team workgroup (TeamHex). Units 1 to 3 hold nothing but explicit instantiations (list macros below), unit 0 declares them `extern template`.
 #ifndef SDEMPC_TU
 #define SDEMPC_TU 0
 #endif
@@ -107,7 +107,7 @@ struct TeamBlock2 {
 // price of small workgroups (the weights are staged once per workgroup, so the per-step control table stays in LDS at three workgroups =
 // twelve waves per CU). The two teams of a workgroup run independent control flow (different instances), so their barrier cannot be
 // s_barrier: a counter in LDS per team, two arrivals per episode (the arriving wave waits for the counter's next even value).
-__shared__ unsigned sdempc_pair_bar[2];
+__shared__ unsigned sdempc_pair_bar[8];
 // Diagnostic builds only (tools/build_variant.sh clk "-DSDEMPC_VAR_PHASE_CLK=1", tools/phase_clock.py): per-wave time by phase
 // (s_memrealtime ticks of 10 ns), summed in LDS over a solve and flushed (>> 10: 10.24 us units, two per word) into KArgs::work in place of the work counters.
 // slots: 0 solve, 1 cost rollouts, 2 their step loops, 3 gradient evaluations (2, 3: kept in LDS only), 4 forward sweeps, 5 adjoint sweeps, 6 team barriers
@@ -121,8 +121,9 @@ DI void clk_add(int slot, unsigned long long t0) { if ((threadIdx.x & 63) == 0) 
 #define CLK_BEGIN(v) ((void)0)
 #define CLK_END(slot, v) ((void)0)
 #endif
-struct TeamPair {
-    static constexpr int NT = 128, NWAVES = 2, IPB = 2, BNT = 256;
+template <int IPB_>
+struct TeamPairT {
+    static constexpr int NT = 128, NWAVES = 2, IPB = IPB_, BNT = 128 * IPB_;
     DI static int tid() { return threadIdx.x & 127; }
     DI static int team() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 7); }
     DI static void sync() {
@@ -138,6 +139,10 @@ struct TeamPair {
         CLK_END(6, tb);
     }
 };
+// Two-wave teams: two per workgroup (three workgroups per CU), or six in ONE twelve-wave workgroup per CU (TeamHex: full-GPU launches; the
+// weights are staged once per CU instead of three times, which leaves 30 KB of LDS free where three 52 KB workgroups leave none)
+using TeamPair = TeamPairT<2>;
+using TeamHex = TeamPairT<6>;
 struct TeamWave {
     static constexpr int NT = 64, NWAVES = 1, IPB = 4, BNT = 256;
     DI static int tid() { return threadIdx.x & 63; }
@@ -982,6 +987,9 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
 #define SDEMPC_DUO_PAIR(X)                                                                                          \
     X(TeamPair, 4, 0, 3, false) X(TeamPair, 4, 1, 3, false) X(TeamPair, 4, 2, 3, false) X(TeamPair, 6, 0, 3, false) X(TeamPair, 6, 1, 3, false) X(TeamPair, 6, 2, 3, false) \
     X(TeamPair, 8, 0, 3, false) X(TeamPair, 8, 1, 3, false) X(TeamPair, 8, 2, 3, false)
+#define SDEMPC_DUO_HEX(X)                                                                                           \
+    X(TeamHex, 4, 0, 3, false) X(TeamHex, 4, 1, 3, false) X(TeamHex, 4, 2, 3, false) X(TeamHex, 6, 0, 3, false) X(TeamHex, 6, 1, 3, false) X(TeamHex, 6, 2, 3, false) \
+    X(TeamHex, 8, 0, 3, false) X(TeamHex, 8, 1, 3, false) X(TeamHex, 8, 2, 3, false)
 #define SDEMPC_DUO_DECL(TEAM, M, F16, MODE, USTG) extern template __global__ void sdempc_solve_kernel<TEAM, M, F16, false, MODE, USTG>(KArgs);
 #define SDEMPC_DUO_DEF(TEAM, M, F16, MODE, USTG) template __global__ void sdempc_solve_kernel<TEAM, M, F16, false, MODE, USTG>(KArgs);
 
@@ -992,8 +1000,12 @@ SDEMPC_DUO_TEAM(SDEMPC_DUO_DEF, TeamBlock2)
 #elif SDEMPC_TU == 2
 SDEMPC_DUO_TEAM(SDEMPC_DUO_DEF, TeamBlock)
 }  // namespace exact / fastm
+#elif SDEMPC_TU == 3
+SDEMPC_DUO_HEX(SDEMPC_DUO_DEF)
+}  // namespace exact / fastm
 #else
 SDEMPC_DUO_PAIR(SDEMPC_DUO_DECL)
+SDEMPC_DUO_HEX(SDEMPC_DUO_DECL)
 SDEMPC_DUO_TEAM(SDEMPC_DUO_DECL, TeamBlock2)
 SDEMPC_DUO_TEAM(SDEMPC_DUO_DECL, TeamBlock)
 
@@ -1093,6 +1105,10 @@ static hipError_t launch_duo_m(const KArgs& a, hipStream_t st) {
 // LDS at three workgroups per CU; otherwise 128-thread workgroups (TeamBlock2)
 template <int M, int F16>
 static hipError_t launch_duo_small(const KArgs& a, hipStream_t st) {
+    // a launch that fills every team slot of the device anyway: one twelve-wave workgroup of six teams per CU
+    const int cus = a.opt.cus > 0 ? a.opt.cus : 256;
+    if (a.opt.ustg != 1 && a.opt.hex != 0 && a.B >= 6 * cus && smem_bytes(a.H, a.m, 6, false, true, 12) <= 156 * 1024)
+        return launch_persistent(sdempc_solve_kernel<TeamHex, M, F16, false, 3, false>, a, st, 12, TeamHex::BNT, true, 6);
     if (a.opt.ustg != 1 && smem_bytes(a.H, a.m, 2, false, true, 4) * 3 <= 156 * 1024)
         return launch_persistent(sdempc_solve_kernel<TeamPair, M, F16, false, 3, false>, a, st, 4, TeamPair::BNT, true, 2);
     return launch_duo_m<TeamBlock2, M, F16>(a, st);
@@ -1251,7 +1267,7 @@ int solve_workspace_rows(const KArgs& k, int B) {
         const bool pk = k.opt.pk >= 0 ? k.opt.pk == 1 : B <= k.opt.cus;
         if (pk) return B;
     }
-    if (k.G >= 2 && k.opt.duo != 0) {       // (team slots come in workgroups of up to two teams: an odd batch leaves the last slot idle but counted)
+    if (k.G >= 2 && k.opt.duo != 0) {       // (team slots come in workgroups of up to two teams: an odd batch leaves the last slot idle but counted; six-team workgroups only run full)
         const int slots = 6 * (k.opt.cus > 0 ? k.opt.cus : 256), even = (B + 1) & ~1;
         return even < slots ? even : slots;
     }

@@ -15,12 +15,10 @@ ap.add_argument("--mode", default="solve", choices=["solve", "rollout", "grad"])
 ap.add_argument("--math-mode", default="exact", choices=["exact", "fast"])
 ap.add_argument("--mlp-dtype", default="f32", choices=["f32", "f16", "f32x3"])
 ap.add_argument("--fixed-work", action="store_true", help="no line search, no stopping rule: max_iter gradient evaluations and rollouts whatever the values")
-ap.add_argument("--fixed-work", action="store_true", help="no line search, no stopping rule: max_iter gradient evaluations and rollouts whatever the values (timing-only diagnostic builds)")
 a = ap.parse_args()
 cfg = load_mpc_config(a.config).replace(math_mode=a.math_mode, mlp_dtype=a.mlp_dtype)
 if a.max_iter: cfg = cfg.replace(max_iter=a.max_iter, max_no_improvement_iter=a.max_iter)
 if a.fixed_work: cfg = cfg.replace(ls_maxls=0, stepsize=1e-4, rtol=0.0, atol=0.0, max_no_improvement_iter=10 ** 6)
-if a.fixed_work: cfg = cfg.replace(ls_maxls=0, stepsize=1e-7, rtol=0.0, atol=0.0, max_no_improvement_iter=10 ** 6)
 H, P, m, B = cfg.horizon, cfg.num_particles, cfg.num_motors, a.batch
 dev = torch.device("cuda", 0)
 S = SdeMpcSolver(cfg, synthetic_iris() if m == 4 else synthetic_hexa(), max_batch=B)

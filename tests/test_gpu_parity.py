@@ -731,7 +731,14 @@ def test_ticketed_persistent_launch_matches_striped_launches_bit_for_bit():
     S.work_counters(reset=True)
     uopt, xevol, info = S.solve_keys(x0, xref, keys, u0, s0)
     assert ", false, 3, " in S.last_kernel_name() and 3 * 6 * S.get_option("device_cus") <= B
+    assert "TeamPairT<6>" in S.last_kernel_name()                         # a launch that fills the device: one six-team workgroup per CU
     assert S.work_counters()[0] == B                                      # every instance solved exactly once
+    S.set_option("hex", 0)                                                # the same launch in two-team workgroups (three per CU): same bits
+    uh, xh, ih = S.solve_keys(x0, xref, keys, u0, s0)
+    assert "TeamPairT<2>" in S.last_kernel_name() and bits_differ(uopt, uh) == 0 and bits_differ(xevol, xh) == 0 and bits_differ(info, ih) == 0
+    S.set_option("hex", 1)
+    S.work_counters(reset=True)
+    assert S.solve_keys(x0, xref, keys, u0, s0)[0].tobytes() == uopt.tobytes() and S.work_counters()[0] == B
     ub, xb, ib = S.solve_keys(x0, xref, keys, u0, s0)                     # second ticketed launch of the handle: the ticket word is not reset between launches
     assert S.work_counters()[0] == 2 * B and bits_differ(uopt, ub) == 0 and bits_differ(xevol, xb) == 0 and bits_differ(info, ib) == 0
     for sl in (slice(0, 600), slice(2300, 2900), slice(4100, 4700)):

@@ -13,6 +13,20 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short short8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// dtype 2: v_mfma_f32_32x32x8_bf16_1k on the k < 8 part of a bf16 case file (lane half h holds k = 4h .. 4h+3)
+__global__ void k8(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, const float* __restrict__ C, float* __restrict__ D) {
+    const size_t t = blockIdx.x;
+    A += t * 512; B += t * 512; C += t * 1024; D += t * 1024;
+    const int l = threadIdx.x, j = l & 31, h = l >> 5;
+    s16x4 a, b;
+    for (int e = 0; e < 4; ++e) { a[e] = (short)A[j * 16 + 4 * h + e]; b[e] = (short)B[(4 * h + e) * 32 + j]; }
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = C[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j];
+    acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, acc, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) D[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = acc[r];
+}
 
 template <int DT>
 __global__ void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, const float* __restrict__ C, float* __restrict__ D) {
@@ -29,7 +43,7 @@ __global__ void k(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 1; }
+    if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.bin [8]\n", argv[0]); return 1; }
     FILE* f = fopen(argv[1], "rb"); if (!f) { perror(argv[1]); return 1; }
     int32_t hdr[4]; if (fread(hdr, 4, 4, f) != 4 || hdr[0] != 0x4D464D41) { fprintf(stderr, "bad header\n"); return 1; }
     const size_t nt = hdr[1]; const int dt = hdr[2];
@@ -42,7 +56,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dA, nt * 1024)); CK(hipMalloc(&dB, nt * 1024)); CK(hipMalloc(&dC, nt * 4096)); CK(hipMalloc(&dD, nt * 4096));
     CK(hipMemcpy(dA, A.data(), nt * 1024, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), nt * 1024, hipMemcpyHostToDevice));
     CK(hipMemcpy(dC, C.data(), nt * 4096, hipMemcpyHostToDevice));
-    if (dt == 0) k<0><<<dim3((unsigned)nt), dim3(64)>>>(dA, dB, dC, dD); else k<1><<<dim3((unsigned)nt), dim3(64)>>>(dA, dB, dC, dD);
+    const bool k8mode = argc > 3 && atoi(argv[3]) == 8;      // third argument 8: the K = 8 instruction on a bf16 file
+    if (k8mode) k8<<<dim3((unsigned)nt), dim3(64)>>>(dA, dB, dC, dD);
+    else if (dt == 0) k<0><<<dim3((unsigned)nt), dim3(64)>>>(dA, dB, dC, dD); else k<1><<<dim3((unsigned)nt), dim3(64)>>>(dA, dB, dC, dD);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(D.data(), dD, nt * 4096, hipMemcpyDeviceToHost));
     FILE* g = fopen(argv[2], "wb"); if (!g) { perror(argv[2]); return 1; }

@@ -751,6 +751,37 @@ def test_ticketed_persistent_launch_matches_striped_launches_bit_for_bit():
     S.close()
 
 
+@pytest.mark.parametrize("m,mlp", [(4, "f16"), (6, "f32x3"), (6, "f32"), (8, "f16"), (8, "f32x3")])
+def test_six_team_workgroups_every_motor_count_and_contraction_mode(m, mlp):
+    """The six-team workgroup (TeamHex, launches that fill every team slot of the device) exists per motor count (4 / 6 / 8 motor
+    instantiations) and contraction mode; the ticket test covers (4, f32), bench.py's verification (4, f32x3). Here the others, small
+    horizon, 1,700 instances: sampled instances against the oracle, the whole batch against the same launch in two-team workgroups."""
+    from sde4mbrl_px4_amd import prng
+    model = synthetic_multirotor(m, seed=3) if m == 8 else (synthetic_iris() if m == 4 else synthetic_hexa())
+    kw = dict(horizon=7, num_short_dt=4, long_step_dt=0.1, num_particles=70, u_slew_coeff=1.0, max_iter=3, max_no_improvement_iter=3, mlp_dtype=mlp)
+    if m != 4:
+        kw.update(input_id=list(range(m)), input_bound=[[1e-4, 1.0]] * m, uref=[0.42] * m)
+    cfg = MPCConfig(**kw)
+    B, H, P = 1700, cfg.horizon, cfg.num_particles
+    x0 = W.random_initial_states(B, 11)
+    xref = np.stack([W.reference_window(0.05 * (b % 97), cfg.time_steps) for b in range(B)])
+    keys = prng.split(prng.PRNGKey(4), B)
+    S = _solver(cfg, model, B)
+    yk, i0 = S.reset()
+    u0 = np.tile(yk[None], (B, 1, 1))
+    s0 = np.full(B, i0["stepsize"], np.float32)
+    uopt, xevol, info = S.solve_keys(x0, xref, keys, u0, s0)
+    assert f"TeamPairT<6>, {m}, {dict(f32=0, f16=1, f32x3=2)[mlp]}, false, 3, false" in S.last_kernel_name(), S.last_kernel_name()
+    S.set_option("hex", 0)
+    u2, x2, i2 = S.solve_keys(x0, xref, keys, u0, s0)
+    assert "TeamPairT<2>" in S.last_kernel_name() and bits_differ(uopt, u2) == 0 and bits_differ(xevol, x2) == 0 and bits_differ(info, i2) == 0
+    O = orc.Oracle(cfg, model)
+    for b in (0, 5, 1535, 1536, B - 1):
+        uo, xe, io = O.solve(x0[b], xref[b], orc.noise_from_key(keys[b], P, H), u0[b], float(s0[b]))[:3]
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0, b
+    S.close()
+
+
 def test_workspaces_scale_with_team_slots_not_with_the_batch():
     """A persistent throughput launch indexes its trajectory / checkpoint / partial-sum workspaces by team slot (1,536 on an MI355X), not by
     instance: a C2 launch of 98,304 instances (64 rounds of the grid) takes the device memory of its inputs and outputs (15 GB of noise)

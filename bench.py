@@ -165,6 +165,14 @@ def sample_indices(B, slots, n_initial=4, n_drawn=6):
     return sorted(set(idx))
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """one line on stderr per phase: a default run takes minutes and must not look hung to whoever started it"""
+    print(f"[bench {time.perf_counter() - _T0:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def lib_hash():
     """sha256 (first 16 hex digits) of the library the solver loaded: ties profiles/pmc_traffic.json to the build it was measured on"""
     import hashlib
@@ -395,14 +403,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        progress(f"timed leg: {args.warmup} warm-up + {args.steps} timed launches of {B} instances per rank")
     for _ in range(args.warmup):
         L.step()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_step in range(args.steps):
         L.step()
+        if rank == 0 and (i_step + 1) % 8 == 0:
+            progress(f"launch {i_step + 1} of {args.steps} enqueued")      # (asynchronous: no sync inside the timed region)
     sync_all()
     t1 = time.perf_counter()
+    if rank == 0:
+        progress(f"timed leg done: {t1 - t0:.1f} s")
     elapsed = max_over_ranks(t1 - t0, device=dev, force=force_dist)
     # per-launch kernel duration from HIP events, measured live on the launch stream (separate launches)
     ev_ms, n_grad, n_fwd = L.timed_events(min(args.steps, 3))
@@ -456,6 +470,7 @@ def main():
                 solver.solve_status()     # raises if a grid barrier of the cooperative layout gave up (results would be invalid)
             return lat, (solver.last_kernel_name() if lat else None), solver.layout_fallbacks()
 
+        progress(f"single-solve latency: {args.latency_reps} solves")
         if args.mlp_dtype == "f32":
             lat, single_kernel, fallbacks = latency_of(L.solver, args.latency_reps, args.latency_warmup)
             lat_same, same_kernel = lat, single_kernel
@@ -514,6 +529,7 @@ def main():
                 legs = legs[1:]
             iris_blob, hexa_blob = synthetic_iris().to_blob(), synthetic_hexa().to_blob()
             for name, path, mlp, Bl, reps, kw in legs:
+                progress(f"other configuration {name}: {Bl} instances, {reps} timed launch(es)")
                 c2 = cfg_of(path, mlp, **kw)
                 bl = iris_blob if c2.num_motors == 4 else hexa_blob
                 Lg = Leg(c2, bl, Bl, dev_ord)
@@ -553,6 +569,7 @@ def main():
                 others[name] = rec
                 Lg.close()
         V.start()
+        progress("CPU verification of sampled instances started in the background; tolerance modes / CPU baseline next")
         if world == 1 and cfg.math_mode == "exact" and not args.no_tolerance_modes and os.path.basename(args.config).startswith("c2_") and not args.max_iter:
             # The optional tolerance-parity mode on the same instances (a warm-up and a timed launch), never the reported value: solves/s and how
             # far its controls are from this run's bit-reproducible path (north star: 1e-4). SPEC.md 10, DESIGN.md 2.
@@ -573,6 +590,7 @@ def main():
                 s2.close()
             out["tolerance_modes"] = dict(modes, note="same instances, cold-start 200-iteration solves; controls against the bit-reproducible path of this run "
                                                        "(abs + rel 1e-4, the north star's tolerance); optional mode without a CPU oracle, not the reported metric")
+        progress("waiting for the CPU verification threads")
         ver_wall = V.join()
         bad_total = 0
         for leg, r in V.results.items():
@@ -597,6 +615,7 @@ def main():
             raise SystemExit(f"bench.py: outputs of a timed launch differ from the oracle in {bad_total} words")
         do_cpu = not args.no_cpu_baseline and world == 1
         if do_cpu:
+            progress("CPU baseline (about 10 s on every usable core) and the C1 single solve")
             # reported baseline: the particle-vectorised build (f32 fma-chain arithmetic), one solve at a time per thread on every usable core, on
             # 40 instances per thread of the same workload (first instances of the GPU batch; ~10 s of wall time)
             n_cpu = min(40 * nthr, B)

@@ -154,6 +154,51 @@ class Verifier:
         return time.time() - self.t0 if self.t0 else 0.0
 
 
+class PowerSampler(threading.Thread):
+    """Shader clock and package power of one GPU, sampled once a second beside the timed launches (`rocm-smi` as a child process: no
+    HIP context, nothing on the launch path). The C2 throughput launch runs the package AT ITS POWER CAP (profiles/r3_power.txt): the
+    figure that explains the clock the kernel is held at. Any failure (no rocm-smi, unexpected output) leaves the fields null."""
+    def __init__(self, dev_ord):
+        super().__init__(daemon=True)
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        try:
+            self.idx = int(vis.split(",")[dev_ord]) if vis else dev_ord
+        except Exception:
+            self.idx = dev_ord
+        self.samples, self.stop_flag, self.cap = [], threading.Event(), None
+
+    def _smi(self, *flags):
+        import re
+        r = subprocess.run(["rocm-smi", "-d", str(self.idx), *flags], capture_output=True, text=True, timeout=15)
+        return r.stdout, re
+
+    def run(self):
+        try:
+            txt, re = self._smi("--showmaxpower")
+            m = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", txt)
+            self.cap = float(m.group(1)) if m else None
+            while not self.stop_flag.wait(1.0):
+                t = time.perf_counter()
+                txt, re = self._smi("--showpower", "--showclocks")
+                mp = re.search(r"Package Power \(W\): ([\d.]+)", txt)
+                mc = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+                if mp and mc:
+                    self.samples.append((t, float(mc.group(1)), float(mp.group(1))))
+        except Exception:
+            pass
+
+    def summary(self, t0, t1):
+        self.stop_flag.set()
+        sel = [(c, w) for t, c, w in self.samples if t0 + 1.0 <= t <= t1]
+        if not sel:
+            return {"package_power_w_median": None, "sclk_mhz_median": None, "power_cap_w": self.cap, "samples": 0,
+                    "note": "rocm-smi gave no sample inside the timed region"}
+        return {"package_power_w_median": float(np.median([w for _, w in sel])), "sclk_mhz_median": float(np.median([c for c, _ in sel])),
+                "power_cap_w": self.cap, "samples": len(sel),
+                "note": "rank 0's GPU, one rocm-smi sample per second inside the timed region (performance level auto): at the cap the firmware lowers the shader "
+                        "clock (2.4 GHz maximum) until the package fits — solves/s = cap / energy per solve"}
+
+
 def sample_indices(B, slots, n_initial=4, n_drawn=6):
     """Instances of a launch to verify: some of the teams' initial assignments, some that a persistent launch hands out by ticket
     (b >= slots; evenly spread), and the last one."""
@@ -346,6 +391,7 @@ def main():
                          "(SPEC.md 9b), bit-identical to the oracle; f32: every contraction an f32 fma chain; f16: fp16-operand MLP contractions (SPEC.md 9)")
     ap.add_argument("--max-iter", type=int, default=0, help="override the YAML's apg_mpc.max_iter (0: keep; profiling runs of the long-horizon config)")
     ap.add_argument("--no-tolerance-modes", action="store_true", help="skip the extra launches in the tolerance-parity mode (math_mode: fast)")
+    ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (package power, shader clock) beside the timed launches")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary legs (C2 f32 chain, C3, C5 f32 / f16)")
     ap.add_argument("--verify", type=int, default=-1, help="instances of the timed launch checked bit for bit against the CPU oracle "
                     "(-1: a sample across the batch incl. ticket-drawn instances; 0: none)")
@@ -403,6 +449,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sampler = None
+    if rank == 0 and not args.no_power:
+        sampler = PowerSampler(dev_ord)
+        sampler.start()
     if rank == 0:
         progress(f"timed leg: {args.warmup} warm-up + {args.steps} timed launches of {B} instances per rank")
     for _ in range(args.warmup):
@@ -415,8 +465,9 @@ def main():
             progress(f"launch {i_step + 1} of {args.steps} enqueued")      # (asynchronous: no sync inside the timed region)
     sync_all()
     t1 = time.perf_counter()
+    power = sampler.summary(t0, t1) if sampler else None
     if rank == 0:
-        progress(f"timed leg done: {t1 - t0:.1f} s")
+        progress(f"timed leg done: {t1 - t0:.1f} s" + (f"; package {power['package_power_w_median']} W of {power['power_cap_w']}, sclk {power['sclk_mhz_median']} MHz" if power else ""))
     elapsed = max_over_ranks(t1 - t0, device=dev, force=force_dist)
     # per-launch kernel duration from HIP events, measured live on the launch stream (separate launches)
     ev_ms, n_grad, n_fwd = L.timed_events(min(args.steps, 3))
@@ -499,6 +550,7 @@ def main():
                                       "workgroup (the second figure). Both arithmetics are bit-identical to the oracle in their mode and agree with each other to 1e-6 on the controls",
             "p50_batch_latency_ms": float(np.median(ev_ms)),
             "library_build": build,
+            "power": power,
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_build": traffic_build, "kernel": kernel_name, "kernel_ms": k_ms,
                          "note": "algorithmic flops = SURVEY 8d MLP formula x P*H*(2*N_grad+N_ls+2) (N_grad = gradient evaluations actually performed: sdempc_work_counters), "

@@ -184,10 +184,14 @@ def test_handle_options_host_side():
     from sde4mbrl_px4_amd import load_mpc_config
     from sde4mbrl_px4_amd.solver import SdeMpcSolver, SdempcError
     cfg = load_mpc_config(os.path.join(CDIR, "c1_iris_posctrl_h20_p32.yaml"))
-    for k in ("SDEMPC_LANE", "SDEMPC_COOP", "SDEMPC_SPEC", "SDEMPC_PK", "SDEMPC_USTG", "SDEMPC_COOP_LAUNCH", "SDEMPC_COOP_FENCE", "SDEMPC_COOP_SPIN_US"):
+    for k in ("SDEMPC_LANE", "SDEMPC_COOP", "SDEMPC_SPEC", "SDEMPC_PK", "SDEMPC_USTG", "SDEMPC_COOP_LAUNCH", "SDEMPC_COOP_FENCE", "SDEMPC_COOP_SPIN_US", "SDEMPC_HEX", "SDEMPC_DUO"):
         os.environ.pop(k, None)
     S = SdeMpcSolver(cfg, synthetic_iris(), max_batch=2)
     assert [S.get_option(k) for k in ("lane", "coop", "spec", "pk", "ustg", "coop_launch", "coop_fence")] == [1, 1, 1, -1, -1, 0, 0]
+    assert S.get_option("hex") == 1 and S.get_option("duo") == -1          # six-team workgroups for launches that fill the device: on
+    S.set_option("hex", 0); assert S.get_option("hex") == 0; S.set_option("hex", 1)
+    with pytest.raises(SdempcError):
+        S.set_option("hex", 2)
     assert S.get_option("coop_spin_us") == 100_000                       # derived budget before the first cooperative solve: 100 ms
     S.set_option("coop_spin_us", 2500); assert S.get_option("coop_spin_us") == 2500
     S.set_option("pk", 0); S.set_option("ustg", 1); S.set_option("coop", 0); S.set_option("coop_fence", 1)

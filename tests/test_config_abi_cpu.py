@@ -217,6 +217,24 @@ def test_entry_scripts_are_valid_python():
     assert nflops == 3520 * 128 * 50 * (2 * 200 + 375 + 2)
     assert bench.checkpoint_bytes(cfg, 200) == 200 * 2 * 4 * 50 * 1280 * 4
     assert bench.effective_cores() >= 1
+    # the power / clock sampler beside the timed launches: parses rocm-smi's text, keeps only samples inside the timed region, survives a missing tool
+    import subprocess, time, types
+    texts = {"--showmaxpower": "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\n",
+             "--showpower": "GPU[0]\t\t: sclk clock level: 1: (1896Mhz)\nGPU[0]\t\t: Current Socket Graphics Package Power (W): 1399.0\n"}
+    real = subprocess.run
+    try:
+        subprocess.run = lambda cmd, **kw: types.SimpleNamespace(stdout=texts[cmd[3]], returncode=0)
+        ps = bench.PowerSampler(0)
+        t0 = time.perf_counter() - 1.5
+        ps.start(); time.sleep(2.6)
+        r = ps.summary(t0, time.perf_counter())
+        assert r["power_cap_w"] == 1400.0 and r["package_power_w_median"] == 1399.0 and r["sclk_mhz_median"] == 1896.0 and r["samples"] >= 1
+        def missing(cmd, **kw): raise FileNotFoundError("rocm-smi")
+        subprocess.run = missing
+        ps = bench.PowerSampler(0); ps.start(); time.sleep(0.2)
+        assert ps.summary(0.0, 1e9)["samples"] == 0
+    finally:
+        subprocess.run = real
 
 
 def test_product_and_tools_never_touch_the_oracle():

@@ -391,6 +391,7 @@ def main():
                          "(SPEC.md 9b), bit-identical to the oracle; f32: every contraction an f32 fma chain; f16: fp16-operand MLP contractions (SPEC.md 9)")
     ap.add_argument("--max-iter", type=int, default=0, help="override the YAML's apg_mpc.max_iter (0: keep; profiling runs of the long-horizon config)")
     ap.add_argument("--no-tolerance-modes", action="store_true", help="skip the extra launches in the tolerance-parity mode (math_mode: fast)")
+    ap.add_argument("--c4-reps", type=int, default=100, help="N > 1: barrier-aligned ticks of the one-instance-per-GPU leg (BASELINE config 4); 0 skips it")
     ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (package power, shader clock) beside the timed launches")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary legs (C2 f32 chain, C3, C5 f32 / f16)")
     ap.add_argument("--verify", type=int, default=-1, help="instances of the timed launch checked bit for bit against the CPU oracle "
@@ -476,6 +477,39 @@ def main():
     n_it = float(info_h[:, 2].mean())
     n_ls = float(info_h[:, 7].mean())
 
+    # BASELINE config 4 (N > 1 only): ONE instance per GPU, all ranks solving theirs at the same time (barrier-aligned ticks, duration of a
+    # tick = the slowest rank's); f32 latency layouts like the single-GPU p50 (a single instance is a latency problem)
+    c4 = None
+    if use_dist and args.c4_reps > 0:
+        from sde4mbrl_px4_amd.dist import max_over_ranks_each
+        from sde4mbrl_px4_amd.solver import SdeMpcSolver
+        if rank == 0:
+            progress(f"config 4: one instance per GPU, {args.c4_reps} barrier-aligned ticks")
+        s1 = L.solver if args.mlp_dtype == "f32" else SdeMpcSolver(cfg.replace(mlp_dtype="f32"), blob, max_batch=8, device=dev_ord)
+        nv1 = L.noise.view(B, -1)
+        durs, c4_gave_up = [], 0
+        for r in range(-3, args.c4_reps):
+            i = (r + 3) % B
+            sync_all()
+            t = time.perf_counter()
+            s1.solve_dev(1, L.x0[i:].data_ptr(), L.xref[i:].data_ptr(), nv1[i:].data_ptr(), L.u0[i:].data_ptr(), L.step_in[i:].data_ptr(),
+                         L.uopt[i:].data_ptr(), L.xevol[i:].data_ptr(), L.info[i:].data_ptr(), L.stream)
+            torch.cuda.synchronize()
+            if r >= 0:
+                durs.append((time.perf_counter() - t) * 1e3)
+            try:
+                s1.solve_status()
+            except Exception:       # a grid barrier gave up (the GPU is shared with another rank: test boxes only): the handle continues in the tile layout
+                c4_gave_up += 1
+        c4_kernel, c4_fallbacks = s1.last_kernel_name(), s1.layout_fallbacks()
+        if s1 is not L.solver:
+            s1.close()
+        ticks = max_over_ranks_each(durs, device=dev, force=force_dist)
+        c4 = {"instances": world, "ticks": len(ticks), "p50_tick_ms": float(np.median(ticks)), "p95_tick_ms": float(np.percentile(ticks, 95)),
+              "value": world / (float(np.median(ticks)) * 1e-3), "unit": "solves/s", "kernel": c4_kernel, "layout_fallbacks_rank0": c4_fallbacks, "barrier_give_ups_rank0": c4_gave_up, "mlp_dtype": "f32",
+              "note": "BASELINE config 4: one Iris H=50 P=128 instance per GPU (random initial states), every rank solving its own at the same time; a tick "
+                      "lasts as long as its slowest rank; no data-path collective (the weights were broadcast once at start)"}
+
     if rank == 0:
         solves = world * B * args.steps
         value = solves / elapsed
@@ -551,6 +585,7 @@ def main():
             "p50_batch_latency_ms": float(np.median(ev_ms)),
             "library_build": build,
             "power": power,
+            "c4_one_instance_per_gpu": c4,
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_build": traffic_build, "kernel": kernel_name, "kernel_ms": k_ms,
                          "note": "algorithmic flops = SURVEY 8d MLP formula x P*H*(2*N_grad+N_ls+2) (N_grad = gradient evaluations actually performed: sdempc_work_counters), "

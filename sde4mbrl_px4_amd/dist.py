@@ -52,6 +52,16 @@ def max_over_ranks(value: float, device=None, force: bool = False) -> float:
     return float(t.item())
 
 
+def max_over_ranks_each(values, device=None, force: bool = False):
+    """Element-wise maximum over ranks of equally long sequences (e.g. per-tick durations of barrier-aligned ticks)."""
+    import torch
+    if not is_distributed(force):
+        return [float(v) for v in values]
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    _dist().all_reduce(t, op=_dist().ReduceOp.MAX)
+    return [float(v) for v in t.cpu().numpy()]
+
+
 def gather_rows(local: np.ndarray, device=None) -> np.ndarray:
     """Concatenate per-rank result rows (e.g. uopt [b, H, m]) in rank order on every rank (reporting only)."""
     import torch

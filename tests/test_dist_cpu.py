@@ -31,8 +31,10 @@ u = np.full((6, 4), 0.71, np.float32)
 costs = np.array([[O.rollout(x0[i], u, W.reference_window(0.0, cfg.time_steps), noise[i])[0]] for i in range(hi - lo)], np.float32)
 allc = gather_rows(costs)
 tmax = max_over_ranks(1.0 + rank)
+from sde4mbrl_px4_amd.dist import max_over_ranks_each
+ticks = max_over_ranks_each([1.0 + rank, 5.0 - 3 * rank, 2.0])       # per-tick durations of barrier-aligned ticks: the slowest rank's each
 if rank == 0:
-    print(json.dumps({"n": int(allc.shape[0]), "costs": [float(c) for c in allc[:, 0]], "tmax": tmax, "bloblen": len(blob)}))
+    print(json.dumps({"n": int(allc.shape[0]), "costs": [float(c) for c in allc[:, 0]], "tmax": tmax, "ticks": ticks, "bloblen": len(blob)}))
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -61,7 +63,7 @@ def test_two_rank_gloo_broadcast_shard_gather(tmp_path):
     outs = [p.communicate(timeout=240) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     res = json.loads(outs[0][0].strip().splitlines()[-1])
-    assert res["n"] == 7 and res["tmax"] == 2.0 and res["bloblen"] == 4 * (16 + 2120)
+    assert res["n"] == 7 and res["tmax"] == 2.0 and res["ticks"] == [2.0, 5.0, 2.0] and res["bloblen"] == 4 * (16 + 2120)
     # single-process reference: same instances, same order
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc

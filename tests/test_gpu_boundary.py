@@ -136,7 +136,7 @@ def test_bench_two_ranks_self_started_on_one_gpu():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "64", "--max-iter", "12",
-                          "--latency-reps", "2", "--latency-warmup", "1", "--no-cpu-baseline", "--verify", "2"],
+                          "--latency-reps", "2", "--latency-warmup", "1", "--no-cpu-baseline", "--verify", "2", "--c4-reps", "6"],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -147,6 +147,8 @@ def test_bench_two_ranks_self_started_on_one_gpu():
     assert rec["verified_instances"] == 2 and rec["verified_bit_exact"] is True
     assert rec["roofline"]["frac"] > 0 and rec["roofline"]["kernel_ms"] > 0
     assert rec["cpu_baseline"].startswith("skipped")                      # stated, not silently absent, in N > 1 lines
+    c4 = rec["c4_one_instance_per_gpu"]                                   # BASELINE config 4: one instance per rank, barrier-aligned ticks
+    assert c4["instances"] == 2 and c4["ticks"] == 6 and c4["p50_tick_ms"] > 0 and c4["value"] > 0
 
 
 def test_bench_rccl_branch_on_one_gpu():
@@ -167,6 +169,7 @@ def test_bench_rccl_branch_on_one_gpu():
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["verified_bit_exact"] is True
+    assert rec["c4_one_instance_per_gpu"]["instances"] == 1 and rec["c4_one_instance_per_gpu"]["barrier_give_ups_rank0"] == 0      # (max over ranks through RCCL)
     # the process really loaded RCCL and ran collectives on it
     chk = subprocess.run([sys.executable, "-c", "import torch, torch.distributed as d, os; d.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0)); "
                           "t = torch.ones(4, device='cuda'); d.all_reduce(t); d.broadcast(t, src=0); d.barrier(); print(d.get_backend(), float(t.sum())); d.destroy_process_group()"],

@@ -115,24 +115,29 @@ class Verifier:
 
     def add(self, leg, cfg, blob, idx, x0, xref, keys, u0, s0, got):
         """got: (uopt, xevol, info) host arrays of the WHOLE batch; idx: instances to check"""
-        for i in idx:
-            self.jobs.append((leg, cfg, blob, int(i), x0[i], xref[i], keys[i], u0[i], s0, got[0][i].copy(), got[1][i].copy(), got[2][i].copy()))
-        self.results.setdefault(leg, {"idx": [int(i) for i in idx], "bad_words": 0, "done": 0, "cpu_s": 0.0})
+        with self.lock:
+            self.results.setdefault(leg, {"idx": [int(i) for i in idx], "bad_words": 0, "done": 0, "cpu_s": 0.0})
+            for i in idx:
+                self.jobs.append((leg, cfg, blob, int(i), x0[i], xref[i], keys[i], u0[i], s0, got[0][i].copy(), got[1][i].copy(), got[2][i].copy()))
+            if self.threads:
+                self.cv.notify_all()
 
     def start(self):
+        """start the workers; jobs added later are picked up too, until close()"""
         orc = cpu_oracle()
         self.t0 = time.time()
-        jobs = list(self.jobs)
-        nxt = [0]
+        self.cv, self.closed, self.nxt = threading.Condition(self.lock), False, 0
         oracles = {}
 
         def work(tid):
             while True:
-                with self.lock:
-                    j = nxt[0]; nxt[0] += 1
-                if j >= len(jobs):
-                    return
-                leg, cfg, blob, i, x0, xref, key, u0, s0, gu, gx, gi = jobs[j]
+                with self.cv:
+                    while self.nxt >= len(self.jobs) and not self.closed:
+                        self.cv.wait()
+                    if self.nxt >= len(self.jobs):
+                        return
+                    job = self.jobs[self.nxt]; self.nxt += 1
+                leg, cfg, blob, i, x0, xref, key, u0, s0, gu, gx, gi = job
                 with self.lock:
                     O = oracles.get((tid, leg))
                 if O is None:
@@ -150,6 +155,12 @@ class Verifier:
         [t.start() for t in self.threads]
 
     def join(self):
+        """no more jobs: wait for the queue to drain"""
+        if not self.threads:
+            return 0.0
+        with self.cv:
+            self.closed = True
+            self.cv.notify_all()
         [t.join() for t in self.threads]
         return time.time() - self.t0 if self.t0 else 0.0
 
@@ -605,6 +616,8 @@ def main():
         if args.verify != 0:
             idx = sample_indices(B, L.slots()) if args.verify < 0 else list(range(min(args.verify, B)))
             V.add("main", cfg, blob, idx, L.x0_h, L.xref_h, L.keys, L.u0_h, L.s0, (uopt_h, xevol_h, info_h))
+            V.start()                          # (after the latency loop, whose host timestamps must not compete with the checker threads; beside every leg below)
+            progress(f"CPU verification of {len(idx)} instances of the timed launch started in the background")
         others = {}
         if world == 1 and not args.no_other_configs and os.path.basename(args.config).startswith("c2_") and not args.max_iter:
             cdir = os.path.join(ROOT, "configs")
@@ -655,8 +668,6 @@ def main():
                         rec["verified_how"] = "the timed full-length launch, bit for bit"
                 others[name] = rec
                 Lg.close()
-        V.start()
-        progress("CPU verification of sampled instances started in the background; tolerance modes / CPU baseline next")
         if world == 1 and cfg.math_mode == "exact" and not args.no_tolerance_modes and os.path.basename(args.config).startswith("c2_") and not args.max_iter:
             # The optional tolerance-parity mode on the same instances (a warm-up and a timed launch), never the reported value: solves/s and how
             # far its controls are from this run's bit-reproducible path (north star: 1e-4). SPEC.md 10, DESIGN.md 2.

@@ -217,6 +217,25 @@ def test_entry_scripts_are_valid_python():
     assert nflops == 3520 * 128 * 50 * (2 * 200 + 375 + 2)
     assert bench.checkpoint_bytes(cfg, 200) == 200 * 2 * 4 * 50 * 1280 * 4
     assert bench.effective_cores() >= 1
+    # the background checker of timed launches: a live queue (jobs added after the start are picked up), mismatching words are counted
+    import orc
+    from sde4mbrl_px4_amd import MPCConfig as _Cfg, synthetic_iris as _iris, prng as _prng
+    from sde4mbrl_px4_amd import workload as _W
+    vc = _Cfg(horizon=6, num_short_dt=6, num_particles=16, u_slew_coeff=1.0, max_iter=3, max_no_improvement_iter=3)
+    vb = _iris().to_blob()
+    vx0 = _W.random_initial_states(5, 0); vxr = np.stack([_W.reference_window(0.0, vc.time_steps)] * 5)
+    vk = _prng.split(_prng.PRNGKey(1), 5); vu0 = np.tile(np.asarray(vc.uref, np.float32), (5, 6, 1))
+    vO = orc.Oracle(vc, vb)
+    vo = [vO.solve(vx0[b], vxr[b], orc.noise_from_key(vk[b], 16, 6), vu0[b], 0.01)[:3] for b in range(5)]
+    got = tuple(np.stack([o[k] for o in vo]) for k in range(3))
+    V = bench.Verifier(3)
+    V.add("main", vc, vb, [0, 2], vx0, vxr, vk, vu0, 0.01, got)
+    V.start()
+    wrong = (got[0].copy(), got[1], got[2]); wrong[0][4, 0, 0] += 1e-3
+    V.add("late", vc, vb, [1, 4], vx0, vxr, vk, vu0, 0.01, wrong)
+    V.join()
+    assert V.results["main"] == dict(V.results["main"], bad_words=0, done=2) and V.results["late"]["bad_words"] == 1 and V.results["late"]["done"] == 2
+    assert bench.Verifier(2).join() == 0.0                                   # never started (--verify 0)
     # the power / clock sampler beside the timed launches: parses rocm-smi's text, keeps only samples inside the timed region, survives a missing tool
     import subprocess, time, types
     texts = {"--showmaxpower": "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\n",

@@ -1124,6 +1124,14 @@ static hipError_t launch_duo(const KArgs& a, hipStream_t st) {
     if (a.m == 6) return launch_duo_m<TeamBlock, 6, F16>(a, st);
     return launch_duo_m<TeamBlock, 8, F16>(a, st);
 }
+// duo = auto, up to four groups: does a batch of B fit resident with one group per wave (launch_solve_team, solve_workspace_rows)?
+static bool one_group_per_wave_batch(const KArgs& a, int B) {
+    if (a.opt.duo >= 0 || a.G > 4) return false;
+    const bool gtab = use_global_ust(a.H, a.m, a.opt) && a.ustg;
+    size_t per_cu = (156 * 1024) / smem_bytes(a.H, a.m, 1, false, !gtab);
+    if (per_cu > 3) per_cu = 3;
+    return (size_t)B <= per_cu * (size_t)(a.opt.cus > 0 ? a.opt.cus : 256);
+}
 template <class Team, int F16>
 static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
     if constexpr (F16 == 0 && !FAST) {
@@ -1145,7 +1153,11 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
     }
     if constexpr (Team::IPB == 1) {
         // auto: every multi-group instance (measured, same box: C2 +1.3 %, C3 +4.4 %, C5 +7.5 % over one group per wave)
-        if (a.G >= 2 && a.opt.duo != 0) return launch_duo<F16>(a, st);
+        // Batches that one 32-particle group per wave holds resident at once (three four-wave workgroups per CU: B <= 3 x CUs at C2) run
+        // that way: four waves per instance instead of the duo layout's two, i.e. the shorter chain per instance and twice the waves per
+        // CU (same box, C2 f32x3: B = 1..256 149 against 245 ms per launch, 512 189 / 260, 768 273 / 306; from 1,024 on the duo layout's
+        // 1,536 resident instances win: 383 / 343)
+        if (a.G >= 2 && a.opt.duo != 0 && !one_group_per_wave_batch(a, a.B)) return launch_duo<F16>(a, st);
         // long horizons: with the control table in LDS only two workgroups fit a CU; without it three do (the kernel is built for three)
         if (use_global_ust(a.H, a.m, a.opt) && a.ustg) {
             if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16, false, 0, true>, a, st, 1, Team::BNT, false);
@@ -1267,6 +1279,7 @@ int solve_workspace_rows(const KArgs& k, int B) {
         const bool pk = k.opt.pk >= 0 ? k.opt.pk == 1 : B <= k.opt.cus;
         if (pk) return B;
     }
+    if (one_group_per_wave_batch(k, B)) return B;      // (launch_solve_team: batches that fit resident with one group per wave)
     if (k.G >= 2 && k.opt.duo != 0) {       // (team slots come in workgroups of up to two teams: an odd batch leaves the last slot idle but counted; six-team workgroups only run full)
         const int slots = 6 * (k.opt.cus > 0 ? k.opt.cus : 256), even = (B + 1) & ~1;
         return even < slots ? even : slots;

@@ -424,10 +424,11 @@ def _check_bit_exact(cfg, model, B, seed, **options):
 
 @pytest.mark.parametrize("mlp", ["f16", "f32x3"])
 @pytest.mark.parametrize("H,P,m,opts", [
-    (24, 70, 4, dict()),                       # three groups: a duo pair without a group B; small batch -> packed-tanh / latency instantiation is f32-only, tile layout here
-    (12, 128, 4, dict(pk=0)),                  # C2 geometry: TeamPair duo throughput instantiation
+    (24, 70, 4, dict()),                       # three groups, small batch: the packed-tanh latency instantiation is f32-only; one group per wave here (batch fits resident)
+    (24, 70, 4, dict(duo=1)),                  # the same in the duo layout: a pair without a group B
+    (12, 128, 4, dict(pk=0, duo=1)),           # C2 geometry: TeamPair duo throughput instantiation
     (12, 128, 4, dict(pk=0, duo=0)),           # one group per wave
-    (9, 33, 6, dict(pk=0)),                    # six rotors, ragged second group
+    (9, 33, 6, dict(pk=0, duo=1)),             # six rotors, ragged second group
     (7, 300, 4, dict(pk=0, ustg=1)),           # ten groups on four waves, control table in global memory
     (16, 32, 4, dict()),                       # one group: one wave per instance (TeamWave)
 ])
@@ -655,8 +656,8 @@ def test_global_control_table_instantiation_bit_exact(H, P, m):
 
 
 # ---- every single-GPU BASELINE config at FULL size, in the kernel instantiation the bench times ---------------------------------------
-# A batch larger than the number of CUs makes launch_solve_team pick the throughput instantiation by itself (three waves per SIMD, scalar
-# tanh; for P > 32 the duo layout, template MODE 3 / 4: sdempc_solve_kernel<TeamPair | TeamBlock, m, F16, false, 3 | 4, USTG> — the kernel `bench.py`
+# A batch larger than one group per wave holds resident (three workgroups per CU: 768 instances at C2) makes launch_solve_team pick the
+# throughput instantiation by itself (three waves per SIMD, scalar tanh; for P > 32 the duo layout, template MODE 3 / 4: sdempc_solve_kernel<TeamPair | TeamBlock, m, F16, false, 3 | 4, USTG> — the kernel `bench.py`
 # names in roofline.kernel, read back from the HIP runtime through sdempc_last_kernel_name), with no option forced.
 def _full_size_case(cfg_name, B, iters, mlp="f32", sample=(0, 1), seed=0, stepsize=None, math="exact"):
     from sde4mbrl_px4_amd import prng
@@ -691,7 +692,7 @@ def _full_size_case(cfg_name, B, iters, mlp="f32", sample=(0, 1), seed=0, stepsi
 
 
 @pytest.mark.parametrize("cfg_name,B,iters,sample", [
-    ("c2_iris_traj_h50_p128.yaml", 512, 10, (0, 100, 255, 256, 300, 511)),      # C2: the bench workload (four particle groups = four waves)
+    ("c2_iris_traj_h50_p128.yaml", 1024, 10, (0, 100, 255, 256, 300, 1023)),    # C2: the bench workload (four particle groups: two per wave in the duo layout)
     ("c3_hexa_traj_h50_p256.yaml", 320, 6, (0, 257, 319)),                      # C3: six rotors, eight particle groups on four waves
     ("c1_iris_posctrl_h20_p32.yaml", 1280, 20, (0, 1025, 1279)),                # C1 geometry: one wave per instance, four instances per workgroup
 ])
@@ -702,10 +703,40 @@ def test_baseline_configs_full_size_throughput_kernel_bit_exact(cfg_name, B, ite
         assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0, b
 
 
+@pytest.mark.parametrize("mlp", ["f32", "f32x3"])
+def test_batches_that_fit_resident_run_one_group_per_wave(mlp):
+    """launch_solve_team: an instance of up to four particle groups runs two groups per wave in the duo layout only when the batch is larger
+    than one group per wave holds resident (three four-wave workgroups per CU); below that the four-waves-per-instance tile layout is the
+    shorter chain (C2: 149 against 245 ms per launch up to 256 instances). Same bits either way, and the oracle's."""
+    from sde4mbrl_px4_amd import prng
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(max_iter=6, max_no_improvement_iter=6, mlp_dtype=mlp)
+    model = synthetic_iris()
+    B, H, P = 300, cfg.horizon, cfg.num_particles
+    x0 = W.random_initial_states(B, 5)
+    xref = np.stack([W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(B)])
+    keys = prng.split(prng.PRNGKey(12), B)
+    S = _solver(cfg, model, B)
+    assert S.get_option("device_cus") < B <= 3 * S.get_option("device_cus")
+    yk, i0 = S.reset()
+    u0 = np.tile(yk[None], (B, 1, 1))
+    s0 = np.full(B, i0["stepsize"], np.float32)
+    uopt, xevol, info = S.solve_keys(x0, xref, keys, u0, s0)
+    kn = S.last_kernel_name()
+    assert "TeamBlock," in kn and "TeamPairT" not in kn and ", false, 0, false" in kn, kn
+    S.set_option("duo", 1)
+    u2, x2, i2 = S.solve_keys(x0, xref, keys, u0, s0)
+    assert "TeamPairT<2>" in S.last_kernel_name() and bits_differ(uopt, u2) == 0 and bits_differ(xevol, x2) == 0 and bits_differ(info, i2) == 0
+    O = orc.Oracle(cfg, model)
+    for b in (0, 299):
+        uo, xe, io = O.solve(x0[b], xref[b], orc.noise_from_key(keys[b], P, H), u0[b], float(s0[b]))[:3]
+        assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0, b
+    S.close()
+
+
 def test_c2_full_size_fast_math_mode_in_the_duo_layout_within_tolerance():
     """`math_mode: fast` (hardware transcendentals, SPEC.md §10) runs the same duo throughput kernels as the exact mode (namespace fastm): full-size
     C2, B > CUs, against the exact oracle within the north star's 1e-4 on the controls, identical line-search decisions."""
-    uopt, xevol, info, res = _full_size_case("c2_iris_traj_h50_p128.yaml", 512, 30, sample=(0, 300, 511), math="fast")
+    uopt, xevol, info, res = _full_size_case("c2_iris_traj_h50_p128.yaml", 1024, 30, sample=(0, 300, 1023), math="fast")
     for b, (uo, xe, io) in res:
         np.testing.assert_allclose(uopt[b], uo, rtol=RTOL, atol=1e-5)
         np.testing.assert_allclose(info[b, 5:7], io[5:7], rtol=2e-5)
@@ -827,7 +858,7 @@ def test_c5_full_size_solve_bit_exact(mlp):
 
 
 @pytest.mark.parametrize("cfg_name,B,iters,sample", [
-    ("c2_iris_traj_h50_p128.yaml", 512, 10, (0, 257, 511)),                     # C2: the bench workload in the f32x3 mode bench.py reports
+    ("c2_iris_traj_h50_p128.yaml", 1024, 10, (0, 257, 1023)),                   # C2: the bench workload in the f32x3 mode bench.py reports
     ("c3_hexa_traj_h50_p256.yaml", 320, 4, (319,)),
 ])
 def test_baseline_configs_full_size_f32x3_bit_exact(cfg_name, B, iters, sample):

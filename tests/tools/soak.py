@@ -12,7 +12,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bad = 0; nonfinite = 0; t0 = time.time()
 LAYOUTS = [("auto", {}), ("coop", {"spec": 0}), ("coop-rt", {"coop_launch": 1}), ("auto-fence", {"coop_fence": 1}), ("coop-fence", {"spec": 0, "coop_fence": 1}),
-           ("tile-pk", {"coop": 0, "pk": 1}), ("tile", {"coop": 0, "pk": 0}), ("tile-gtab", {"coop": 0, "pk": 0, "ustg": 1}),
+           ("tile-pk", {"coop": 0, "pk": 1}), ("tile", {"coop": 0, "pk": 0}), ("tile-duo", {"coop": 0, "pk": 0, "duo": 1}), ("tile-gtab", {"coop": 0, "pk": 0, "ustg": 1, "duo": 1}),
            ("tile-nolane", {"coop": 0, "lane": 0, "pk": 0}), ("tile-noduo", {"coop": 0, "pk": 0, "duo": 0}), ("tile-noduo-gtab", {"coop": 0, "pk": 0, "duo": 0, "ustg": 1})]
 MLPS = (sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32", "f32", "f16", "f32x3", "f32x3"])     # contraction modes to draw from (SPEC.md 9, 9b): all bit-exact
 used = {}

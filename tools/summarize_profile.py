@@ -22,7 +22,13 @@ os.makedirs(out, exist_ok=True)
 
 def counters(pattern, kname):
     acc = collections.defaultdict(float); calls = collections.defaultdict(int)
+    files = collections.defaultdict(list)
     for f in glob.glob(os.path.join(a.src, pattern, "*", "*_counter_collection.csv")):
+        files[os.path.dirname(f)].append(f)
+    for d, fs in files.items():       # gpurun MERGES a call's files into gpurun_out/: an earlier call's passes may still lie beside the new ones — newest only
+        if len(fs) > 1:
+            print(f"note: {len(fs)} runs in {d}, using the newest", file=sys.stderr)
+        f = max(fs, key=os.path.getmtime)
         for r in csv.DictReader(open(f)):
             if kname in r["Kernel_Name"]:
                 acc[r["Counter_Name"]] += float(r["Counter_Value"]); calls[r["Counter_Name"]] += 1
@@ -30,7 +36,7 @@ def counters(pattern, kname):
 
 ks = glob.glob(os.path.join(a.src, "trace", "*", "*kernel_stats.csv"))
 if ks:
-    shutil.copy(ks[0], os.path.join(out, f"{a.tag}_kernel_stats.csv"))
+    shutil.copy(max(ks, key=os.path.getmtime), os.path.join(out, f"{a.tag}_kernel_stats.csv"))
 log = os.path.join(a.src, "bench_trace.log")
 bench = None
 if os.path.exists(log):

@@ -1107,8 +1107,8 @@ template <int M, int F16>
 static hipError_t launch_duo_small(const KArgs& a, hipStream_t st) {
     // a launch that fills every team slot of the device anyway: one twelve-wave workgroup of six teams per CU
     const int cus = a.opt.cus > 0 ? a.opt.cus : 256;
-    if (a.opt.ustg != 1 && a.opt.hex != 0 && a.B >= 6 * cus && smem_bytes(a.H, a.m, 6, false, true, 12) <= 156 * 1024)
-        return launch_persistent(sdempc_solve_kernel<TeamHex, M, F16, false, 3, false>, a, st, 12, TeamHex::BNT, true, 6);
+    if (a.opt.ustg != 1 && a.opt.hex != 0 && a.B >= 6 * cus && smem_bytes(a.H, a.m, TeamHex::IPB, false, true, 2 * TeamHex::IPB) <= 156 * 1024)
+        return launch_persistent(sdempc_solve_kernel<TeamHex, M, F16, false, 3, false>, a, st, 2 * TeamHex::IPB, TeamHex::BNT, true, TeamHex::IPB);
     if (a.opt.ustg != 1 && smem_bytes(a.H, a.m, 2, false, true, 4) * 3 <= 156 * 1024)
         return launch_persistent(sdempc_solve_kernel<TeamPair, M, F16, false, 3, false>, a, st, 4, TeamPair::BNT, true, 2);
     return launch_duo_m<TeamBlock2, M, F16>(a, st);

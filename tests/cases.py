@@ -24,6 +24,11 @@ def golden_cases():
         "c3_hexa_h10_p33_small": (c3.replace(horizon=10, num_short_dt=6, long_step_dt=0.1, num_particles=33, max_iter=15,
                                              max_no_improvement_iter=15, discount=0.97), synthetic_hexa(), 7, 1.3, False),
         "iris_shipped_h20_p1": (sh.replace(max_iter=30, max_no_improvement_iter=30), synthetic_iris(), 11, 0.2, False),
+        # the matrix-pipe contraction modes (SPEC.md §9, §9b): the oracle evaluates them through its model of the instruction (§9a)
+        "c2_traj_h12_p40_f32x3": (c2.replace(horizon=12, num_short_dt=12, num_particles=40, max_iter=25, max_no_improvement_iter=25, mlp_dtype="f32x3"),
+                                  synthetic_iris(), 5, 0.7, False),
+        "c3_hexa_h10_p33_f16": (c3.replace(horizon=10, num_short_dt=6, long_step_dt=0.1, num_particles=33, max_iter=15,
+                                           max_no_improvement_iter=15, discount=0.97, mlp_dtype="f16"), synthetic_hexa(), 7, 1.3, False),
     }
 
 

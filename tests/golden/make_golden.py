@@ -7,7 +7,7 @@ installable here, and the reference holds no tests or fixtures.
 oracle itself against drift and give the GPU tests fixed inputs/outputs; they do not pin parity with
 the original JAX path (parity unpinned).
 
-Usage: python tests/golden/make_golden.py   (rewrites the .npz files next to this script)
+Usage: python tests/golden/make_golden.py [name ...]   (rewrites the .npz files next to this script; all cases, or the named ones)
 """
 import os
 import sys
@@ -50,7 +50,8 @@ def case(name, cfg, model, seed, curr_t=0.0, pos=False, u_pert=0.1, trace=True):
 
 def main():
     for name, (cfg, model, seed, curr_t, pos) in golden_cases().items():
-        case(name, cfg, model, seed, curr_t=curr_t, pos=pos)
+        if len(sys.argv) < 2 or name in sys.argv[1:]:
+            case(name, cfg, model, seed, curr_t=curr_t, pos=pos)
 
 
 if __name__ == "__main__":

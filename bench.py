@@ -462,7 +462,7 @@ def main():
         torch.cuda.synchronize()
 
     sampler = None
-    if rank == 0 and not args.no_power:
+    if not args.no_power:              # every rank samples its own GPU; rank 0's figures are reported, the spread over the ranks beside them
         sampler = PowerSampler(dev_ord)
         sampler.start()
     if rank == 0:
@@ -478,6 +478,13 @@ def main():
     sync_all()
     t1 = time.perf_counter()
     power = sampler.summary(t0, t1) if sampler else None
+    if power is not None and use_dist:
+        # the ranks' medians side by side (a node whose GPUs all sit at their caps may be held lower as a whole: the spread shows it)
+        from sde4mbrl_px4_amd.dist import max_over_ranks_each
+        c_, w_ = power["sclk_mhz_median"], power["package_power_w_median"]
+        have = c_ is not None and w_ is not None
+        ext = max_over_ranks_each([c_ if have else -1e30, -(c_ if have else 1e30), w_ if have else -1e30, -(w_ if have else 1e30)], device=dev, force=force_dist)
+        power["over_ranks"] = {"sclk_mhz_median_max": ext[0], "sclk_mhz_median_min": -ext[1], "package_power_w_median_max": ext[2], "package_power_w_median_min": -ext[3]} if ext[0] > -1e29 and ext[1] > -1e29 else None
     if rank == 0:
         progress(f"timed leg done: {t1 - t0:.1f} s" + (f"; package {power['package_power_w_median']} W of {power['power_cap_w']}, sclk {power['sclk_mhz_median']} MHz" if power else ""))
     elapsed = max_over_ranks(t1 - t0, device=dev, force=force_dist)

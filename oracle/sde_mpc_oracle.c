@@ -223,6 +223,25 @@ static void x3_contract(const int32_t (*Wm)[HID][2][16], const int32_t (*Wx)[HID
         out[i] = acc;
     }
 }
+/* Test entry (tests/test_mfma16_model_cpu.py): one 32x32 contraction out[i] = c[i] + sum_k W[i][k] v[k] on caller-supplied operands, in the
+ * f32 fma chain of SPEC.md §4 (mode 0) or as the twelve instructions of §9b (mode 2) — the two arithmetics of layer 2, without a model around them */
+void NAME(contract32)(int mode, const float* W, const float* v, const float* c, float* out) {
+    if (mode == 2) {
+        static int32_t Wm[3][HID][2][16], Wx[3][HID][2][16];
+        for (int i = 0; i < HID; ++i) for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k) {
+            uint16_t lb[3];
+            bf16_limbs(W[i * HID + slot_unit(hf, k)], lb);
+            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); Wm[l][i][hf][k] = o.m; Wx[l][i][hf][k] = o.ex; }
+        }
+        x3_contract(Wm, Wx, v, c, out);
+        return;
+    }
+    for (int i = 0; i < HID; ++i) {
+        float acc = c ? c[i] : 0.0f;
+        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { const int k = (r & 3) + 8 * (r >> 2) + 4 * h; acc = fmaf(W[i * HID + k], v[k], acc); }
+        out[i] = acc;
+    }
+}
 #endif
 
 static int parse_blob(const void* blob, model_t* M, int f16) {

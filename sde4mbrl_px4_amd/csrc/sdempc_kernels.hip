@@ -1011,6 +1011,20 @@ SDEMPC_DUO_TEAM(SDEMPC_DUO_DECL, TeamBlock)
 
 #include "sdempc_spec.inc.h"
 
+#if SDEMPC_DEV_KERNEL
+// Development aid (tools/dev_isa.sh): only ONE latency kernel is instantiated, device side only, so that a change to the lane-layout step can
+// be compiled to ISA and counted in seconds instead of the four minutes of the whole translation unit. Never part of a build.
+#if SDEMPC_DEV_KERNEL == 1
+template __global__ void sdempc_solve_spec_kernel<4, false>(KArgs);
+#elif SDEMPC_DEV_KERNEL == 2
+template __global__ void sdempc_solve_spec_kernel<4, true>(KArgs);
+#elif SDEMPC_DEV_KERNEL == 3
+template __global__ void sdempc_solve_kernel<TeamBlock, 4, false, true, 2>(KArgs);
+#elif SDEMPC_DEV_KERNEL == 4
+template __global__ void sdempc_solve_kernel<TeamWave, 4, false, false, 1>(KArgs);
+#endif
+}  // namespace exact
+#else
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -1377,6 +1391,7 @@ hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int 
     return exact::launch_relayout(to_dev, in, out, B, P, G, C, st);
 }
 #endif
+#endif  // SDEMPC_DEV_KERNEL
 #endif  // SDEMPC_TU == 0
 
 }  // namespace sdempc

@@ -64,6 +64,7 @@ struct LaneW {
     float w3nk;          // w3n[k]
     float wo[16];        // this lane's output half-chain: W3[c][koff(r) + 4 hs] (lanes c + 8 hs, c < 6), w3n[..] (c == 6), else 0
     float wz[32];        // this lane's adjoint half-chain: positions 0..15 density units, 16..31 drift units
+    float bo;            // bias of this lane's output chain: b3[c] (lanes c < 6), b3n (lane 6), else 0
     int obase, zbase;    // first source lane of the chains (4 hs, +32 for the density output chain)
     bool is_u;           // gu-bar chain (lanes 16..31): skips the density positions
 };
@@ -82,6 +83,7 @@ DI void load_lane_weights(const KArgs& a, LaneW& W, int lane) {
     W.w3nk = w[OFF_W3N + k];
     const int c = lane & 7, hs = (lane >> 3) & 1;
     const bool row0 = lane < 16, row1 = lane >= 16 && lane < 32;
+    W.bo = lane < 6 ? a.M.b3[lane < 6 ? lane : 0] : lane == 6 ? a.M.b3n : 0.0f;
     W.obase = (row0 && c == 6) ? 32 + 4 * hs : 4 * hs;
     W.zbase = 4 * hs;
     W.is_u = row1;
@@ -100,27 +102,37 @@ DI void load_lane_weights(const KArgs& a, LaneW& W, int lane) {
 }
 
 // SPEC.md §3.4 tanh4 with the four values of a group in the four lanes of a DPP quad
-DI float lane_tanh(float av, int lane) {
+// (quad broadcasts without an initialised destination: every lane of a quad_perm is valid; the per-lane pick of r_q is two bit-field
+// selects on lane masks — left to `?:` the compiler built EXEC-mask regions around the multiplications: ten scalar instructions per call,
+// and for a lone wave every instruction, scalar ones included, costs five cycles of issue time)
+template <int CTRL>
+DI float dppq_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); }
+DI float sel_f(float a, float b, unsigned m) {      // m all ones: a, zero: b   (v_bfi_b32)
+    return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
+}
+struct LaneSel { unsigned q1, q2; };                // all ones where lane & 1 / lane & 2
+DI LaneSel lane_sel(int lane) { LaneSel s; s.q1 = (lane & 1) ? ~0u : 0u; s.q2 = (lane & 2) ? ~0u : 0u; return s; }
+DI float lane_tanh(float av, const LaneSel& ls) {
     const float d = 1.0f + exp2_spec(clampf(av, -9.0f, 9.0f), 2.885390043258667f);
-    const float d0 = dpp_f<0x00>(d), d1 = dpp_f<0x55>(d), d2 = dpp_f<0xAA>(d), d3 = dpp_f<0xFF>(d);
+    const float d0 = dppq_f<0x00>(d), d1 = dppq_f<0x55>(d), d2 = dppq_f<0xAA>(d), d3 = dppq_f<0xFF>(d);
     const float p2 = d0 * d1, p3 = p2 * d2, p4 = p3 * d3;
     float r = rcp_spec(p4);
     const float r3 = r * p3; r = r * d3;
     const float r2 = r * p2; r = r * d2;
     const float r1 = r * d0;
     const float r0 = r * d1;
-    const int q = lane & 3;
-    const float rq = (q & 2) ? ((q & 1) ? r3 : r2) : ((q & 1) ? r1 : r0);
+    const float rq = sel_f(sel_f(r3, r2, ls.q1), sel_f(r1, r0, ls.q1), ls.q2);
     return FMA(-2.0f, rq, 1.0f);
 }
 
 // forward MLPs of one step; h1: drift (lanes 0..31) / density (32..63) hidden unit, h2: layer-2 unit (both halves)
 DI void lane_fwd_mlp(const KArgs& a, const LaneW& W, const float* ust, int lane, const float* z, float& h1, float& h2, float* o, float& eta) {
     const int k = lane & 31, hh = lane >> 5;
+    const LaneSel ls = lane_sel(lane);
     float a1 = hh ? W.c1n : ust[k];
 #pragma unroll
     for (int j = 0; j < NN; ++j) a1 = FMA(W.w1[j], z[j], a1);
-    h1 = lane_tanh(a1, lane);
+    h1 = lane_tanh(a1, ls);
     float a2 = W.b2k;
 #pragma unroll
     for (int r = 0; r < 16; r += 4) {      // eight lanes are read ahead of their fma chain (a read right before its use costs a wait state)
@@ -132,7 +144,7 @@ DI void lane_fwd_mlp(const KArgs& a, const LaneW& W, const float* ust, int lane,
         for (int e = 0; e < 8; ++e) a2 = FMA(W.w2row[rowmap(r + (e >> 1), e & 1)], sv[e], a2);
         __builtin_amdgcn_sched_barrier(0);
     }
-    h2 = lane_tanh(a2, lane);
+    h2 = lane_tanh(a2, ls);
     const float Mreg = hh ? h1 : h2;     // lanes 0..31: layer-2 activations, lanes 32..63: density hidden units
     // all 16 gathers first, ONE wait, then the fma chain (left to itself the compiler waits before every fma: for a lone wave a
     // s_waitcnt costs as much issue time as a vector instruction, tools/salu_probe.hip)
@@ -141,10 +153,11 @@ DI void lane_fwd_mlp(const KArgs& a, const LaneW& W, const float* ust, int lane,
     float P = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) P = FMA(W.wo[r], gsrc[r], P);
-    const float Pc = P + dpp_f<0x128>(P);   // row_ror:8 -> lane c: P_0 + P_1
+    // lane c < 7: (P_0 + P_1) + bias of its chain, added in the lane (two scalar operands in one add would cost a move each)
+    const float Pc = (P + dpp_f<0x128>(P)) + W.bo;   // row_ror:8 -> lane c: P_0 + P_1
 #pragma unroll
-    for (int i = 0; i < 6; ++i) o[i] = readlane_f(Pc, i) + a.M.b3[i];
-    eta = sigmoid_spec(readlane_f(Pc, 6) + a.M.b3n);
+    for (int i = 0; i < 6; ++i) o[i] = readlane_f(Pc, i);
+    eta = sigmoid_spec(readlane_f(Pc, 6));
 }
 
 // adjoint of the MLPs: zb[6], gq[0..M-1]

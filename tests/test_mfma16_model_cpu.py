@@ -146,3 +146,62 @@ def test_f16_mode_uses_the_instruction_model():
     c16, c32 = O16.rollout(x0, u, xref, noise)[0], O32.rollout(x0, u, xref, noise)[0]
     assert c16 != c32 and abs(c16 - c32) <= 1e-3 * abs(c32)
     assert O16.rollout(x0, u, xref, noise)[0] == c16
+
+
+def _contract(mode, Wm, v, c):
+    L = orc.lib()
+    L.orc_contract32.restype = None
+    L.orc_contract32.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    Wm = np.ascontiguousarray(Wm, np.float32); v = np.ascontiguousarray(v, np.float32); c = np.ascontiguousarray(c, np.float32)
+    out = np.empty(32, np.float32)
+    L.orc_contract32(mode, Wm.ctypes.data, v.ctypes.data, c.ctypes.data, out.ctypes.data)
+    return out
+
+
+def test_f32x3_contraction_is_as_close_to_float64_as_the_f32_chain():
+    """The claim behind reporting `mlp_dtype: f32x3` (README): a layer-2 contraction in the three-limb split is not further from the
+    exact value than the 32-step f32 fma chain — on random operands and on adversarial ones (all products of one sign, where the group
+    truncation toward zero of SPEC.md §9a is biased in the same direction every time)."""
+    rng = np.random.default_rng(7)
+    def run(gen, n):
+        e32, ex3, worst = [], [], 0.0
+        for _ in range(n):
+            Wm, v, c = gen()
+            ref = c.astype(np.float64) + Wm.astype(np.float64) @ v.astype(np.float64)
+            mag = np.abs(c.astype(np.float64)) + np.abs(Wm.astype(np.float64)) @ np.abs(v.astype(np.float64))      # condition-free scale of every output
+            d32 = (_contract(0, Wm, v, c).astype(np.float64) - ref) / mag
+            dx3 = (_contract(2, Wm, v, c).astype(np.float64) - ref) / mag
+            e32.append(d32); ex3.append(dx3)
+        e32, ex3 = np.concatenate(e32), np.concatenate(ex3)
+        return np.sqrt((e32 ** 2).mean()), np.sqrt((ex3 ** 2).mean()), np.abs(e32).max(), np.abs(ex3).max(), ex3.mean()
+    # (i) the shapes of the model: N(0, 1/32) weights, tanh-range activations
+    r32, rx3, m32, mx3, _ = run(lambda: ((rng.standard_normal((32, 32)) / np.sqrt(32)).astype(np.float32),
+                                           np.tanh(rng.standard_normal(32)).astype(np.float32), (0.1 * rng.standard_normal(32)).astype(np.float32)), 200)
+    assert rx3 <= 1.25 * r32 and mx3 <= 1.5 * m32, (r32, rx3, m32, mx3)
+    assert mx3 <= 2.0 ** -22                                        # a few ulp of the sum of magnitudes at worst
+    # (ii) adversarial: every product positive and of similar size (truncation toward zero always loses; the chain's errors are unbiased)
+    r32, rx3, m32, mx3, bias = run(lambda: (rng.uniform(0.5, 1.0, (32, 32)).astype(np.float32), rng.uniform(0.5, 1.0, 32).astype(np.float32),
+                                             rng.uniform(0.0, 1.0, 32).astype(np.float32)), 200)
+    assert mx3 <= 2.0 ** -22 and rx3 <= 2.0 * r32, (r32, rx3, m32, mx3, bias)
+    assert bias <= 0.0                                              # the documented direction of the bias (toward zero on positive sums) ...
+    assert abs(bias) <= 2.0 ** -24                                  # ... and its size: below half an ulp of the result
+    # (iii) wide dynamic range inside one row (small products vanish 24 bits below the leading one in either arithmetic)
+    r32, rx3, m32, mx3, _ = run(lambda: ((rng.standard_normal((32, 32)) * np.exp2(rng.integers(-12, 4, (32, 32)))).astype(np.float32),
+                                           (rng.standard_normal(32) * np.exp2(rng.integers(-8, 2, 32))).astype(np.float32), np.zeros(32, np.float32)), 200)
+    assert mx3 <= 2.0 ** -21 and rx3 <= 2.0 * r32, (r32, rx3, m32, mx3)
+
+
+def test_model_keeps_a_non_finite_running_value():
+    """An earlier group (or instruction of a chain) that overflowed leaves inf in the accumulator: finite products cannot bring it back
+    (the hardware keeps inf; the integer decode of exponent field 255 must not be taken for 2^128)."""
+    z = np.zeros(16, np.uint16)
+    big = np.uint16(0x7F7F)                                       # largest finite bf16, 3.39e38
+    a, b = z.copy(), z.copy()
+    a[0], b[0] = big, _bf(2.0)                                    # group 1 overflows ...
+    a[8], b[8] = big, _bf(-1.0)                                   # ... group 2 adds a huge negative finite product
+    assert _dot(1, a, b, 0.0) == np.float32(np.inf) and _dot(1, a, b, 0.0, soa=True) == np.float32(np.inf)
+    # chained instructions: a C that is already inf stays inf through both groups (and -inf likewise)
+    a, b = z.copy(), z.copy()
+    a[3], b[3] = big, _bf(-1.0); a[12], b[12] = big, _bf(-1.0)
+    assert _dot(1, a, b, np.inf) == np.float32(np.inf) and _dot(1, a, b, -np.inf) == np.float32(-np.inf)
+    assert _dot(0, z, z, np.inf) == np.float32(np.inf)

@@ -1,0 +1,295 @@
+"""SPEC.md §10a study, phase 1: gather what v_rcp_f32 / v_rsq_f32 / v_exp_f32 return on an MI355X.
+
+Runs on the GPU box (`gpurun -- python tools/transc_study/study.py gather`). Writes small, compressed summaries under
+gpurun_out/transc/: the canonical tables (all 2^23 mantissas of one binade) as int8 differences from a deterministic float64
+reference that the analysis scripts recompute offline, and exhaustive (2^32 inputs) structure checks evaluated on the GPU with
+torch integer arithmetic.  Nothing here is product code or test code.
+"""
+import ctypes
+import json
+import lzma
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(ROOT, "gpurun_out", "transc")
+RCP, RSQ, EXP, LOG = 0, 1, 2, 3
+
+
+def lib():
+    L = ctypes.CDLL(os.path.join(HERE, "libtransc.so"))
+    L.transc_eval_range.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]
+    L.transc_eval_array.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    L.transc_mode.argtypes = [ctypes.c_void_p]
+    return L
+
+
+# ---- deterministic float64 references (IEEE mul / add / div / sqrt only: identical on every machine) ----
+def ref_rcp_bits(xb):
+    x = xb.astype(np.uint32).view(np.float32).astype(np.float64)
+    with np.errstate(all="ignore"):
+        return (1.0 / x).astype(np.float32).view(np.uint32)
+
+
+def ref_rsq_bits(xb):
+    x = xb.astype(np.uint32).view(np.float32).astype(np.float64)
+    with np.errstate(all="ignore"):
+        return (1.0 / np.sqrt(x)).astype(np.float32).view(np.uint32)
+
+
+_LN2 = 0.6931471805599453
+_SQRT2 = 1.4142135623730951
+
+
+def exp2_f64(x):
+    """2^x in float64 from mul / add only (Taylor in r*ln2, |r| <= 0.5, degree 20), x a float64 array, |x| < 1000."""
+    n = np.floor(x)
+    r = (x - n) - 0.5
+    t = r * _LN2
+    p = np.full_like(t, 1.0 / 2432902008176640000.0)
+    for k in range(19, 0, -1):
+        c = 1.0
+        for j in range(2, k + 1):
+            c *= j
+        p = p * t + 1.0 / c
+    p = p * t + 1.0
+    return np.ldexp(p * _SQRT2, n.astype(np.int64))
+
+
+def ref_exp_bits(xb):
+    x = xb.astype(np.uint32).view(np.float32).astype(np.float64)
+    with np.errstate(all="ignore"):
+        return exp2_f64(x).astype(np.float32).view(np.uint32)
+
+
+REFS = {RCP: ref_rcp_bits, RSQ: ref_rsq_bits, EXP: ref_exp_bits}
+
+
+def save_delta(name, xb, hb, func):
+    rb = REFS[func](xb)
+    d = hb.astype(np.int64) - rb.astype(np.int64)
+    hist = {int(k): int(v) for k, v in zip(*np.unique(d, return_counts=True))}
+    ok = bool(np.abs(d).max() < 120)
+    if ok:
+        blob = lzma.compress(d.astype(np.int8).tobytes(), preset=6)
+        with open(os.path.join(OUT, name + ".i8.xz"), "wb") as f:
+            f.write(blob)
+    return {"name": name, "n": int(len(xb)), "first_bits": int(xb[0]), "hist": hist if len(hist) < 40 else "wide", "stored": ok,
+            "bytes": len(blob) if ok else 0}
+
+
+def main_gather():
+    import torch
+    os.makedirs(OUT, exist_ok=True)
+    L = lib()
+    dev = torch.device("cuda:0")
+    rep = {"device": torch.cuda.get_device_name(0)}
+    mode = torch.zeros(4, dtype=torch.int32, device=dev)
+    assert L.transc_mode(mode.data_ptr()) == 0
+    rep["mode_reg"] = int(mode[0].item()) & 0xFFFFFFFF
+    N = 1 << 23
+    buf = torch.zeros(N, dtype=torch.int32, device=dev)
+
+    def block(func, start, n=N, stride=1):
+        assert L.transc_eval_range(func, start, stride, n, buf.data_ptr()) == 0
+        return buf[:n].cpu().numpy().view(np.uint32).copy()
+
+    blocks = []
+    t0 = time.time()
+    for func, fname, fields in ((RCP, "rcp", [127, 128, 126, 1, 253, 254]), (RSQ, "rsq", [127, 128, 126, 129, 1, 2, 254]),
+                                (EXP, "exp", [127, 126, 125, 124, 123, 120, 115, 110, 104, 128, 129, 130, 131, 132, 133])):
+        for fld in fields:
+            for sign in ((0, 1) if func == EXP else (0,)):
+                start = (sign << 31) | (fld << 23)
+                xb = (np.arange(N, dtype=np.uint64) + start).astype(np.uint32)
+                hb = block(func, start)
+                blocks.append(save_delta(f"{fname}_s{sign}_e{fld}", xb, hb, func))
+                print(blocks[-1]["name"], blocks[-1]["hist"], blocks[-1]["bytes"], f"{time.time() - t0:.0f}s", flush=True)
+    rep["blocks"] = blocks
+
+    # specials and denormal inputs, verbatim
+    spec = [0x00000000, 0x80000000, 0x7F800000, 0xFF800000, 0x7FC00000, 0xFFC00000, 0x7F800001, 0x00000001, 0x80000001, 0x007FFFFF,
+            0x00800000, 0x7F7FFFFF, 0xFF7FFFFF, 0x3F800000, 0xBF800000, 0x00400000, 0x00200000, 0x00100000, 0x7E800000, 0x7F000000,
+            0x7E000000, 0x7EFFFFFF, 0x7F000001, 0xC2FC0000, 0xC2FE0000, 0xC3000000, 0xC3150000, 0xC3160000, 0x42FE0000, 0x42FFFFFF, 0x43000000]
+    sp = torch.tensor(np.array(spec, np.uint32).view(np.int32), device=dev)
+    so = torch.zeros_like(sp)
+    rep["specials"] = {}
+    for func, fname in ((RCP, "rcp"), (RSQ, "rsq"), (EXP, "exp")):
+        assert L.transc_eval_array(func, sp.data_ptr(), len(spec), so.data_ptr()) == 0
+        rep["specials"][fname] = {f"{a:08x}": f"{int(b) & 0xFFFFFFFF:08x}" for a, b in zip(spec, so.cpu().numpy())}
+    # denormal inputs: all 2^23 positive ones for rcp and rsq
+    for func, fname in ((RCP, "rcp"), (RSQ, "rsq"), (EXP, "exp")):
+        hb = block(func, 0)
+        xb = np.arange(N, dtype=np.uint32)
+        if func == EXP:
+            rep[f"{fname}_denorm_in"] = {f"{int(k):08x}": int(v) for k, v in zip(*np.unique(hb, return_counts=True))}
+        else:
+            blocks.append(save_delta(f"{fname}_s0_e0", xb[1:], hb[1:], func))
+
+    # ---- exhaustive structure checks on the GPU ----
+    CH = 1 << 26
+    inb = torch.zeros(CH, dtype=torch.int32, device=dev)
+    outb = torch.zeros(CH, dtype=torch.int32, device=dev)
+
+    def canon(func, fld):
+        assert L.transc_eval_range(func, fld << 23, 1, N, buf.data_ptr()) == 0
+        return buf.to(torch.int64) & 0xFFFFFFFF
+
+    # rcp: result(±2^e * 1.m) == ±2^-e * result(1.m) whenever both are normal
+    Tc = canon(RCP, 127).clone()
+    cats = {}
+    ex = {}
+    for c in range((1 << 32) // CH):
+        start = c * CH
+        assert L.transc_eval_range(RCP, start, 1, CH, outb.data_ptr()) == 0
+        xb = torch.arange(start, start + CH, dtype=torch.int64, device=dev)
+        hb = outb.to(torch.int64) & 0xFFFFFFFF
+        E = (xb >> 23) & 0xFF
+        m = xb & 0x7FFFFF
+        s = xb >> 31
+        t = Tc[m]
+        tf = (t >> 23) & 0xFF
+        ef = tf + 127 - E
+        expect = (s << 31) | (ef << 23) | (t & 0x7FFFFF)
+        normal_in = (E >= 1) & (E <= 254)
+        normal_out = (ef >= 1) & (ef <= 254)
+        good = normal_in & normal_out
+        bad = good & (hb != expect)
+        for nm, mask in (("normal_checked", good), ("normal_mismatch", bad), ("normal_in_result_outside", normal_in & ~normal_out)):
+            cats[nm] = cats.get(nm, 0) + int(mask.sum().item())
+        if int(bad.sum().item()) and len(ex) < 16:
+            idx = torch.nonzero(bad)[:4, 0]
+            for i in idx.tolist():
+                ex[f"{start + i:08x}"] = [f"{int(hb[i]):08x}", f"{int(expect[i]):08x}"]
+        # results outside the normal range: what are they? (record a compact census)
+        m2 = normal_in & ~normal_out
+        if int(m2.sum().item()):
+            hx = hb[m2]
+            key = "outside_census"
+            zero = int(((hx & 0x7FFFFFFF) == 0).sum().item())
+            den = int((((hx >> 23) & 0xFF) == 0).sum().item()) - zero
+            inf = int(((hx & 0x7FFFFFFF) == 0x7F800000).sum().item())
+            cc = cats.setdefault(key, {"zero": 0, "denormal": 0, "inf": 0, "other": 0})
+            cc["zero"] += zero; cc["denormal"] += den; cc["inf"] += inf; cc["other"] += int(hx.numel()) - zero - den - inf
+    rep["rcp_structure"] = {"counts": cats, "examples": ex}
+    print("rcp structure", rep["rcp_structure"], flush=True)
+
+    # rsq: result(2^(2k+p) * 1.m) == 2^-k * result(2^p * 1.m), p in {0, 1}, positive normal inputs
+    T0 = canon(RSQ, 127).clone()
+    T1 = canon(RSQ, 128).clone()
+    cats = {}
+    ex = {}
+    for c in range((1 << 31) // CH):
+        start = c * CH
+        assert L.transc_eval_range(RSQ, start, 1, CH, outb.data_ptr()) == 0
+        xb = torch.arange(start, start + CH, dtype=torch.int64, device=dev)
+        hb = outb.to(torch.int64) & 0xFFFFFFFF
+        E = (xb >> 23) & 0xFF
+        m = xb & 0x7FFFFF
+        e = E - 127
+        p = e & 1
+        k = (e - p) >> 1
+        t = torch.where(p == 0, T0[m], T1[m])
+        ef = ((t >> 23) & 0xFF) - k
+        expect = (ef << 23) | (t & 0x7FFFFF)
+        good = (E >= 1) & (E <= 254)
+        bad = good & (hb != expect)
+        cats["normal_checked"] = cats.get("normal_checked", 0) + int(good.sum().item())
+        cats["normal_mismatch"] = cats.get("normal_mismatch", 0) + int(bad.sum().item())
+        if int(bad.sum().item()) and len(ex) < 16:
+            for i in torch.nonzero(bad)[:4, 0].tolist():
+                ex[f"{start + i:08x}"] = [f"{int(hb[i]):08x}", f"{int(expect[i]):08x}"]
+    # negative inputs: all NaN?
+    negcount = {}
+    for c in range((1 << 31) // CH):
+        start = (1 << 31) + c * CH
+        assert L.transc_eval_range(RSQ, start, 1, CH, outb.data_ptr()) == 0
+        hb = outb.to(torch.int64) & 0xFFFFFFFF
+        u, n = torch.unique(hb, return_counts=True)
+        if u.numel() < 64:
+            for a, b in zip(u.tolist(), n.tolist()):
+                negcount[f"{a:08x}"] = negcount.get(f"{a:08x}", 0) + b
+        else:
+            negcount["many"] = negcount.get("many", 0) + 1
+    rep["rsq_structure"] = {"counts": cats, "examples": ex, "negative_inputs": negcount if len(negcount) < 200 else "many"}
+    print("rsq structure", rep["rsq_structure"], flush=True)
+
+    # exp2: (i) x >= 1 or x <= -1 (fraction on the 2^-23 grid or coarser): result(x) == 2^(n-1) * result(1 + f)?
+    Te = canon(EXP, 127).clone()   # result(1 + f), f = m / 2^23
+    cats = {}
+    ex = {}
+    for c in range((1 << 32) // CH):
+        start = c * CH
+        xb = torch.arange(start, start + CH, dtype=torch.int64, device=dev)
+        E = (xb >> 23) & 0xFF
+        if int(E.max().item()) < 127 or int(E.min().item()) > 134:
+            continue
+        assert L.transc_eval_range(EXP, start, 1, CH, outb.data_ptr()) == 0
+        hb = outb.to(torch.int64) & 0xFFFFFFFF
+        m = (xb & 0x7FFFFF) | 0x800000
+        s = xb >> 31
+        sh = E - 127                      # 0..7: x = m * 2^(sh-23)
+        fixed = m << sh                   # |x| * 2^23
+        fixed = torch.where(s == 1, -fixed, fixed)
+        n = fixed >> 23                   # floor
+        f = fixed & 0x7FFFFF
+        t = Te[f]
+        ef = ((t >> 23) & 0xFF) + n - 1
+        expect = (ef << 23) | (t & 0x7FFFFF)
+        good = (E >= 127) & (E <= 134) & (ef >= 1) & (ef <= 254)
+        bad = good & (hb != expect)
+        cats["checked"] = cats.get("checked", 0) + int(good.sum().item())
+        cats["mismatch"] = cats.get("mismatch", 0) + int(bad.sum().item())
+        if int(bad.sum().item()) and len(ex) < 16:
+            for i in torch.nonzero(bad)[:4, 0].tolist():
+                ex[f"{start + i:08x}"] = [f"{int(hb[i]):08x}", f"{int(expect[i]):08x}"]
+    rep["exp_structure_integer_part"] = {"counts": cats, "examples": ex}
+    print("exp structure", rep["exp_structure_integer_part"], flush=True)
+
+    # (ii) |x| < 1: does the result depend on x only through its fraction truncated / rounded to some grid 2^-G?
+    res = {}
+    for fld in range(126, 96, -1):
+        for sign in (0, 1):
+            start = (sign << 31) | (fld << 23)
+            assert L.transc_eval_range(EXP, start, 1, N, buf.data_ptr()) == 0
+            hb = buf.to(torch.int64) & 0xFFFFFFFF
+            m = torch.arange(N, dtype=torch.int64, device=dev) | 0x800000
+            k = 127 - fld                 # x = m * 2^(-23-k)
+            row = {}
+            for G in (23, 24, 25, 26, 27, 28):
+                # fixed-point fraction on the 2^-G grid
+                shift = 23 + k - G
+                for mode in ("trunc", "floor", "rne"):
+                    if shift <= 0:
+                        q = m << (-shift)
+                        q = -q if sign else q
+                    else:
+                        mm = -m if sign else m
+                        if mode == "floor":
+                            q = mm >> shift
+                        elif mode == "trunc":
+                            q = (m >> shift)
+                            q = -q if sign else q
+                        else:
+                            half = 1 << (shift - 1)
+                            fl = mm >> shift
+                            rem = mm - (fl << shift)
+                            q = fl + ((rem > half) | ((rem == half) & ((fl & 1) == 1))).to(torch.int64)
+                    # results must be a function of q: count inputs whose result differs from the first result seen with the same q
+                    # (q is monotone in m, so equal q are adjacent)
+                    same = q[1:] == q[:-1]
+                    viol = int((same & (hb[1:] != hb[:-1])).sum().item())
+                    row[f"G{G}_{mode}"] = viol
+            res[f"s{sign}_e{fld}"] = row
+    rep["exp_fraction_grid_violations"] = res
+    with open(os.path.join(OUT, "gather.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    print("done", f"{time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__":
+    {"gather": main_gather}[sys.argv[1]]()

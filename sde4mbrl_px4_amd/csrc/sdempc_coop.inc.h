@@ -67,15 +67,12 @@ DI float coop_total(const float* pq, int P, int G, int lane) {
     return ((S0 + S1) + S2) + S3;
 }
 
-DI LaneIO lane_io_coop(const KArgs& a, const CoopCtx& C, int b, int p) {
+DI Lane2IO lane_io_coop(const KArgs& a, const CoopCtx& C, int b, int p) {
     const int H = a.H;
-    LaneIO io;
+    Lane2IO io;
     io.x0 = a.x0 + (size_t)b * NX;
-    io.nz = a.noise + ((size_t)(b * a.G + (p >> 5)) * H) * NN * 32 + (p & 31);
-    io.ck = C.ck + (size_t)p * (H + 1) * COOP_ROW; io.ck_t = COOP_ROW;     // H + 1 rows: row t also carries x_t, t = 0..H
-    io.xs = io.ck + LANE_ACT_X; io.xs_t = COOP_ROW; io.xs_i = 1;
+    io.ck = C.ck + (size_t)p * (H + 1) * COOP_ROW;
     io.out = C.pp + (size_t)(C.epoch & 1u) * part_stride(H) * C.Ppad + p; io.os = C.Ppad;
-    io.add0 = false;
     return io;
 }
 
@@ -85,13 +82,15 @@ DI float coop_rollout(const KArgs& a, const Smem& sm, const LaneW& W, CoopCtx& C
     const int H = a.H, P = a.P, G = a.G, lane = tid & 63, wave = tid >> 6, PS = part_stride(H);
     const bool want_mean = xmean_out != nullptr;
     Team::sync();
-    block_prepass<Team>(a, sm, u, tid);
+    lane2_prepass<Team>(a, sm, u, tid);
     float cu = block_ucost<Team>(a, sm, u, tid);
     const int p = C.wgi * 4 + wave;
     const float* pbuf = C.pp + (size_t)(C.epoch & 1u) * PS * C.Ppad;
     if (p < P) {
-        const LaneIO io = lane_io_coop(a, C, b, p);
-        lane_particle_rollout(a, sm, W, io, lane, false, want_mean);
+        const Lane2IO io = lane_io_coop(a, C, b, p);
+        const Lane2Lds L = lane2_lds(a, sm, wave);
+        if (want_mean) lane2_rollout<true>(a, sm, L, io, lane);
+        else lane2_rollout<false>(a, sm, L, io, lane);
     }
     coop_barrier(C, tid);
     if (wave == 0) { const float t0 = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, P, G, lane); if (lane == 0) sm.red[12] = t0; }
@@ -111,13 +110,13 @@ DI float coop_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, CoopCtx&
     const int H = a.H, P = a.P, G = a.G, lane = tid & 63, wave = tid >> 6, PS = part_stride(H);
     constexpr int nq = M + 4;
     Team::sync();
-    block_prepass<Team>(a, sm, y, tid);
+    lane2_prepass<Team>(a, sm, y, tid);
     float cu = block_ucost<Team>(a, sm, y, tid);
     const int p = C.wgi * 4 + wave;
     const float* pbuf = C.pp + (size_t)(C.epoch & 1u) * PS * C.Ppad;
     if (p < P) {
-        const LaneIO io = lane_io_coop(a, C, b, p);
-        lane_particle_grad<M>(a, sm, W, io, lane);
+        const Lane2IO io = lane_io_coop(a, C, b, p);
+        lane2_grad<M>(a, sm, lane2_lds(a, sm, wave), io, lane);
     }
     coop_barrier(C, tid);
     // particle sums of the nq adjoint outputs of every step -> LDS (wave w takes the steps t = w, w + 4, ...)

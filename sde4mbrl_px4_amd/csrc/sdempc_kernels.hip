@@ -166,11 +166,14 @@ struct Smem {
     float *dt, *sdt, *disc;                            // [H], [H][6], [H+1]
     float *red;                                        // [16] block-reduction scratch
     float *tot;                                        // cooperative path only: [H*12] particle sums of the adjoint outputs
+    float *rec, *nzl, *cend;                           // cooperative path only (sdempc_lane2.inc.h): step records [H][REC], noise rows of the four waves [4][H][NZL], end of the carve
     float *v[6];                                       // N-vectors: 0 xk, 1 yk, 2 xn, 3 g, 4 d1, 5 ucur
     float *nzs;                                        // duo layout only: this WAVE's noise staging rows [6][64] (LDS-DMA target), behind every team's state
 };
 constexpr int NZ_STAGE = 6 * 64;                       // floats per wave
 constexpr int UST = 36;
+constexpr int REC = 64, NZL = 8;                       // cooperative layouts: floats per step record / per noise row in LDS (sdempc_lane2.inc.h)
+constexpr int COOP_ROW = 172;                          // floats per (particle, step) checkpoint row of the cooperative layouts (sdempc_lane2.inc.h)
 
 DI Smem carve(float* base, int H, int m, int team, bool coop = false, bool ust_lds = true) {
     Smem s;
@@ -199,6 +202,7 @@ DI Smem carve(float* base, int H, int m, int team, bool coop = false, bool ust_l
     s.red = p; p += 16;
     for (int i = 0; i < 6; ++i) { s.v[i] = p; p += nv; }
     s.tot = p;                       // only the cooperative kernel (one team per workgroup) reserves it: see smem_bytes
+    s.rec = s.tot + ((H * 12 + 3) & ~3); s.nzl = s.rec + H * REC; s.cend = s.nzl + 4 * H * NZL;      // (coop only)
     s.nzs = nullptr;                 // set by the duo kernel (smem_floats(...) + wave * NZ_STAGE)
     (void)coop;
     return s;
@@ -206,7 +210,7 @@ DI Smem carve(float* base, int H, int m, int team, bool coop = false, bool ust_l
 __host__ __device__ inline size_t smem_floats(int H, int m, int ipb, bool coop = false, bool ust_lds = true) {
     size_t shared = 6 * HID + 4 * HID + NN * 2 * HID + (size_t)m * HID + 2 * HID * HID + 1024 + ((H + 3) & ~3) + ((H * NN + 3) & ~3) + ((H + 1 + 3) & ~3);
     size_t per_team = (ust_lds ? (size_t)H * UST : 0) + (((H + 1) * NX + 3) & ~3) + 16 + 6 * (size_t)((H * m + 3) & ~3);
-    return shared + ipb * per_team + (coop ? (size_t)((H * 12 + 3) & ~3) : 0);
+    return shared + ipb * per_team + (coop ? (size_t)((H * 12 + 3) & ~3) + (size_t)H * REC + (size_t)4 * H * NZL : 0);
 }
 // nz_waves: waves per workgroup that get a noise staging area (duo launches), 0 otherwise
 inline size_t smem_bytes(int H, int m, int ipb, bool coop = false, bool ust_lds = true, int nz_waves = 0) {
@@ -437,6 +441,8 @@ DI float group_ordered_sum(const float* rows, int G, int PS, int i) {
 }
 
 #include "sdempc_lane.inc.h"
+
+#include "sdempc_lane2.inc.h"
 
 #include "sdempc_coop.inc.h"
 
@@ -776,8 +782,9 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     load_weights(a, sm, ww, threadIdx.x, Team::BNT);                                 \
     __syncthreads();                                                                 \
     if (b >= a.B) return; /* no workgroup-wide barrier below this line in TeamWave */ \
-    if constexpr (MODE == 1 || MODE == 2) load_lane_weights(a, LW, threadIdx.x & 63); \
-    load_common<Team>(a, sm, b, tid);
+    if constexpr (MODE == 1) load_lane_weights(a, LW, threadIdx.x & 63);              \
+    load_common<Team>(a, sm, b, tid);                                                \
+    if constexpr (MODE == 2) { __syncthreads(); lane2_stage<Team>(a, sm, b, CC.wgi, tid); }
 
 template <class Team, int F16, int MODE = 0>
 __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_rollout_kernel(KArgs a) {

@@ -200,7 +200,6 @@ DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp&
 }
 
 constexpr int LANE_ACT_H1 = 0, LANE_ACT_H2 = 64, LANE_ACT_SC = 128, LANE_ACT_X = 136;   // offsets inside one checkpoint row
-constexpr int COOP_ROW = 160;      // floats per (particle, step) checkpoint row of the cooperative path: h1[64] h2[64] scalars[8] x_t[13] pad
 
 // Where one particle's streams live (the same device functions serve the P == 1 team and the cooperative multi-workgroup path)
 struct LaneIO {

@@ -17,15 +17,12 @@ constexpr int SPEC_GROUPS = 7, SPEC_SLOTS = 9, SPEC_CKS = 4;
 constexpr int SLOT_SEQ = 6, SLOT_GRAD = 5;        // slots 0..4 and 7, 8: the items of a parallel phase
 constexpr int SLOT_T3 = 7, SLOT_Y3 = 8;           // third parallel trial and the candidate gradient behind it (groups 5, 6)
 
-DI LaneIO lane_io_slot(const KArgs& a, const CoopCtx& C, int b, int p, unsigned par, int slot) {
+DI Lane2IO lane_io_slot(const KArgs& a, const CoopCtx& C, int b, int p, unsigned par, int slot) {
     const int H = a.H;
-    LaneIO io;
+    Lane2IO io;
     io.x0 = a.x0 + (size_t)b * NX;
-    io.nz = a.noise + ((size_t)(b * a.G + (p >> 5)) * H) * NN * 32 + (p & 31);
-    io.ck = C.ck + (size_t)p * (H + 1) * COOP_ROW; io.ck_t = COOP_ROW;
-    io.xs = io.ck + LANE_ACT_X; io.xs_t = COOP_ROW; io.xs_i = 1;
+    io.ck = C.ck + (size_t)p * (H + 1) * COOP_ROW;
     io.out = C.pp + (size_t)(par * SPEC_SLOTS + slot) * part_stride(H) * C.Ppad + p; io.os = C.Ppad;
-    io.add0 = false;
     return io;
 }
 // after a phase's barrier, in every workgroup: expected cost of control sequence u whose particle outputs sit in (par, slot)
@@ -80,14 +77,14 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     C.ck = a.coop_ck + ((size_t)b * SPEC_CKS + (grp == 6 ? 3 : grp >= 2 && grp <= 4 ? grp - 2 : 0)) * a.P * (H + 1) * COOP_ROW;    // gradients run on groups 2..4 and 6 (or 0 when there are only two)
     Smem sm = carve(smem, H, m, 0, true);
     WaveW ww;
-    LaneW LW;
     load_weights(a, sm, ww, tid, Team::BNT);
     __syncthreads();
     if (b >= a.B) return;
-    load_lane_weights(a, LW, lane);
     load_common<Team>(a, sm, b, tid);
+    __syncthreads();
+    lane2_stage<Team>(a, sm, b, C.wgi, tid);
     const int nv = (N + 3) & ~3;
-    float* ex = sm.tot + ((H * 12 + 3) & ~3);
+    float* ex = sm.cend;
     float *xn1 = ex, *xn2 = ex + nv, *y1 = ex + 2 * nv, *y2 = ex + 3 * nv, *xn3 = ex + 4 * nv, *y3 = ex + 5 * nv, *mred = ex + SPEC_XV * nv;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
     for (int e = tid; e < N; e += Team::NT) {
@@ -153,13 +150,15 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         gd_3 = uni_f(gd_3); rs_3 = uni_f(rs_3); cu_3 = uni_f(cu_3);
         if (iact) {      // the only call site of the particle work
             __syncthreads();
-            block_prepass<Team>(a, sm, iu, tid);
+            lane2_prepass<Team>(a, sm, iu, tid);
             __syncthreads();
             const int p = C.wgi * 4 + wave;
             if (p < a.P) {
-                const LaneIO io = lane_io_slot(a, C, b, p, par, islot);
-                if (igrad) lane_particle_grad<M>(a, sm, LW, io, lane);
-                else lane_particle_rollout(a, sm, LW, io, lane, false, imean);
+                const Lane2IO io = lane_io_slot(a, C, b, p, par, islot);
+                const Lane2Lds L = lane2_lds(a, sm, wave);
+                if (igrad) lane2_grad<M>(a, sm, L, io, lane);
+                else if (imean) lane2_rollout<true>(a, sm, L, io, lane);
+                else lane2_rollout<false>(a, sm, L, io, lane);
             }
         }
         coop_barrier(C, tid);

@@ -195,12 +195,12 @@ DI void fwd_mlp_tiles(const KArgs& a, const Smem& sm, const WaveW& ww, const flo
 }
 
 // ---- uniform tail of a step: rigid body, Euler-Maruyama update, quaternion renormalisation ----
-DI void fwd_tail(const KArgs& a, const Smem& sm, const float* ust, int t, const float* x, const float* xi, const float* Rm, const float* o, float eta, float* xn, StepAux& A) {
-    const float dt = sm.dt[t];
+// (the _v forms take the step's constants as values / pointers of the caller's choice: tz = {Tz, tau0, tau1, tau2}, sdt = sigma_i sqrt(dt_t))
+DI void fwd_tail_v(const KArgs& a, const float dt, const float* tz, const float* sdt, const float* x, const float* xi, const float* Rm, const float* o, float eta, float* xn, StepAux& A) {
     const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
     A.eta = eta;
     // rigid body
-    A.Fb[0] = a.M.sF[0] * o[0]; A.Fb[1] = a.M.sF[1] * o[1]; A.Fb[2] = FMA(a.M.sF[2], o[2], ust[32]);
+    A.Fb[0] = a.M.sF[0] * o[0]; A.Fb[1] = a.M.sF[1] * o[1]; A.Fb[2] = FMA(a.M.sF[2], o[2], tz[0]);
     float acc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -210,7 +210,7 @@ DI void fwd_tail(const KArgs& a, const Smem& sm, const float* ust, int t, const 
     acc[2] = acc[2] - a.M.grav;
     float taub[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { taub[i] = FMA(a.M.sT[i], o[3 + i], ust[33 + i]); A.Jom[i] = a.M.J[i] * x[10 + i]; }
+    for (int i = 0; i < 3; ++i) { taub[i] = FMA(a.M.sT[i], o[3 + i], tz[1 + i]); A.Jom[i] = a.M.J[i] * x[10 + i]; }
     float cr[3];
     cr[0] = FMA(x[11], A.Jom[2], -(x[12] * A.Jom[1]));
     cr[1] = FMA(x[12], A.Jom[0], -(x[10] * A.Jom[2]));
@@ -223,7 +223,6 @@ DI void fwd_tail(const KArgs& a, const Smem& sm, const float* ust, int t, const 
     dq[1] = 0.5f * FMA(-qz, x[11], FMA(qy, x[12], qw * x[10]));
     dq[2] = 0.5f * FMA(-qx, x[12], FMA(qz, x[10], qw * x[11]));
     dq[3] = 0.5f * FMA(-qy, x[10], FMA(qx, x[11], qw * x[12]));
-    const float* sdt = sm.sdt + t * NN;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         xn[i] = FMA(x[3 + i], dt, x[i]);
@@ -237,6 +236,9 @@ DI void fwd_tail(const KArgs& a, const Smem& sm, const float* ust, int t, const 
     if constexpr (FAST) A.rn = __builtin_amdgcn_rsqf(n2); else A.rn = rsqrt_spec(n2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { A.qn[i] = qt[i] * A.rn; xn[6 + i] = A.qn[i]; }
+}
+DI void fwd_tail(const KArgs& a, const Smem& sm, const float* ust, int t, const float* x, const float* xi, const float* Rm, const float* o, float eta, float* xn, StepAux& A) {
+    fwd_tail_v(a, sm.dt[t], ust + 32, sm.sdt + t * NN, x, xi, Rm, o, eta, xn, A);
 }
 
 template <int F16, bool PK = false>
@@ -322,9 +324,7 @@ struct VjpTmp {
 
 // ---- head: everything upstream of the MLPs (per particle); gq[M..M+3] = thrust / rotor-torque adjoints ----
 template <int M>
-DI void vjp_head(const KArgs& a, const Smem& sm, int t, const float* x, const float* xi, const StepAux& A, const float* L, float etabar_cost, VjpTmp& T, float* gq) {
-    const float dt = sm.dt[t];
-    const float* sdt = sm.sdt + t * NN;
+DI void vjp_head_v(const KArgs& a, const float dt, const float* sdt, const float* x, const float* xi, const StepAux& A, const float* L, float etabar_cost, VjpTmp& T, float* gq) {
     const float* Rm = A.Rm;
     const float* om = x + 10;
     float eb = etabar_cost;
@@ -359,6 +359,10 @@ DI void vjp_head(const KArgs& a, const Smem& sm, int t, const float* x, const fl
     for (int i = 0; i < 3; ++i) { ob[i] = a.M.sF[i] * Fbb[i]; ob[3 + i] = a.M.sT[i] * taub_b[i]; }
     gq[M] = Fbb[2];
     gq[M + 1] = taub_b[0]; gq[M + 2] = taub_b[1]; gq[M + 3] = taub_b[2];
+}
+template <int M>
+DI void vjp_head(const KArgs& a, const Smem& sm, int t, const float* x, const float* xi, const StepAux& A, const float* L, float etabar_cost, VjpTmp& T, float* gq) {
+    vjp_head_v<M>(a, sm.dt[t], sm.sdt + t * NN, x, xi, A, L, etabar_cost, T, gq);
 }
 
 // ---- MLP part in the MFMA tile layout: zb[6] = adjoint of z, gq[0..M-1] = W1u^T abar1 (per particle) ----
@@ -599,8 +603,7 @@ DI void vjp_mlp_tiles(const Smem& sm, int h, int lane, const StepAux& A, const V
 }
 
 // ---- tail: adjoint of the state (per particle) ----
-DI void vjp_tail(const Smem& sm, int t, const float* x, const StepAux& A, const float* L, const VjpTmp& T, const float* zb, float* lam) {
-    const float dt = sm.dt[t];
+DI void vjp_tail_v(const float dt, const float* x, const StepAux& A, const float* L, const VjpTmp& T, const float* zb, float* lam) {
     const float* Rm = A.Rm;
     const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
     const float* v = x + 3;
@@ -642,6 +645,9 @@ DI void vjp_tail(const Smem& sm, int t, const float* x, const StepAux& A, const 
     for (int i = 0; i < 3; ++i) { lam[i] = L[i]; lam[3 + i] = vbar[i]; lam[10 + i] = omb[i]; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) lam[6 + i] = qb[i];
+}
+DI void vjp_tail(const Smem& sm, int t, const float* x, const StepAux& A, const float* L, const VjpTmp& T, const float* zb, float* lam) {
+    vjp_tail_v(sm.dt[t], x, A, L, T, zb, lam);
 }
 
 template <int M, int F16 = 0>

@@ -1,0 +1,214 @@
+"""One workload on one GPU (solver handle + device-resident inputs and outputs), the single-solve latency loop, BASELINE config 4 and the
+secondary configurations of bench.py's default line."""
+import os
+import time
+
+import numpy as np
+
+from .counts import F16_MFMA_PEAK_TF, F32_MFMA_PEAK_TF, HBM_PEAK_GBS, f16_contraction_flops, roofline_of
+from .verify import sample_indices
+
+
+class Leg:
+    """One workload on this rank's GPU: solver + device-resident inputs and outputs."""
+
+    def __init__(self, cfg, blob, B, dev_ord, rank=0, world=1, pos=False):
+        import torch
+        from sde4mbrl_px4_amd import prng
+        from sde4mbrl_px4_amd import workload as W
+        from sde4mbrl_px4_amd.solver import SdeMpcSolver
+        self.cfg, self.blob, self.B = cfg, blob, B
+        H, P, m = cfg.horizon, cfg.num_particles, cfg.num_motors
+        dev = torch.device("cuda", dev_ord)
+        self.solver = SdeMpcSolver(cfg, blob, max_batch=B, device=dev_ord)
+        self.x0_h = W.random_initial_states(B, rank * B)
+        self.xref_h = np.stack([W.constant_reference(W.HOVER, H) if pos else W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(B)])
+        # noise: drawn on the device from per-instance threefry keys (SPEC.md 7; the m_mpc path), launch seed 10 (iris_sdectrl.launch:8)
+        self.keys = prng.split(prng.PRNGKey(10), world * B)[rank * B:(rank + 1) * B]
+        yk, info0 = self.solver.reset()
+        self.u0_h = np.tile(yk[None], (B, 1, 1))
+        self.s0 = float(info0["stepsize"])
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.x0 = torch.from_numpy(self.x0_h).to(dev)
+        self.xref = torch.from_numpy(self.xref_h).to(dev)
+        self.noise = torch.empty(self.solver.lib.sdempc_noise_dev_floats(self.solver._h, B), dtype=torch.float32, device=dev)
+        self.solver.noise_from_keys_dev(self.keys, self.noise.data_ptr(), self.stream)
+        self.u0 = torch.from_numpy(self.u0_h).to(dev)
+        self.step_in = torch.full((B,), self.s0, dtype=torch.float32, device=dev)
+        self.uopt = torch.empty((B, H, m), dtype=torch.float32, device=dev)
+        self.xevol = torch.empty((B, H + 1, 13), dtype=torch.float32, device=dev)
+        self.info = torch.empty((B, 8), dtype=torch.float32, device=dev)
+
+    def step(self, solver=None, out=None):
+        u, x, i = out or (self.uopt, self.xevol, self.info)
+        (solver or self.solver).solve_dev(self.B, self.x0.data_ptr(), self.xref.data_ptr(), self.noise.data_ptr(), self.u0.data_ptr(),
+                                          self.step_in.data_ptr(), u.data_ptr(), x.data_ptr(), i.data_ptr(), self.stream)
+
+    def solve_one(self, solver, i):
+        """instance i of the batch alone (B = 1 launch of the same C-ABI entry point), outputs into the batch's own rows"""
+        nv = self.noise.view(self.B, -1)
+        solver.solve_dev(1, self.x0[i:].data_ptr(), self.xref[i:].data_ptr(), nv[i:].data_ptr(), self.u0[i:].data_ptr(), self.step_in[i:].data_ptr(),
+                         self.uopt[i:].data_ptr(), self.xevol[i:].data_ptr(), self.info[i:].data_ptr(), self.stream)
+
+    def timed_events(self, reps):
+        """reps launches timed one by one with HIP events on the launch stream; returns (ms list, work counters per solve)"""
+        import torch
+        torch.cuda.synchronize()
+        self.solver.work_counters(reset=True)
+        ms = []
+        for _ in range(reps):
+            self.step()
+            ms.append(self.solver.last_kernel_ms())
+        torch.cuda.synchronize()
+        self.solver.solve_status()
+        w_solves, w_grads, w_fwd = self.solver.work_counters()
+        if w_solves != self.B * reps:
+            raise SystemExit(f"bench.py: {w_solves} solves counted on the device for {reps} launches of {self.B} instances")
+        return ms, w_grads / max(w_solves, 1), w_fwd / max(w_solves, 1)
+
+    def host_outputs(self):
+        return self.uopt.cpu().numpy(), self.xevol.cpu().numpy(), self.info.cpu().numpy()
+
+    def slots(self):
+        return 6 * self.solver.get_option("device_cus")
+
+    def close(self):
+        self.solver.close()
+
+
+def latency_of(L, solver, reps, warm):
+    """p50 / p95 protocol of SURVEY.md §8(d): one problem instance after the other, host timestamps around a device sync"""
+    import torch
+    lat = []
+    for r in range(-warm if reps > 0 else 0, reps):
+        i = r % L.B
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        L.solve_one(solver, i)
+        torch.cuda.synchronize()
+        if r >= 0:
+            lat.append((time.perf_counter() - t) * 1e3)
+        solver.solve_status()     # raises if a grid barrier of the cooperative layout gave up (results would be invalid)
+    return lat, (solver.last_kernel_name() if lat else None), solver.layout_fallbacks()
+
+
+def config4_leg(L, cfg, blob, dev, dev_ord, world, reps, mlp_dtype, sync_all, force_dist):
+    """BASELINE config 4 (N > 1 only): ONE instance per GPU, all ranks solving theirs at the same time (barrier-aligned ticks, duration of a
+    tick = the slowest rank's); f32 latency layouts like the single-GPU p50 (a single instance is a latency problem)"""
+    import torch
+    from sde4mbrl_px4_amd.solver import SdempcError
+    from sde4mbrl_px4_amd.dist import max_over_ranks_each
+    from sde4mbrl_px4_amd.solver import SdeMpcSolver
+    s1 = L.solver if mlp_dtype == "f32" else SdeMpcSolver(cfg.replace(mlp_dtype="f32"), blob, max_batch=8, device=dev_ord)
+    durs, gave_up = [], 0
+    for r in range(-3, reps):
+        i = (r + 3) % L.B
+        sync_all()
+        t = time.perf_counter()
+        L.solve_one(s1, i)
+        torch.cuda.synchronize()
+        d = (time.perf_counter() - t) * 1e3
+        ok = True
+        try:
+            s1.solve_status()
+        except SdempcError as e:
+            # a grid barrier gave up (the GPU is shared with another rank: test boxes only): the handle continues in the tile layout and the tick is
+            # not a measurement; anything else (a ticket mismatch, a launch failure) is an error of the run
+            if "barrier" not in str(e):
+                raise
+            gave_up += 1
+            ok = False
+        if r >= 0:
+            durs.append(d if ok else float("nan"))
+    kernel, fallbacks = s1.last_kernel_name(), s1.layout_fallbacks()
+    if s1 is not L.solver:
+        s1.close()
+    # a tick counts only if every rank measured it: NaN survives the MAX over the ranks
+    ticks = [t for t in max_over_ranks_each(durs, device=dev, force=force_dist, nan_propagates=True) if t == t]
+    if not ticks:
+        return {"instances": world, "ticks": 0, "value": None, "barrier_give_ups_rank0": gave_up, "kernel": kernel,
+                "note": "no tick completed on every rank without a barrier give-up"}
+    return {"instances": world, "ticks": len(ticks), "ticks_dropped": len(durs) - len(ticks), "p50_tick_ms": float(np.median(ticks)), "p95_tick_ms": float(np.percentile(ticks, 95)),
+            "value": world / (float(np.median(ticks)) * 1e-3), "unit": "solves/s", "kernel": kernel, "layout_fallbacks_rank0": fallbacks, "barrier_give_ups_rank0": gave_up, "mlp_dtype": "f32",
+            "note": "BASELINE config 4: one Iris H=50 P=128 instance per GPU (random initial states), every rank solving its own at the same time; a tick "
+                    "lasts as long as its slowest rank; no data-path collective (the weights were broadcast once at start)"}
+
+
+def other_config_legs(root, main_mlp, B, dev, dev_ord, cfg_of, V, verify, progress):
+    """C2 in the f32 chain, C3, C5 (main arithmetic and f16): one or two timed launches each, roofline fractions, a sample handed to the verifier"""
+    import torch
+    from sde4mbrl_px4_amd import synthetic_hexa, synthetic_iris
+    from sde4mbrl_px4_amd.solver import SdeMpcSolver
+    cdir = os.path.join(root, "configs")
+    legs = [("c2_f32_chain", os.path.join(cdir, "c2_iris_traj_h50_p128.yaml"), "f32", B, 2),
+            ("c3", os.path.join(cdir, "c3_hexa_traj_h50_p256.yaml"), main_mlp, 6144, 2),
+            ("c5_f32x3" if main_mlp == "f32x3" else "c5_f32", os.path.join(cdir, "c5_iris_traj_h200_p1024.yaml"), main_mlp, 768, 1),
+            ("c5_f16", os.path.join(cdir, "c5_iris_traj_h200_p1024.yaml"), "f16", 768, 1)]
+    if main_mlp == "f32":
+        legs = legs[1:]
+    iris_blob, hexa_blob = synthetic_iris().to_blob(), synthetic_hexa().to_blob()
+    others = {}
+    for name, path, mlp, Bl, reps in legs:
+        progress(f"other configuration {name}: {Bl} instances, {reps} timed launch(es)")
+        c2 = cfg_of(path, mlp)
+        bl = iris_blob if c2.num_motors == 4 else hexa_blob
+        Lg = Leg(c2, bl, Bl, dev_ord)
+        Lg.step(); torch.cuda.synchronize()                       # warm-up launch
+        ms, ng, nf = Lg.timed_events(reps)
+        kn = Lg.solver.last_kernel_name()
+        km = float(np.mean(ms))
+        tf, gbs, _, _, _ = roofline_of(c2, Bl, km, ng, nf)
+        uo, xo, io = Lg.host_outputs()
+        rec = {"config": os.path.basename(path), "mlp_dtype": mlp, "instances": Bl, "launches_timed": reps, "value": Bl / (km * 1e-3), "unit": "solves/s",
+               "kernel_ms": km, "kernel": kn, "roofline_frac": tf / F32_MFMA_PEAK_TF, "roofline_hbm_frac": gbs / HBM_PEAK_GBS,
+               "N_it_mean": float(io[:, 2].mean()), "N_grad_evaluated_mean": ng, "N_forward_rollouts_mean": nf}
+        if mlp == "f16":
+            f16_tf = f16_contraction_flops(c2, ng, nf) * Bl / (km * 1e-3) / 1e12
+            rec["matrix_pipe_use_f16"] = {"achieved": f16_tf, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": f16_tf / F16_MFMA_PEAK_TF,
+                                          "note": "NOT a roofline of this kernel: K = 6 and K = 32 contractions of a 32-wide MLP cannot fill the matrix pipe (under 2 % of the "
+                                                  "2.5 PFLOP/s dense f16 peak by construction); the kernel is bound by the f32 vector work beside them (roofline_frac)"}
+        if verify != 0:
+            if name.startswith("c5"):
+                # a full-length C5 solve takes the scalar oracle minutes: the SAME instances are solved once more with three iterations from a
+                # step size at which all three take steps (tests/test_gpu_parity.py::test_c5_full_size_solve_bit_exact) and that launch is checked;
+                # ONE full-length C5 solve per arithmetic is compared bit for bit by tests/tools/fullsize_parity.py (recorded under profiles/)
+                c3it = c2.replace(max_iter=3, max_no_improvement_iter=3)
+                s3 = SdeMpcSolver(c3it, bl, max_batch=Bl, device=dev_ord)
+                u3, x3, i3 = torch.empty_like(Lg.uopt), torch.empty_like(Lg.xevol), torch.empty_like(Lg.info)
+                st3 = torch.full((Bl,), 1e-11, dtype=torch.float32, device=dev)
+                s3.solve_dev(Bl, Lg.x0.data_ptr(), Lg.xref.data_ptr(), Lg.noise.data_ptr(), Lg.u0.data_ptr(), st3.data_ptr(), u3.data_ptr(), x3.data_ptr(), i3.data_ptr(), Lg.stream)
+                torch.cuda.synchronize()
+                V.add(name, c3it, bl, [Bl - 1], Lg.x0_h, Lg.xref_h, Lg.keys, Lg.u0_h, 1e-11, (u3.cpu().numpy(), x3.cpu().numpy(), i3.cpu().numpy()))
+                rec["verified_how"] = "3-iteration launch of the same instances (same kernel instantiation, step size 1e-11), last instance, bit for bit"
+                s3.close()
+            else:
+                vi = sample_indices(Bl, Lg.slots(), n_initial=1, n_drawn=1)
+                V.add(name, c2, bl, vi, Lg.x0_h, Lg.xref_h, Lg.keys, Lg.u0_h, Lg.s0, (uo, xo, io))
+                rec["verified_how"] = "the timed full-length launch, bit for bit"
+        others[name] = rec
+        Lg.close()
+    return others
+
+
+def tolerance_mode_legs(L, cfg, blob, dev_ord, uopt_h):
+    """The optional tolerance-parity mode on the same instances (a warm-up and a timed launch), never the reported value: solves/s and how
+    far its controls are from this run's bit-reproducible path (north star: 1e-4). SPEC.md 10, DESIGN.md 2."""
+    import torch
+    from sde4mbrl_px4_amd.solver import SdeMpcSolver
+    B = L.B
+    modes = {}
+    u2 = torch.empty_like(L.uopt); x2 = torch.empty_like(L.xevol); i2 = torch.empty_like(L.info)
+    for name, kw in (("math_mode_fast", dict(math_mode="fast")),):
+        s2 = SdeMpcSolver(cfg.replace(**kw), blob, max_batch=B, device=dev_ord)
+        for _ in range(2):                  # (a first launch of these kernels measured 7 % slow)
+            L.step(s2, (u2, x2, i2))
+            ms2 = s2.last_kernel_ms()
+        torch.cuda.synchronize()
+        du = np.abs(u2.cpu().numpy() - uopt_h).reshape(B, -1)
+        ok = np.all(du <= 1e-4 + 1e-4 * np.abs(uopt_h).reshape(B, -1), axis=1)
+        modes[name] = {"value": B / (ms2 * 1e-3), "unit": "solves/s", "kernel": s2.last_kernel_name(),
+                       "max_abs_du_vs_exact_median": float(np.median(du.max(axis=1))), "max_abs_du_vs_exact_worst": float(du.max()),
+                       "instances_within_1e-4_of_exact": float(ok.mean())}
+        s2.close()
+    return dict(modes, note="same instances, cold-start 200-iteration solves; controls against the bit-reproducible path of this run "
+                            "(abs + rel 1e-4, the north star's tolerance); optional mode without a CPU oracle, not the reported metric")

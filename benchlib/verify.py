@@ -1,0 +1,176 @@
+"""bench.py's CPU legs: the oracle (oracle/, test infrastructure) as the checker of timed launches and as the reported cpu_baseline. Nothing here runs
+inside a timed region, and nothing under sde4mbrl_px4_amd/ imports it."""
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def effective_cores():
+    """Host cores this process may actually use: min(os.cpu_count, affinity, cgroup v2 cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_oracle():
+    """The CPU restatement (oracle/, test infrastructure): bench.py touches it only in its CPU legs — as the checker of the
+    timed launch's outputs and as the reported cpu_baseline, never inside the timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    return orc
+
+
+def words_differ(a, b):
+    """f32 words whose bits differ (NaNs compared as a class: x86 and gfx950 produce different NaN signs, SPEC.md §3.7)."""
+    fa, fb = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    both_nan = np.isnan(fa) & np.isnan(fb)
+    return int(((fa.view(np.uint32) != fb.view(np.uint32)) & ~both_nan).sum())
+
+
+def sample_indices(B, slots, n_initial=4, n_drawn=6):
+    """Instances of a launch to verify: some of the teams' initial assignments, some that a persistent launch hands out by ticket
+    (b >= slots; evenly spread), and the last one."""
+    idx = list(range(min(n_initial, B)))
+    if B > slots + 1:
+        idx += [int(v) for v in np.linspace(slots, B - 2, n_drawn)]
+    if B - 1 not in idx:
+        idx.append(B - 1)
+    return sorted(set(idx))
+
+
+def cpu_solve_instances(cfg, model, n_threads, x0, xref, keys, u0, s0, fast=False, native=False):
+    """CPU leg, kind 'port': the C oracle (CPU restatement of SPEC.md) solves the given instances — instances of the GPU batch, noise
+    derived from the same threefry keys — one solve at a time per thread. fast=False: the bit-exact checker (what the GPU results are
+    compared with; native=True takes its -O3 -march=native build, same source and same bits); fast=True: the same source built as the
+    particle-vectorised timing build (oracle/Makefile: liborc_vec.so, 16 particles per call through GCC vector extensions, contraction
+    allowed: tolerance parity), the credible CPU timing. Returns (solves/s, wall s, outputs)."""
+    orc = cpu_oracle()
+    n = len(x0)
+    O = [orc.Oracle(cfg, model, vec=fast, fast=native and not fast) for _ in range(n_threads)]
+    P, H = cfg.num_particles, cfg.horizon
+    out = [None] * n
+    nxt = [0]
+    lock = threading.Lock()
+
+    def work(i):
+        while True:
+            with lock:
+                j = nxt[0]; nxt[0] += 1
+            if j >= n:
+                return
+            noise = orc.noise_from_key(keys[j], P, H)
+            out[j] = O[i].solve(x0[j], xref[j], noise, u0[j], s0)[:3]
+
+    t0 = time.time()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    [t.start() for t in th]; [t.join() for t in th]
+    dt = time.time() - t0
+    return n / dt, dt, out
+
+
+class Verifier:
+    """Background checker of timed launches: worker threads solve sampled instances with the CPU oracle (ctypes releases the GIL) while
+    the main thread goes on with the GPU legs; results are collected at the end. A worker that dies (an exception inside the oracle or
+    the comparison) is recorded: bench.py exits non-zero when any leg has fewer checked instances than it asked for."""
+
+    def __init__(self, n_threads):
+        self.jobs, self.results, self.lock = [], {}, threading.Lock()
+        self.n_threads, self.threads, self.t0 = max(1, n_threads), [], None
+        self.errors = []
+
+    def add(self, leg, cfg, blob, idx, x0, xref, keys, u0, s0, got):
+        """got: (uopt, xevol, info) host arrays of the WHOLE batch; idx: instances to check"""
+        with self.lock:
+            self.results.setdefault(leg, {"idx": [int(i) for i in idx], "bad_words": 0, "done": 0, "cpu_s": 0.0})
+            for i in idx:
+                self.jobs.append((leg, cfg, blob, int(i), x0[i], xref[i], keys[i], u0[i], s0, got[0][i].copy(), got[1][i].copy(), got[2][i].copy()))
+            if self.threads:
+                self.cv.notify_all()
+
+    def start(self):
+        """start the workers; jobs added later are picked up too, until close()"""
+        orc = cpu_oracle()
+        self.t0 = time.time()
+        self.cv, self.closed, self.nxt = threading.Condition(self.lock), False, 0
+        oracles = {}
+
+        def work(tid):
+            while True:
+                with self.cv:
+                    while self.nxt >= len(self.jobs) and not self.closed:
+                        self.cv.wait()
+                    if self.nxt >= len(self.jobs):
+                        return
+                    job = self.jobs[self.nxt]; self.nxt += 1
+                leg, cfg, blob, i, x0, xref, key, u0, s0, gu, gx, gi = job
+                try:
+                    with self.lock:
+                        O = oracles.get((tid, leg))
+                    if O is None:
+                        O = orc.Oracle(cfg, blob)                  # the bit-exact checker build the parity tests use
+                        with self.lock:
+                            oracles[(tid, leg)] = O
+                    t = time.time()
+                    noise = orc.noise_from_key(key, cfg.num_particles, cfg.horizon)
+                    uo, xe, io = O.solve(x0, xref, noise, u0, s0)[:3]
+                    bad = words_differ(gu, uo) + words_differ(gx, xe) + words_differ(gi, io)
+                    with self.lock:
+                        r = self.results[leg]; r["bad_words"] += bad; r["done"] += 1; r["cpu_s"] += time.time() - t
+                except Exception as e:       # the job stays "not done": bench.py reports the leg as unverified and exits non-zero
+                    with self.lock:
+                        self.errors.append(f"{leg}[{i}]: {type(e).__name__}: {e}")
+
+        self.threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(self.n_threads)]
+        [t.start() for t in self.threads]
+
+    def join(self):
+        """no more jobs: wait for the queue to drain"""
+        if not self.threads:
+            return 0.0
+        with self.cv:
+            self.closed = True
+            self.cv.notify_all()
+        [t.join() for t in self.threads]
+        return time.time() - self.t0 if self.t0 else 0.0
+
+    def incomplete(self):
+        """legs whose checked count is short of what was asked (a worker died)"""
+        return {leg: (r["done"], len(r["idx"])) for leg, r in self.results.items() if r["done"] != len(r["idx"])}
+
+
+def cpu_c1_single_solve_ms(model_blob, reps=3):
+    """BASELINE config 1 (Iris posctrl YAML, H=20, 32 particles, CPU path, single solve, no GPU): one thread, median wall time of a full
+    cold-start solve, by the particle-vectorised timing build and by the bit-exact scalar build."""
+    orc = cpu_oracle()
+    from sde4mbrl_px4_amd import load_mpc_config, prng
+    from sde4mbrl_px4_amd import workload as W
+    cfg = load_mpc_config(os.path.join(ROOT, "configs", "c1_iris_posctrl_h20_p32.yaml"))
+    x0 = W.random_initial_states(reps, 0)
+    keys = prng.split(prng.PRNGKey(10), reps)
+    u0 = np.tile(np.asarray(cfg.uref, np.float32)[None], (cfg.horizon, 1))
+    out = {}
+    for kind, O in (("vec", orc.Oracle(cfg, model_blob, vec=True)), ("scalar", orc.Oracle(cfg, model_blob))):
+        ms, nit = [], []
+        for r in range(reps):
+            noise = orc.noise_from_key(keys[r], cfg.num_particles, cfg.horizon)
+            xref = W.constant_reference(W.HOVER, cfg.horizon)
+            t = time.perf_counter()
+            _, _, info, _ = O.solve(x0[r], xref, noise, u0, cfg.ls_init_stepsize)
+            ms.append((time.perf_counter() - t) * 1e3)
+            nit.append(float(info[2]))
+        out[kind] = (float(np.median(ms)), float(np.mean(nit)))
+    return out, cfg

@@ -218,6 +218,7 @@ inline size_t smem_bytes(int H, int m, int ipb, bool coop = false, bool ust_lds 
 }
 
 // blob float payload offsets (SPEC.md §2)
+constexpr int OFF_SF = 40;     // sF[3], sT[3]
 constexpr int OFF_W1Z = 56, OFF_B1 = OFF_W1Z + 384, OFF_W1U = OFF_B1 + 64, OFF_W2 = OFF_W1U + 256, OFF_B2 = OFF_W2 + 1024,
               OFF_W3 = OFF_B2 + 32, OFF_B3 = OFF_W3 + 256, OFF_W3N = OFF_B3 + 8, OFF_B3N = OFF_W3N + 32;
 

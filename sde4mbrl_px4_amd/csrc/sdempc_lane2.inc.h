@@ -19,7 +19,9 @@
 //     disjoint halves of what LaneW keeps alive for the whole kernel: 125 registers, i.e. AGPR round trips inside the loops);
 //   * the adjoint's per-step outputs leave from the lanes that hold them (one store instead of eight, no read-lane round trip).
 // ================================================================================================
-constexpr int RC_T = 32, RC_DT = 36, RC_SDT = 40, RC_XR = 48;   // {Tz, tau[3]}, {dt, w_t, 0, 0}, sdt[6] + 2 pad, xref_{t+1}[13] + 3 pad
+// record: c_t[32] | -0 -0 Tz tau[3] | dt w_t | sdt[6] 2 pad | xref_{t+1}[13] 3 pad.   Elements 32 .. 37 are what lane c < 6 adds to its scaled MLP
+// output: F_b = (sF0 o0, sF1 o1, fma(sF2, o2, Tz)), tau_b = fma(sT_i, o_{3+i}, tau_i) — fma(s, o, -0) is s * o bit for bit
+constexpr int RC_Z = 32, RC_T = 34, RC_DT = 38, RC_SDT = 40, RC_XR = 48;
 // checkpoint row of the cooperative layouts, floats per (particle, step): h1[64] h2[64] | x_t[13] eta F_b[3] 1/|q~| q_{t+1}[4] R(q_t)[9] gx[13]
 // (COOP_ROW = 128 + 44, sdempc_kernels.hip)
 constexpr int CK_H1 = 0, CK_H2 = 64, CK_X = 128, CK_NU = 11;      // CK_NU float4 of uniform values behind the two activation rows
@@ -65,13 +67,14 @@ template <class Team>
 DI void lane2_stage(const KArgs& a, const Smem& sm, int b, int wgi, int tid) {
     const int H = a.H;
     for (int i = tid; i < H * 32; i += Team::NT) {
-        const int t = i >> 5, j = (i & 31) + 32;          // record element 32 .. 63 (32 .. 35 belong to the prepass)
+        const int t = i >> 5, j = (i & 31) + 32;          // record element 32 .. 63 (34 .. 37 belong to the prepass)
         float v = 0.0f;
-        if (j == RC_DT) v = sm.dt[t];
+        if (j < RC_T) v = -0.0f;
+        else if (j == RC_DT) v = sm.dt[t];
         else if (j == RC_DT + 1) v = sm.disc[t];
         else if (j >= RC_SDT && j < RC_SDT + NN) v = sm.sdt[t * NN + (j - RC_SDT)];
         else if (j >= RC_XR && j < RC_XR + NX) v = sm.xref[(t + 1) * NX + (j - RC_XR)];
-        if (j >= RC_DT) sm.rec[t * REC + j] = v;
+        if (j < RC_T || j >= RC_DT) sm.rec[t * REC + j] = v;
     }
     for (int i = tid; i < 4 * H * NZL; i += Team::NT) {
         const int w = i / (H * NZL), r = i - w * (H * NZL), t = r >> 3, c = r & 7, p = wgi * 4 + w;
@@ -102,13 +105,14 @@ DI void lane2_prepass(const KArgs& a, const Smem& sm, const float* u, int tid) {
             t1 = FMA(-a.M.rx[j], T, t1);
             t2 = t2 + Mq;
         }
-        *reinterpret_cast<float4*>(sm.rec + t * REC + RC_T) = make_float4(Tz, t0, t1, t2);
+        float* r = sm.rec + t * REC + RC_T;
+        r[0] = Tz; r[1] = t0; r[2] = t1; r[3] = t2;
     }
 }
 
 // ---- weights of one sweep, from the LDS images load_weights staged (f32 mode: A2 / A2T hold W2 / W2^T in MFMA lane order) ----
 struct L2FwdW {
-    float w1[NN], c1n, b2k, w2row[HID], wo[16], bo;
+    float w1[NN], c1n, b2k, w2row[HID], wo[16], bo, so;      // bo / so: bias and residual scale (sF, sT) of this lane's output chain
     int obase;
 };
 struct L2AdjW {
@@ -147,6 +151,8 @@ DI void lane2_load_fwd(const KArgs& a, const Smem& sm, L2FwdW& W, int lane) {
     }
     const float bv = a.wts[lane < 6 ? OFF_B3 + lane : OFF_B3N];       // (every lane loads: no divergent region)
     W.bo = lane <= 6 ? bv : 0.0f;
+    const float sv = a.wts[OFF_SF + (lane < 6 ? lane : 0)];           // sF[3], sT[3] (SPEC.md §2)
+    W.so = lane < 6 ? sv : 0.0f;
 }
 DI void lane2_load_adj(const KArgs& a, const Smem& sm, L2AdjW& W, int lane) {
     const int k = lane & 31;
@@ -171,8 +177,9 @@ DI void lane2_load_adj(const KArgs& a, const Smem& sm, L2AdjW& W, int lane) {
     }
 }
 
-// forward MLPs of one step (lane_fwd_mlp with the sweep's own weights; ck: c_t[k] of this lane's drift unit)
-DI void lane2_fwd_mlp(const L2FwdW& W, const LaneSel& ls, int hh, float ck, const float* z, float& h1, float& h2, float* o, float& eta) {
+// forward MLPs of one step (lane_fwd_mlp with the sweep's own weights; ck: c_t[k] of this lane's drift unit; zt: what lane c < 6 adds to its
+// scaled output, RC_Z + c of the record). ft[0..2] = F_b, ft[3..5] = tau_b
+DI void lane2_fwd_mlp(const L2FwdW& W, const LaneSel& ls, int hh, float ck, float zt, const float* z, float& h1, float& h2, float* ft, float& eta) {
     float a1 = hh ? W.c1n : ck;
 #pragma unroll
     for (int j = 0; j < NN; ++j) a1 = FMA(W.w1[j], z[j], a1);
@@ -196,8 +203,9 @@ DI void lane2_fwd_mlp(const L2FwdW& W, const LaneSel& ls, int hh, float ck, cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) P = FMA(W.wo[r], gsrc[r], P);
     const float Pc = (P + dpp_f<0x128>(P)) + W.bo;   // row_ror:8 -> lane c: (P_0 + P_1) + bias of its chain
+    const float S = FMA(W.so, Pc, zt);               // lanes 0 .. 2: F_b, lanes 3 .. 5: tau_b (SPEC.md §5.2)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) o[i] = readlane_f(Pc, i);
+    for (int i = 0; i < 6; ++i) ft[i] = readlane_f(S, i);
     eta = sigmoid_spec(readlane_f(Pc, 6));
 }
 
@@ -238,12 +246,13 @@ DI float lane2_vjp_mlp(const L2AdjW& W, int hh, float h1, float h2, const VjpTmp
 }
 
 // the constants of step t, from its record
-struct StepK { float tz[4], dt, wt, sdt[NN], xr[NX], xi[NN]; };
+struct StepK { float dt, wt, sdt[NN], xr[NX], xi[NN]; };
+DI float2 lds2(const float* p) { return *reinterpret_cast<const float2*>(p); }
 DI void lane2_step_consts(const float* rp, const float* np, StepK& K) {
-    const float4 t4 = lds4(rp + RC_T), d4 = lds4(rp + RC_DT), s4 = lds4(rp + RC_SDT), s5 = lds4(rp + RC_SDT + 4);
+    const float2 d4 = lds2(rp + RC_DT);
+    const float4 s4 = lds4(rp + RC_SDT), s5 = lds4(rp + RC_SDT + 4);
     const float4 x0 = lds4(rp + RC_XR), x1 = lds4(rp + RC_XR + 4), x2 = lds4(rp + RC_XR + 8), x3 = lds4(rp + RC_XR + 12);
     const float4 n0 = lds4(np), n1 = lds4(np + 4);
-    K.tz[0] = t4.x; K.tz[1] = t4.y; K.tz[2] = t4.z; K.tz[3] = t4.w;
     K.dt = d4.x; K.wt = d4.y;
     K.sdt[0] = s4.x; K.sdt[1] = s4.y; K.sdt[2] = s4.z; K.sdt[3] = s4.w; K.sdt[4] = s5.x; K.sdt[5] = s5.y;
     K.xr[0] = x0.x; K.xr[1] = x0.y; K.xr[2] = x0.z; K.xr[3] = x0.w; K.xr[4] = x1.x; K.xr[5] = x1.y; K.xr[6] = x1.z; K.xr[7] = x1.w;
@@ -277,15 +286,17 @@ DI void lane2_rollout(const KArgs& a, const Smem& sm, const Lane2Lds& L, const L
     StepAux A;
     const float* rp = L.rec;
     const float* rk = L.rec + (lane & 31);
+    const float* rz = L.rec + RC_Z + (lane < 6 ? lane : 0);
     const float* np = L.nz;
     for (int t = 0; t < H; ++t) {
-        const float ck = *rk;
+        const float ck = *rk, zt = *rz;
         StepK K;
         lane2_step_consts(rp, np, K);
-        float z[NN], h1, h2, o[6], eta, xn[NX];
+        float z[NN], h1, h2, ft[6], eta, xn[NX];
         fwd_head(x, A.Rm, z);
-        lane2_fwd_mlp(W, ls, hh, ck, z, h1, h2, o, eta);
-        fwd_tail_v(a, K.dt, K.tz, K.sdt, x, K.xi, A.Rm, o, eta, xn, A);
+        lane2_fwd_mlp(W, ls, hh, ck, zt, z, h1, h2, ft, eta);
+        A.Fb[0] = ft[0]; A.Fb[1] = ft[1]; A.Fb[2] = ft[2];
+        fwd_tail_ft(a, K.dt, ft + 3, K.sdt, x, K.xi, A.Rm, eta, xn, A);
         float l = stage_cost<false, false>(a, xn, K.xr, nullptr);
         l = FMA(a.C.res_mult * A.eta, A.eta, l);
         J = FMA(K.wt, l, J);
@@ -295,7 +306,7 @@ DI void lane2_rollout(const KArgs& a, const Smem& sm, const Lane2Lds& L, const L
 #pragma unroll
             for (int i = 0; i < NX; ++i) store_sc1_masked(1ull, io.out + (size_t)((t + 1) * NX + i) * io.os, x[i]);
         }
-        rp += REC; rk += REC; np += NZL;
+        rp += REC; rk += REC; rz += REC; np += NZL;
     }
     store_sc1_masked(1ull, io.out + (size_t)(PS - 1) * io.os, J);
 }
@@ -325,17 +336,19 @@ DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane
         float J = 0.0f;
         const float* rp = L.rec;
         const float* rk = L.rec + (lane & 31);
+        const float* rz = L.rec + RC_Z + (lane < 6 ? lane : 0);
         const float* np = L.nz;
         float* row = io.ck;
         auto fstep = [&](const float (&x)[NX], float (&xn)[NX]) {
-            const float ck = *rk;
+            const float ck = *rk, zt = *rz;
             StepK K;
             lane2_step_consts(rp, np, K);
             StepAux A;
-            float z[NN], h1, h2, o[6], eta, gx[NX];
+            float z[NN], h1, h2, ft[6], eta, gx[NX];
             fwd_head(x, A.Rm, z);
-            lane2_fwd_mlp(W, ls, hh, ck, z, h1, h2, o, eta);
-            fwd_tail_v(a, K.dt, K.tz, K.sdt, x, K.xi, A.Rm, o, eta, xn, A);
+            lane2_fwd_mlp(W, ls, hh, ck, zt, z, h1, h2, ft, eta);
+            A.Fb[0] = ft[0]; A.Fb[1] = ft[1]; A.Fb[2] = ft[2];
+            fwd_tail_ft(a, K.dt, ft + 3, K.sdt, x, K.xi, A.Rm, eta, xn, A);
             float l = stage_cost<true, false>(a, xn, K.xr, gx);
             l = FMA(a.C.res_mult * A.eta, A.eta, l);
             J = FMA(K.wt, l, J);
@@ -345,7 +358,7 @@ DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane
                                  {A.Fb[2], A.rn, A.qn[0], A.qn[1]}, {A.qn[2], A.qn[3], A.Rm[0], A.Rm[1]}, {A.Rm[2], A.Rm[3], A.Rm[4], A.Rm[5]},
                                  {A.Rm[6], A.Rm[7], A.Rm[8], gx[0]}, {gx[1], gx[2], gx[3], gx[4]}, {gx[5], gx[6], gx[7], gx[8]}, {gx[9], gx[10], gx[11], gx[12]}};
             store_row_uniform(row, u);
-            rp += REC; rk += REC; np += NZL; row += COOP_ROW;
+            rp += REC; rk += REC; rz += REC; np += NZL; row += COOP_ROW;
         };
         int t = 0;
         for (; t + 1 < H; t += 2) { fstep(xa, xb); fstep(xb, xa); }
@@ -368,7 +381,8 @@ DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane
     auto step = [&](int t, const AdjRow& R) {
         const float* rp = L.rec + t * REC;
         const float* np = L.nz + t * NZL;
-        const float4 d4 = lds4(rp + RC_DT), s4 = lds4(rp + RC_SDT), s5 = lds4(rp + RC_SDT + 4), n0 = lds4(np), n1 = lds4(np + 4);
+        const float2 d4 = lds2(rp + RC_DT);
+        const float4 s4 = lds4(rp + RC_SDT), s5 = lds4(rp + RC_SDT + 4), n0 = lds4(np), n1 = lds4(np + 4);
         const float dt = d4.x, dsc = d4.y;
         const float sdt[NN] = {s4.x, s4.y, s4.z, s4.w, s5.x, s5.y}, xi[NN] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y};
         const float4* u = R.u;

@@ -196,11 +196,10 @@ DI void fwd_mlp_tiles(const KArgs& a, const Smem& sm, const WaveW& ww, const flo
 
 // ---- uniform tail of a step: rigid body, Euler-Maruyama update, quaternion renormalisation ----
 // (the _v forms take the step's constants as values / pointers of the caller's choice: tz = {Tz, tau0, tau1, tau2}, sdt = sigma_i sqrt(dt_t))
-DI void fwd_tail_v(const KArgs& a, const float dt, const float* tz, const float* sdt, const float* x, const float* xi, const float* Rm, const float* o, float eta, float* xn, StepAux& A) {
+// (_ft: body force A.Fb and body torque taub already formed by the caller — the lane layouts scale the MLP outputs in the lanes that hold them)
+DI void fwd_tail_ft(const KArgs& a, const float dt, const float* taub, const float* sdt, const float* x, const float* xi, const float* Rm, float eta, float* xn, StepAux& A) {
     const float qw = x[6], qx = x[7], qy = x[8], qz = x[9];
     A.eta = eta;
-    // rigid body
-    A.Fb[0] = a.M.sF[0] * o[0]; A.Fb[1] = a.M.sF[1] * o[1]; A.Fb[2] = FMA(a.M.sF[2], o[2], tz[0]);
     float acc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -208,9 +207,8 @@ DI void fwd_tail_v(const KArgs& a, const float dt, const float* tz, const float*
         acc[i] = Fw * a.M.inv_mass;
     }
     acc[2] = acc[2] - a.M.grav;
-    float taub[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { taub[i] = FMA(a.M.sT[i], o[3 + i], tz[1 + i]); A.Jom[i] = a.M.J[i] * x[10 + i]; }
+    for (int i = 0; i < 3; ++i) A.Jom[i] = a.M.J[i] * x[10 + i];
     float cr[3];
     cr[0] = FMA(x[11], A.Jom[2], -(x[12] * A.Jom[1]));
     cr[1] = FMA(x[12], A.Jom[0], -(x[10] * A.Jom[2]));
@@ -236,6 +234,13 @@ DI void fwd_tail_v(const KArgs& a, const float dt, const float* tz, const float*
     if constexpr (FAST) A.rn = __builtin_amdgcn_rsqf(n2); else A.rn = rsqrt_spec(n2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { A.qn[i] = qt[i] * A.rn; xn[6 + i] = A.qn[i]; }
+}
+DI void fwd_tail_v(const KArgs& a, const float dt, const float* tz, const float* sdt, const float* x, const float* xi, const float* Rm, const float* o, float eta, float* xn, StepAux& A) {
+    A.Fb[0] = a.M.sF[0] * o[0]; A.Fb[1] = a.M.sF[1] * o[1]; A.Fb[2] = FMA(a.M.sF[2], o[2], tz[0]);
+    float taub[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) taub[i] = FMA(a.M.sT[i], o[3 + i], tz[1 + i]);
+    fwd_tail_ft(a, dt, taub, sdt, x, xi, Rm, eta, xn, A);
 }
 DI void fwd_tail(const KArgs& a, const Smem& sm, const float* ust, int t, const float* x, const float* xi, const float* Rm, const float* o, float eta, float* xn, StepAux& A) {
     fwd_tail_v(a, sm.dt[t], ust + 32, sm.sdt + t * NN, x, xi, Rm, o, eta, xn, A);

@@ -8,16 +8,15 @@ child processes (rendezvous on 127.0.0.1), relays rank 0's JSON line and exits w
 A "step" = one launch of the solve kernel over one batch of B independent MPC problem instances per GPU
 (synthetic initial states; inputs already resident in HBM). Weak scaling: B per GPU is fixed, instances are
 sharded one batch per GPU with no data-path collective; rank 0 broadcasts the shared model blob once over RCCL
-at start-up. Rank 0 prints ONE JSON line. The timed launch's outputs of the first instances are compared bit for
+at start-up. Rank 0 prints ONE JSON line. The timed launch's outputs of sampled instances are compared bit for
 bit with the CPU oracle solving the same instances (verified_instances / verified_bit_exact in the line).
+
+This file: argument parsing, the timed leg, the JSON line. The pieces live in benchlib/ (counts, verify, power, ranks, legs).
 """
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
-import threading
 import time
 
 import numpy as np
@@ -25,203 +24,30 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-F32_MFMA_PEAK_TF = 157.3     # dense f32-input MFMA peak (= f32 vector peak), same guide
-
-
-def algorithmic_counts(cfg, n_it, n_ls):
-    """SURVEY.md §8(d) per-solve algorithmic bytes and flops (n_w = 6 noisy dims, f32)."""
-    P, H, m = cfg.num_particles, cfg.horizon, cfg.num_motors
-    nw = 6
-    b_grad = 4 * (P * H * nw + 2 * P * (H + 1) * 13 + P * H * nw + 2 * H * m + (H + 1) * 13)
-    b_ls = 4 * (P * H * nw + H * m + (H + 1) * 13)
-    w_bytes = 4 * 2120
-    # init-cost rollout and final mean-trajectory rollout are forward-only passes too
-    bytes_solve = n_it * b_grad + (n_ls + 2) * b_ls + w_bytes
-    f_step = 2 * ((6 + m) * 32 + 32 * 32 + 32 * 6) + 2 * (6 * 32 + 32 * 1)   # drift + density nets, forward
-    flops_solve = f_step * P * H * (2 * n_it + n_ls + 2)
-    return bytes_solve, flops_solve, b_grad, b_ls
-
-
-def checkpoint_bytes(cfg, n_it):
-    """Implementation stream on top of the algorithmic bytes: the gradient's forward sweep checkpoints the
-    layer-2 activations + 5 step scalars per particle-step (1280 floats per 32-particle group and step),
-    written once and read once per gradient evaluation."""
-    G = (cfg.num_particles + 31) // 32
-    return int(n_it * 2 * G * cfg.horizon * 1280 * 4)
-
-
-def effective_cores():
-    """Host cores this process may actually use: min(os.cpu_count, affinity, cgroup v2 cpu.max quota)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return n
-
-
-def cpu_oracle():
-    """The CPU restatement (oracle/, test infrastructure): bench.py touches it only in its CPU legs below — as the checker of the
-    timed launch's outputs and as the reported cpu_baseline, never inside the timed region."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import orc
-    return orc
-
-
-def cpu_solve_instances(cfg, model, n_threads, x0, xref, keys, u0, s0, fast=False, native=False):
-    """CPU leg, kind 'port': the C oracle (CPU restatement of SPEC.md) solves the given instances — instances of the GPU batch, noise
-    derived from the same threefry keys — one solve at a time per thread. fast=False: the bit-exact checker (what the GPU results are
-    compared with; native=True takes its -O3 -march=native build, same source and same bits); fast=True: the same source built as the
-    particle-vectorised timing build (oracle/Makefile: liborc_vec.so, 16 particles per call through GCC vector extensions, contraction
-    allowed: tolerance parity), the credible CPU timing. Returns (solves/s, wall s, outputs)."""
-    orc = cpu_oracle()
-    n = len(x0)
-    O = [orc.Oracle(cfg, model, vec=fast, fast=native and not fast) for _ in range(n_threads)]
-    P, H = cfg.num_particles, cfg.horizon
-    out = [None] * n
-    nxt = [0]
-    lock = threading.Lock()
-
-    def work(i):
-        while True:
-            with lock:
-                j = nxt[0]; nxt[0] += 1
-            if j >= n:
-                return
-            noise = orc.noise_from_key(keys[j], P, H)
-            out[j] = O[i].solve(x0[j], xref[j], noise, u0[j], s0)[:3]
-
-    t0 = time.time()
-    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
-    [t.start() for t in th]; [t.join() for t in th]
-    dt = time.time() - t0
-    return n / dt, dt, out
-
-
-class Verifier:
-    """Background checker of timed launches: worker threads solve sampled instances with the CPU oracle (ctypes releases the GIL) while
-    the main thread goes on with the GPU legs; results are collected at the end. Test infrastructure on the checker side only."""
-
-    def __init__(self, n_threads):
-        self.jobs, self.results, self.lock = [], {}, threading.Lock()
-        self.n_threads, self.threads, self.t0 = max(1, n_threads), [], None
-
-    def add(self, leg, cfg, blob, idx, x0, xref, keys, u0, s0, got):
-        """got: (uopt, xevol, info) host arrays of the WHOLE batch; idx: instances to check"""
-        with self.lock:
-            self.results.setdefault(leg, {"idx": [int(i) for i in idx], "bad_words": 0, "done": 0, "cpu_s": 0.0})
-            for i in idx:
-                self.jobs.append((leg, cfg, blob, int(i), x0[i], xref[i], keys[i], u0[i], s0, got[0][i].copy(), got[1][i].copy(), got[2][i].copy()))
-            if self.threads:
-                self.cv.notify_all()
-
-    def start(self):
-        """start the workers; jobs added later are picked up too, until close()"""
-        orc = cpu_oracle()
-        self.t0 = time.time()
-        self.cv, self.closed, self.nxt = threading.Condition(self.lock), False, 0
-        oracles = {}
-
-        def work(tid):
-            while True:
-                with self.cv:
-                    while self.nxt >= len(self.jobs) and not self.closed:
-                        self.cv.wait()
-                    if self.nxt >= len(self.jobs):
-                        return
-                    job = self.jobs[self.nxt]; self.nxt += 1
-                leg, cfg, blob, i, x0, xref, key, u0, s0, gu, gx, gi = job
-                with self.lock:
-                    O = oracles.get((tid, leg))
-                if O is None:
-                    O = orc.Oracle(cfg, blob)                  # the bit-exact checker build the parity tests use
-                    with self.lock:
-                        oracles[(tid, leg)] = O
-                t = time.time()
-                noise = orc.noise_from_key(key, cfg.num_particles, cfg.horizon)
-                uo, xe, io = O.solve(x0, xref, noise, u0, s0)[:3]
-                bad = words_differ(gu, uo) + words_differ(gx, xe) + words_differ(gi, io)
-                with self.lock:
-                    r = self.results[leg]; r["bad_words"] += bad; r["done"] += 1; r["cpu_s"] += time.time() - t
-
-        self.threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(self.n_threads)]
-        [t.start() for t in self.threads]
-
-    def join(self):
-        """no more jobs: wait for the queue to drain"""
-        if not self.threads:
-            return 0.0
-        with self.cv:
-            self.closed = True
-            self.cv.notify_all()
-        [t.join() for t in self.threads]
-        return time.time() - self.t0 if self.t0 else 0.0
-
-
-class PowerSampler(threading.Thread):
-    """Shader clock and package power of one GPU, sampled once a second beside the timed launches (`rocm-smi` as a child process: no
-    HIP context, nothing on the launch path). The C2 throughput launch runs the package AT ITS POWER CAP (profiles/r3_power.txt): the
-    figure that explains the clock the kernel is held at. Any failure (no rocm-smi, unexpected output) leaves the fields null."""
-    def __init__(self, dev_ord):
-        super().__init__(daemon=True)
-        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
-        try:
-            self.idx = int(vis.split(",")[dev_ord]) if vis else dev_ord
-        except Exception:
-            self.idx = dev_ord
-        self.samples, self.stop_flag, self.cap = [], threading.Event(), None
-
-    def _smi(self, *flags):
-        import re
-        r = subprocess.run(["rocm-smi", "-d", str(self.idx), *flags], capture_output=True, text=True, timeout=15)
-        return r.stdout, re
-
-    def run(self):
-        try:
-            txt, re = self._smi("--showmaxpower")
-            m = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", txt)
-            self.cap = float(m.group(1)) if m else None
-            while not self.stop_flag.wait(1.0):
-                t = time.perf_counter()
-                txt, re = self._smi("--showpower", "--showclocks")
-                mp = re.search(r"Package Power \(W\): ([\d.]+)", txt)
-                mc = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
-                if mp and mc:
-                    self.samples.append((t, float(mc.group(1)), float(mp.group(1))))
-        except Exception:
-            pass
-
-    def summary(self, t0, t1):
-        self.stop_flag.set()
-        sel = [(c, w) for t, c, w in self.samples if t0 + 1.0 <= t <= t1]
-        if not sel:
-            return {"package_power_w_median": None, "sclk_mhz_median": None, "power_cap_w": self.cap, "samples": 0,
-                    "note": "rocm-smi gave no sample inside the timed region"}
-        return {"package_power_w_median": float(np.median([w for _, w in sel])), "sclk_mhz_median": float(np.median([c for c, _ in sel])),
-                "power_cap_w": self.cap, "samples": len(sel),
-                "note": "rank 0's GPU, one rocm-smi sample per second inside the timed region (performance level auto): at the cap the firmware lowers the shader "
-                        "clock (2.4 GHz maximum) until the package fits — solves/s = cap / energy per solve"}
-
-
-def sample_indices(B, slots, n_initial=4, n_drawn=6):
-    """Instances of a launch to verify: some of the teams' initial assignments, some that a persistent launch hands out by ticket
-    (b >= slots; evenly spread), and the last one."""
-    idx = list(range(min(n_initial, B)))
-    if B > slots + 1:
-        idx += [int(v) for v in np.linspace(slots, B - 2, n_drawn)]
-    if B - 1 not in idx:
-        idx.append(B - 1)
-    return sorted(set(idx))
-
+from benchlib.counts import F32_MFMA_PEAK_TF, HBM_PEAK_GBS, checkpoint_bytes, roofline_of      # noqa: E402
+from benchlib.ranks import spawn_ranks      # noqa: E402
+from benchlib.verify import Verifier, cpu_c1_single_solve_ms, cpu_solve_instances, effective_cores, sample_indices      # noqa: E402
 
 _T0 = time.perf_counter()
+_REAL_STDOUT = None
+
+
+def own_stdout():
+    """The driver parses ONE JSON line from rank 0's stdout, and libraries below us write there too (gloo: "[Gloo] Rank 0 is connected to ..."):
+    from here on file descriptor 1 points at stderr and only emit() writes to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
 
 
 def progress(msg):
@@ -236,153 +62,37 @@ def lib_hash():
     return hashlib.sha256(open(_abi.lib_path(), "rb").read()).hexdigest()[:16]
 
 
-def words_differ(a, b):
-    """f32 words whose bits differ (NaNs compared as a class: x86 and gfx950 produce different NaN signs, SPEC.md §3.7)."""
-    fa, fb = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
-    both_nan = np.isnan(fa) & np.isnan(fb)
-    return int(((fa.view(np.uint32) != fb.view(np.uint32)) & ~both_nan).sum())
-
-
-def cpu_c1_single_solve_ms(model_blob, reps=3):
-    """BASELINE config 1 (Iris posctrl YAML, H=20, 32 particles, CPU path, single solve, no GPU): one thread, median wall time of a full
-    cold-start solve, by the particle-vectorised timing build and by the bit-exact scalar build."""
-    orc = cpu_oracle()
-    from sde4mbrl_px4_amd import load_mpc_config, prng
-    from sde4mbrl_px4_amd import workload as W
-    cfg = load_mpc_config(os.path.join(ROOT, "configs", "c1_iris_posctrl_h20_p32.yaml"))
-    x0 = W.random_initial_states(reps, 0)
-    keys = prng.split(prng.PRNGKey(10), reps)
-    u0 = np.tile(np.asarray(cfg.uref, np.float32)[None], (cfg.horizon, 1))
-    out = {}
-    for kind, O in (("vec", orc.Oracle(cfg, model_blob, vec=True)), ("scalar", orc.Oracle(cfg, model_blob))):
-        ms, nit = [], []
-        for r in range(reps):
-            noise = orc.noise_from_key(keys[r], cfg.num_particles, cfg.horizon)
-            xref = W.constant_reference(W.HOVER, cfg.horizon)
-            t = time.perf_counter()
-            _, _, info, _ = O.solve(x0[r], xref, noise, u0, cfg.ls_init_stepsize)
-            ms.append((time.perf_counter() - t) * 1e3)
-            nit.append(float(info[2]))
-        out[kind] = (float(np.median(ms)), float(np.mean(nit)))
-    return out, cfg
-
-
-def spawn_ranks(n, argv):
-    """`bench.py --gpus N` without a launcher: start the N ranks as children (nothing in this process has touched the GPU), relay
-    rank 0's output, return the worst child's return code. Rendezvous on 127.0.0.1 with a free port."""
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    # rank 0's stdout is drained by a thread so that the parent can watch every child: a rank that dies (no GPU for it, bad install)
-    # would otherwise leave the others waiting in the rendezvous / a barrier until the collective timeout
-    chunks = []
-    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    rd.start()
-    failed = 0
-    while any(p.poll() is None for p in procs):
-        bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
-        if bad:
-            failed = abs(bad[0]) or 1
-            for p in procs:             # exactly the children started above
-                if p.poll() is None:
-                    p.terminate()
-            for p in procs:
-                try:
-                    p.wait(timeout=20)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        time.sleep(0.2)
-    rd.join(timeout=10)
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(b"".join(chunks).decode())
-    sys.stdout.flush()
-    return failed or max(abs(rc) for rc in rcs)
-
-
 DEFAULT_MLP = "f32x3"      # the reported arithmetic: f32 operands and accumulation, layer-2 contractions as three-limb bf16 splits (SPEC.md 9b)
 
 DTYPE_NOTE = {
     "f32": "f32",
     "f32x3": "f32 (state, accumulation and every operand f32; the two 32x32 MLP contractions per step evaluated as three-limb bf16 splits of "
-             "both f32 operands on v_mfma_f32_32x32x16_bf16: error against float64 not larger than the f32 fma chain's, bit-identical to the CPU oracle)",
+             "both f32 operands on v_mfma_f32_32x32x16_bf16: error against float64 not larger than the f32 fma chain's "
+             "(tests/test_mfma16_model_cpu.py), bit-identical to the CPU oracle)",
     "f16": "f16 MLP operands / f32 accumulate and state",
 }
 
 
-class Leg:
-    """One workload on this rank's GPU: solver + device-resident inputs and outputs."""
-
-    def __init__(self, cfg, blob, B, dev_ord, rank=0, world=1, pos=False):
-        import torch
-        from sde4mbrl_px4_amd import prng
-        from sde4mbrl_px4_amd import workload as W
-        from sde4mbrl_px4_amd.solver import SdeMpcSolver
-        self.cfg, self.blob, self.B = cfg, blob, B
-        H, P, m = cfg.horizon, cfg.num_particles, cfg.num_motors
-        dev = torch.device("cuda", dev_ord)
-        self.solver = SdeMpcSolver(cfg, blob, max_batch=B, device=dev_ord)
-        self.x0_h = W.random_initial_states(B, rank * B)
-        self.xref_h = np.stack([W.constant_reference(W.HOVER, H) if pos else W.reference_window(0.05 * (b % 160), cfg.time_steps) for b in range(B)])
-        # noise: drawn on the device from per-instance threefry keys (SPEC.md 7; the m_mpc path), launch seed 10 (iris_sdectrl.launch:8)
-        self.keys = prng.split(prng.PRNGKey(10), world * B)[rank * B:(rank + 1) * B]
-        yk, info0 = self.solver.reset()
-        self.u0_h = np.tile(yk[None], (B, 1, 1))
-        self.s0 = float(info0["stepsize"])
-        self.stream = torch.cuda.current_stream().cuda_stream
-        self.x0 = torch.from_numpy(self.x0_h).to(dev)
-        self.xref = torch.from_numpy(self.xref_h).to(dev)
-        self.noise = torch.empty(self.solver.lib.sdempc_noise_dev_floats(self.solver._h, B), dtype=torch.float32, device=dev)
-        self.solver.noise_from_keys_dev(self.keys, self.noise.data_ptr(), self.stream)
-        self.u0 = torch.from_numpy(self.u0_h).to(dev)
-        self.step_in = torch.full((B,), self.s0, dtype=torch.float32, device=dev)
-        self.uopt = torch.empty((B, H, m), dtype=torch.float32, device=dev)
-        self.xevol = torch.empty((B, H + 1, 13), dtype=torch.float32, device=dev)
-        self.info = torch.empty((B, 8), dtype=torch.float32, device=dev)
-
-    def step(self, solver=None, out=None):
-        u, x, i = out or (self.uopt, self.xevol, self.info)
-        (solver or self.solver).solve_dev(self.B, self.x0.data_ptr(), self.xref.data_ptr(), self.noise.data_ptr(), self.u0.data_ptr(),
-                                          self.step_in.data_ptr(), u.data_ptr(), x.data_ptr(), i.data_ptr(), self.stream)
-
-    def timed_events(self, reps):
-        """reps launches timed one by one with HIP events on the launch stream; returns (ms list, work counters per solve)"""
-        import torch
-        torch.cuda.synchronize()
-        self.solver.work_counters(reset=True)
-        ms = []
-        for _ in range(reps):
-            self.step()
-            ms.append(self.solver.last_kernel_ms())
-        torch.cuda.synchronize()
-        self.solver.solve_status()
-        w_solves, w_grads, w_fwd = self.solver.work_counters()
-        if w_solves != self.B * reps:
-            raise SystemExit(f"bench.py: {w_solves} solves counted on the device for {reps} launches of {self.B} instances")
-        return ms, w_grads / max(w_solves, 1), w_fwd / max(w_solves, 1)
-
-    def host_outputs(self):
-        return self.uopt.cpu().numpy(), self.xevol.cpu().numpy(), self.info.cpu().numpy()
-
-    def slots(self):
-        return 6 * self.solver.get_option("device_cus")
-
-    def close(self):
-        self.solver.close()
-
-
-def roofline_of(cfg, B, k_ms, n_grad, n_fwd, kernel_name):
-    bytes_solve, flops_solve, b_grad, b_ls = algorithmic_counts(cfg, n_grad, n_fwd - 2)
-    ach_gbs = bytes_solve * B / (k_ms * 1e-3) / 1e9
-    ach_tf = flops_solve * B / (k_ms * 1e-3) / 1e12
-    return ach_tf, ach_gbs, bytes_solve, b_grad, b_ls
+def dry_run(args, rank, world):
+    """SDEMPC_BENCH_DRY=1 (tests, no GPU): the rank plumbing of an N-rank run — rendezvous, blob broadcast, all-reduce MAX, barriers — over gloo on
+    the CPU, then one JSON line from rank 0. SDEMPC_BENCH_FAIL_RANK=r makes rank r fail before the rendezvous (what a rank without a usable GPU does)."""
+    import torch.distributed as dist
+    from sde4mbrl_px4_amd import synthetic_iris
+    from sde4mbrl_px4_amd.dist import broadcast_blob, max_over_ranks, max_over_ranks_each
+    if os.environ.get("SDEMPC_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(f"bench.py: rank {rank}: simulated start-up failure (SDEMPC_BENCH_FAIL_RANK)")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blob = synthetic_iris().to_blob() if rank == 0 else b""
+    blob = broadcast_blob(blob, src=0)
+    dist.barrier()
+    slowest = max_over_ranks(1.0 + rank)
+    ticks = max_over_ranks_each([float(rank), float("inf") if rank == world - 1 else 0.5])
+    dist.barrier()
+    if rank == 0:
+        emit({"dry_run": True, "n_gpus": world, "blob_bytes": len(blob), "max_over_ranks": slowest, "ticks": [t if np.isfinite(t) else None for t in ticks]})
+    dist.destroy_process_group()
 
 
 def main():
@@ -403,7 +113,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=0, help="override the YAML's apg_mpc.max_iter (0: keep; profiling runs of the long-horizon config)")
     ap.add_argument("--no-tolerance-modes", action="store_true", help="skip the extra launches in the tolerance-parity mode (math_mode: fast)")
     ap.add_argument("--c4-reps", type=int, default=100, help="N > 1: barrier-aligned ticks of the one-instance-per-GPU leg (BASELINE config 4); 0 skips it")
-    ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (package power, shader clock) beside the timed launches")
+    ap.add_argument("--no-power", action="store_true", help="do not sample package power / shader clock beside the timed launches")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary legs (C2 f32 chain, C3, C5 f32 / f16)")
     ap.add_argument("--verify", type=int, default=-1, help="instances of the timed launch checked bit for bit against the CPU oracle "
                     "(-1: a sample across the batch incl. ticket-drawn instances; 0: none)")
@@ -411,19 +121,25 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # self-start: this process never touches the GPU (no torch.cuda / HIP call has been made yet)
-        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
-
-    import torch
-    import torch.distributed as dist
-    from sde4mbrl_px4_amd import load_mpc_config, synthetic_hexa, synthetic_iris
+        raise SystemExit(spawn_ranks(args.gpus, __file__, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    own_stdout()
+    if os.environ.get("SDEMPC_BENCH_DRY") == "1":
+        return dry_run(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+    from benchlib.legs import Leg, config4_leg, latency_of, other_config_legs, tolerance_mode_legs
+    from benchlib.power import PowerSampler
+    from sde4mbrl_px4_amd import load_mpc_config, synthetic_hexa, synthetic_iris
+
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        raise SystemExit(f"bench.py: rank {rank} needs a GPU: the product path has no CPU fallback")
     # test hooks (single-GPU boxes): SDEMPC_BENCH_DEVICE pins every rank to one ordinal, SDEMPC_BENCH_BACKEND=gloo replaces RCCL,
     # SDEMPC_BENCH_FORCE_DIST=1 initialises the process group even for one rank (the RCCL branch — init, device-tensor broadcast, all-reduce,
     # barrier, destroy — then runs on a one-GPU box); the driver's multi-GPU runs use none of them (one GPU per rank, backend nccl = RCCL over xGMI)
@@ -436,10 +152,13 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        except Exception as e:      # named on this rank's stderr; the self-starting parent quotes it in its summary line (benchlib/ranks.py)
+            raise SystemExit(f"bench.py: rank {rank} of {world}: init_process_group({backend!r}) on device {dev_ord} failed: {type(e).__name__}: {e}")
 
     def cfg_of(path, mlp, **kw):
         return load_mpc_config(path).replace(mlp_dtype=mlp, **kw)
@@ -448,6 +167,7 @@ def main():
     if args.max_iter:
         cfg = cfg.replace(max_iter=args.max_iter, max_no_improvement_iter=args.max_iter)
     H, P, m, B = cfg.horizon, cfg.num_particles, cfg.num_motors, args.batch
+    c2_run = os.path.basename(args.config).startswith("c2_")
     # shared model: rank 0 builds it, RCCL broadcast over xGMI (read-only weights are the only shared data)
     from sde4mbrl_px4_amd.dist import broadcast_blob, max_over_ranks
     blob = (synthetic_iris() if m == 4 else synthetic_hexa()).to_blob() if rank == 0 else b""
@@ -462,8 +182,16 @@ def main():
         torch.cuda.synchronize()
 
     sampler = None
-    if not args.no_power:              # every rank samples its own GPU; rank 0's figures are reported, the spread over the ranks beside them
-        sampler = PowerSampler(dev_ord)
+    if not args.no_power and rank == 0:        # rank 0 samples every GPU of the job (sysfs; no child process, no collective)
+        ords = [int(os.environ["SDEMPC_BENCH_DEVICE"])] * world if "SDEMPC_BENCH_DEVICE" in os.environ else list(range(world))
+        pci = {}
+        for o in set(ords):
+            try:
+                pr = torch.cuda.get_device_properties(o)
+                pci[o] = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            except Exception:
+                pass
+        sampler = PowerSampler(ords, pci)
         sampler.start()
     if rank == 0:
         progress(f"timed leg: {args.warmup} warm-up + {args.steps} timed launches of {B} instances per rank")
@@ -478,13 +206,6 @@ def main():
     sync_all()
     t1 = time.perf_counter()
     power = sampler.summary(t0, t1) if sampler else None
-    if power is not None and use_dist:
-        # the ranks' medians side by side (a node whose GPUs all sit at their caps may be held lower as a whole: the spread shows it)
-        from sde4mbrl_px4_amd.dist import max_over_ranks_each
-        c_, w_ = power["sclk_mhz_median"], power["package_power_w_median"]
-        have = c_ is not None and w_ is not None
-        ext = max_over_ranks_each([c_ if have else -1e30, -(c_ if have else 1e30), w_ if have else -1e30, -(w_ if have else 1e30)], device=dev, force=force_dist)
-        power["over_ranks"] = {"sclk_mhz_median_max": ext[0], "sclk_mhz_median_min": -ext[1], "package_power_w_median_max": ext[2], "package_power_w_median_min": -ext[3]} if ext[0] > -1e29 and ext[1] > -1e29 else None
     if rank == 0:
         progress(f"timed leg done: {t1 - t0:.1f} s" + (f"; package {power['package_power_w_median']} W of {power['power_cap_w']}, sclk {power['sclk_mhz_median']} MHz" if power else ""))
     elapsed = max_over_ranks(t1 - t0, device=dev, force=force_dist)
@@ -495,49 +216,23 @@ def main():
     n_it = float(info_h[:, 2].mean())
     n_ls = float(info_h[:, 7].mean())
 
-    # BASELINE config 4 (N > 1 only): ONE instance per GPU, all ranks solving theirs at the same time (barrier-aligned ticks, duration of a
-    # tick = the slowest rank's); f32 latency layouts like the single-GPU p50 (a single instance is a latency problem)
     c4 = None
     if use_dist and args.c4_reps > 0:
-        from sde4mbrl_px4_amd.dist import max_over_ranks_each
-        from sde4mbrl_px4_amd.solver import SdeMpcSolver
         if rank == 0:
             progress(f"config 4: one instance per GPU, {args.c4_reps} barrier-aligned ticks")
-        s1 = L.solver if args.mlp_dtype == "f32" else SdeMpcSolver(cfg.replace(mlp_dtype="f32"), blob, max_batch=8, device=dev_ord)
-        nv1 = L.noise.view(B, -1)
-        durs, c4_gave_up = [], 0
-        for r in range(-3, args.c4_reps):
-            i = (r + 3) % B
-            sync_all()
-            t = time.perf_counter()
-            s1.solve_dev(1, L.x0[i:].data_ptr(), L.xref[i:].data_ptr(), nv1[i:].data_ptr(), L.u0[i:].data_ptr(), L.step_in[i:].data_ptr(),
-                         L.uopt[i:].data_ptr(), L.xevol[i:].data_ptr(), L.info[i:].data_ptr(), L.stream)
-            torch.cuda.synchronize()
-            if r >= 0:
-                durs.append((time.perf_counter() - t) * 1e3)
-            try:
-                s1.solve_status()
-            except Exception:       # a grid barrier gave up (the GPU is shared with another rank: test boxes only): the handle continues in the tile layout
-                c4_gave_up += 1
-        c4_kernel, c4_fallbacks = s1.last_kernel_name(), s1.layout_fallbacks()
-        if s1 is not L.solver:
-            s1.close()
-        ticks = max_over_ranks_each(durs, device=dev, force=force_dist)
-        c4 = {"instances": world, "ticks": len(ticks), "p50_tick_ms": float(np.median(ticks)), "p95_tick_ms": float(np.percentile(ticks, 95)),
-              "value": world / (float(np.median(ticks)) * 1e-3), "unit": "solves/s", "kernel": c4_kernel, "layout_fallbacks_rank0": c4_fallbacks, "barrier_give_ups_rank0": c4_gave_up, "mlp_dtype": "f32",
-              "note": "BASELINE config 4: one Iris H=50 P=128 instance per GPU (random initial states), every rank solving its own at the same time; a tick "
-                      "lasts as long as its slowest rank; no data-path collective (the weights were broadcast once at start)"}
+        c4 = config4_leg(L, cfg, blob, dev, dev_ord, world, args.c4_reps, args.mlp_dtype, sync_all, force_dist)
 
+    rc = 0
     if rank == 0:
         solves = world * B * args.steps
         value = solves / elapsed
         k_ms = float(np.mean(ev_ms))
-        ach_tf, ach_gbs, bytes_solve, b_grad, b_ls = roofline_of(cfg, B, k_ms, n_grad, n_fwd, kernel_name)
-        # HBM bytes per launch from the PMC counters: they need rocprofv3 around the process (separate --pmc passes for FETCH_SIZE and
-        # WRITE_SIZE, MI355X_MICROARCH.md), so the figure comes from the committed summary of those passes for this config, batch, arithmetic
-        # and BUILD (tools/profile_round.sh -> profiles/pmc_traffic.json records the sha256 of the library it measured): null when the
-        # loaded library is another build than the one the counters were taken on
-        traffic, traffic_src, traffic_build = None, None, None
+        ach_tf, ach_gbs, bytes_solve, b_grad, b_ls = roofline_of(cfg, B, k_ms, n_grad, n_fwd)
+        # HBM bytes per launch and the vector-issue figures from the PMC counters: they need rocprofv3 around the process (separate --pmc passes,
+        # MI355X_MICROARCH.md), so they come from the committed summary of those passes for this config, batch, arithmetic and BUILD
+        # (tools/profile_round.sh -> profiles/pmc_traffic.json records the sha256 of the library it measured): null when the loaded library is
+        # another build than the one the counters were taken on
+        traffic, traffic_src, traffic_build, valu_issue = None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         build = lib_hash()
         if os.path.exists(pmc):
@@ -545,46 +240,30 @@ def main():
                 rec = json.load(open(pmc)).get(f"{os.path.basename(args.config)}:B{B}:{args.mlp_dtype}", {})
                 traffic_build = rec.get("traffic_build")
                 if traffic_build == build:
-                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
+                    traffic, traffic_src, valu_issue = rec.get("hbm_bytes_per_launch"), rec.get("source"), rec.get("valu_issue")
                 else:
                     traffic_src = f"stale: counters were taken on build {traffic_build}, this run loaded {build}"
             except Exception:
                 traffic, traffic_src = None, None
         # p50 / p95 latency of a single solve (B=1 launches), outside the timed region: SURVEY.md §8(d) protocol, >= 20 warm-up
-        # and >= 1000 timed solves by default, one problem instance after the other (host timestamps around a device sync).
-        # A single instance is a latency problem, not a throughput one: the library's latency layouts (one particle per wave over
-        # ceil(P/4) x 7 workgroups, speculative line search) exist for the f32 fma-chain arithmetic, so the reported p50 is measured on a
-        # handle in mlp_dtype f32 — what a deployment that cares about one vehicle's tick would configure — and the single-instance time in
-        # the arithmetic of the throughput number (tile layout on one workgroup) is reported beside it.
+        # and >= 1000 timed solves by default. A single instance is a latency problem, not a throughput one: the library's latency layouts
+        # (one particle per wave over ceil(P/4) x 7 workgroups, speculative line search) exist for the f32 fma-chain arithmetic, so the p50
+        # is measured on a handle in mlp_dtype f32 — what a deployment that cares about one vehicle's tick would configure — and the
+        # single-instance time in the arithmetic of the throughput number (tile layout on one workgroup) is reported beside it.
         from sde4mbrl_px4_amd.solver import SdeMpcSolver
-        nv = L.noise.view(B, -1)
-
-        def latency_of(solver, reps, warm):
-            lat = []
-            for r in range(-warm if reps > 0 else 0, reps):
-                i = r % B
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                solver.solve_dev(1, L.x0[i:].data_ptr(), L.xref[i:].data_ptr(), nv[i:].data_ptr(), L.u0[i:].data_ptr(), L.step_in[i:].data_ptr(),
-                                 L.uopt[i:].data_ptr(), L.xevol[i:].data_ptr(), L.info[i:].data_ptr(), L.stream)
-                torch.cuda.synchronize()
-                if r >= 0:
-                    lat.append((time.perf_counter() - t) * 1e3)
-                solver.solve_status()     # raises if a grid barrier of the cooperative layout gave up (results would be invalid)
-            return lat, (solver.last_kernel_name() if lat else None), solver.layout_fallbacks()
-
         progress(f"single-solve latency: {args.latency_reps} solves")
         if args.mlp_dtype == "f32":
-            lat, single_kernel, fallbacks = latency_of(L.solver, args.latency_reps, args.latency_warmup)
+            lat, single_kernel, fallbacks = latency_of(L, L.solver, args.latency_reps, args.latency_warmup)
             lat_same, same_kernel = lat, single_kernel
         else:
             s_lat = SdeMpcSolver(cfg.replace(mlp_dtype="f32"), blob, max_batch=8, device=dev_ord)
-            lat, single_kernel, fallbacks = latency_of(s_lat, args.latency_reps, args.latency_warmup)
+            lat, single_kernel, fallbacks = latency_of(L, s_lat, args.latency_reps, args.latency_warmup)
             s_lat.close()
-            lat_same, same_kernel, _ = latency_of(L.solver, min(args.latency_reps, 30), min(args.latency_warmup, 2))
+            lat_same, same_kernel, _ = latency_of(L, L.solver, min(args.latency_reps, 30), min(args.latency_warmup, 2))
+        arith = {"f32": "f32 fma chains", "f32x3": "f32 with three-limb bf16 split contractions (f32x3)", "f16": "f16 MLP operands"}[args.mlp_dtype]
         out = {
-            "metric": "MPC solves/sec, Iris H=50 P=128 (p50 solve latency in p50_solve_latency_ms)" if os.path.basename(args.config).startswith("c2_")
-                      else f"MPC solves/sec, {os.path.basename(args.config)}",
+            "metric": (f"MPC solves/sec, Iris H=50 P=128, arithmetic {args.mlp_dtype} (p50 solve latency in p50_solve_latency_ms: arithmetic f32; same-arithmetic pairs in by_arithmetic)"
+                       if c2_run else f"MPC solves/sec, {os.path.basename(args.config)}, arithmetic {args.mlp_dtype}"),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_NOTE[args.mlp_dtype], "mlp_dtype": args.mlp_dtype, "data": "synthetic",
@@ -606,9 +285,13 @@ def main():
             "c4_one_instance_per_gpu": c4,
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_build": traffic_build, "kernel": kernel_name, "kernel_ms": k_ms,
+                         "binding_resource": "vector (VALU) instruction issue at the package power cap — not the MFMA pipe (busy for a fifth of the cycles) and not HBM",
+                         "valu_issue": valu_issue,
                          "note": "algorithmic flops = SURVEY 8d MLP formula x P*H*(2*N_grad+N_ls+2) (N_grad = gradient evaluations actually performed: sdempc_work_counters), "
-                                 "against the 157.3 TFLOP/s f32 peak (f32 vector peak = f32-input MFMA peak): every operand and every accumulation of the path is f32. "
-                                 "In the f32x3 mode 74 % of those flops (the two 32x32 contractions) are executed as 6 bf16 limb products each on the matrix pipe (2.5 PFLOP/s dense): "
+                                 "against the 157.3 TFLOP/s f32 peak (f32 vector peak = f32-input MFMA peak): every operand and every accumulation of the path is f32; `bound` keeps the "
+                                 "contract's vocabulary for that comparison. What binds the kernel is in binding_resource / valu_issue (vector instructions per SIMD, shader cycles, "
+                                 "and the fraction of the cycles the stream takes at the best rate a SIMD issues it: PMC passes of the same build, profiles/). "
+                                 "In the f32x3 mode 74 % of the counted flops (the two 32x32 contractions) run as 6 bf16 limb products each on the matrix pipe (2.5 PFLOP/s dense): "
                                  "the kernel is bound by the f32 vector work beside them (tanh, rigid body, adjoint algebra), not by either matrix peak"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "traffic": traffic, "bytes_per_solve": bytes_solve, "B_grad": b_grad, "B_ls": b_ls,
@@ -626,77 +309,20 @@ def main():
             V.start()                          # (after the latency loop, whose host timestamps must not compete with the checker threads; beside every leg below)
             progress(f"CPU verification of {len(idx)} instances of the timed launch started in the background")
         others = {}
-        if world == 1 and not args.no_other_configs and os.path.basename(args.config).startswith("c2_") and not args.max_iter:
-            cdir = os.path.join(ROOT, "configs")
-            legs = [("c2_f32_chain", os.path.join(cdir, "c2_iris_traj_h50_p128.yaml"), "f32", B, 2, {}),
-                    ("c3", os.path.join(cdir, "c3_hexa_traj_h50_p256.yaml"), args.mlp_dtype, 6144, 2, {}),
-                    ("c5_f32x3" if args.mlp_dtype == "f32x3" else "c5_f32", os.path.join(cdir, "c5_iris_traj_h200_p1024.yaml"), args.mlp_dtype, 768, 1, {}),
-                    ("c5_f16", os.path.join(cdir, "c5_iris_traj_h200_p1024.yaml"), "f16", 768, 1, {})]
-            if args.mlp_dtype == "f32":
-                legs = legs[1:]
-            iris_blob, hexa_blob = synthetic_iris().to_blob(), synthetic_hexa().to_blob()
-            for name, path, mlp, Bl, reps, kw in legs:
-                progress(f"other configuration {name}: {Bl} instances, {reps} timed launch(es)")
-                c2 = cfg_of(path, mlp, **kw)
-                bl = iris_blob if c2.num_motors == 4 else hexa_blob
-                Lg = Leg(c2, bl, Bl, dev_ord)
-                Lg.step(); torch.cuda.synchronize()                       # warm-up launch
-                ms, ng, nf = Lg.timed_events(reps)
-                kn = Lg.solver.last_kernel_name()
-                km = float(np.mean(ms))
-                tf, gbs, _, _, _ = roofline_of(c2, Bl, km, ng, nf, kn)
-                uo, xo, io = Lg.host_outputs()
-                rec = {"config": os.path.basename(path), "mlp_dtype": mlp, "instances": Bl, "launches_timed": reps, "value": Bl / (km * 1e-3), "unit": "solves/s",
-                       "kernel_ms": km, "kernel": kn, "roofline_frac": tf / F32_MFMA_PEAK_TF, "roofline_hbm_frac": gbs / HBM_PEAK_GBS,
-                       "N_it_mean": float(io[:, 2].mean()), "N_grad_evaluated_mean": ng, "N_forward_rollouts_mean": nf}
-                if mlp == "f16":
-                    f16_flops = (2 * (6 * 64 + 32 * 32) * (ng + nf) + 2 * (6 * 64) * ng) * c2.num_particles * c2.horizon
-                    rec["roofline_mfma_f16"] = {"achieved": f16_flops * Bl / (km * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                                                "frac": f16_flops * Bl / (km * 1e-3) / 1e12 / 2500.0,
-                                                "note": "flops of the contractions on v_mfma_f32_32x32x16_f16 against the 2.5 PFLOP/s dense f16 peak: K = 6 and K = 32 contractions of a "
-                                                        "32-wide MLP leave the matrix pipe nearly idle by design; the kernel is bound by the f32 vector work"}
-                if args.verify != 0:
-                    if name.startswith("c5"):
-                        # a full-length C5 solve takes the scalar oracle minutes: the SAME instances are solved once more with three iterations from a
-                        # step size at which all three take steps (tests/test_gpu_parity.py::test_c5_full_size_solve_bit_exact) and that launch is checked
-                        c3it = c2.replace(max_iter=3, max_no_improvement_iter=3)
-                        from sde4mbrl_px4_amd.solver import SdeMpcSolver
-                        s3 = SdeMpcSolver(c3it, bl, max_batch=Bl, device=dev_ord)
-                        u3, x3, i3 = torch.empty_like(Lg.uopt), torch.empty_like(Lg.xevol), torch.empty_like(Lg.info)
-                        st3 = torch.full((Bl,), 1e-11, dtype=torch.float32, device=dev)
-                        s3.solve_dev(Bl, Lg.x0.data_ptr(), Lg.xref.data_ptr(), Lg.noise.data_ptr(), Lg.u0.data_ptr(), st3.data_ptr(), u3.data_ptr(), x3.data_ptr(), i3.data_ptr(), Lg.stream)
-                        torch.cuda.synchronize()
-                        V.add(name, c3it, bl, [Bl - 1], Lg.x0_h, Lg.xref_h, Lg.keys, Lg.u0_h, 1e-11, (u3.cpu().numpy(), x3.cpu().numpy(), i3.cpu().numpy()))
-                        rec["verified_how"] = "3-iteration launch of the same instances (same kernel instantiation, step size 1e-11), last instance, bit for bit"
-                        s3.close()
-                    else:
-                        vi = sample_indices(Bl, Lg.slots(), n_initial=1, n_drawn=1)
-                        V.add(name, c2, bl, vi, Lg.x0_h, Lg.xref_h, Lg.keys, Lg.u0_h, Lg.s0, (uo, xo, io))
-                        rec["verified_how"] = "the timed full-length launch, bit for bit"
-                others[name] = rec
-                Lg.close()
-        if world == 1 and cfg.math_mode == "exact" and not args.no_tolerance_modes and os.path.basename(args.config).startswith("c2_") and not args.max_iter:
-            # The optional tolerance-parity mode on the same instances (a warm-up and a timed launch), never the reported value: solves/s and how
-            # far its controls are from this run's bit-reproducible path (north star: 1e-4). SPEC.md 10, DESIGN.md 2.
-            from sde4mbrl_px4_amd.solver import SdeMpcSolver
-            modes = {}
-            u2 = torch.empty_like(L.uopt); x2 = torch.empty_like(L.xevol); i2 = torch.empty_like(L.info)
-            for name, kw in (("math_mode_fast", dict(math_mode="fast")),):
-                s2 = SdeMpcSolver(cfg.replace(**kw), blob, max_batch=B, device=dev_ord)
-                for _ in range(2):                  # (a first launch of these kernels measured 7 % slow)
-                    L.step(s2, (u2, x2, i2))
-                    ms2 = s2.last_kernel_ms()
-                torch.cuda.synchronize()
-                du = np.abs(u2.cpu().numpy() - uopt_h).reshape(B, -1)
-                ok = np.all(du <= 1e-4 + 1e-4 * np.abs(uopt_h).reshape(B, -1), axis=1)
-                modes[name] = {"value": B / (ms2 * 1e-3), "unit": "solves/s", "kernel": s2.last_kernel_name(),
-                               "max_abs_du_vs_exact_median": float(np.median(du.max(axis=1))), "max_abs_du_vs_exact_worst": float(du.max()),
-                               "instances_within_1e-4_of_exact": float(ok.mean())}
-                s2.close()
-            out["tolerance_modes"] = dict(modes, note="same instances, cold-start 200-iteration solves; controls against the bit-reproducible path of this run "
-                                                       "(abs + rel 1e-4, the north star's tolerance); optional mode without a CPU oracle, not the reported metric")
+        if world == 1 and not args.no_other_configs and c2_run and not args.max_iter:
+            others = other_config_legs(ROOT, args.mlp_dtype, B, dev, dev_ord, cfg_of, V, args.verify, progress)
+        if world == 1 and cfg.math_mode == "exact" and not args.no_tolerance_modes and c2_run and not args.max_iter:
+            out["tolerance_modes"] = tolerance_mode_legs(L, cfg, blob, dev_ord, uopt_h)
+        # the two same-arithmetic pairs of the headline configuration side by side (a handle has ONE mlp_dtype)
+        if c2_run and not args.max_iter:
+            p50 = out["p50_solve_latency_ms"]
+            by = {args.mlp_dtype: {"solves_per_s": value, "p50_ms": out["p50_solve_latency_ms_in_the_throughput_arithmetic"],
+                                   "layouts": "persistent duo tiles / " + ("speculative one-particle-per-wave" if args.mlp_dtype == "f32" else "tile layout on one workgroup")}}
+            if args.mlp_dtype != "f32":
+                by["f32"] = {"solves_per_s": others.get("c2_f32_chain", {}).get("value"), "p50_ms": p50, "layouts": "persistent duo tiles / speculative one-particle-per-wave"}
+            out["by_arithmetic"] = by
         progress("waiting for the CPU verification threads")
-        ver_wall = V.join()
+        V.join()
         bad_total = 0
         for leg, r in V.results.items():
             ok = r["bad_words"] == 0 and r["done"] == len(r["idx"])
@@ -715,9 +341,13 @@ def main():
             out["verified_instances"], out["verified_bit_exact"] = 0, None
         if others:
             out["other_configs"] = others
-        if bad_total:
-            print(json.dumps(out))
-            raise SystemExit(f"bench.py: outputs of a timed launch differ from the oracle in {bad_total} words")
+        short = V.incomplete()
+        if bad_total or short:
+            if short:
+                out["verification_errors"] = V.errors[:8]
+            emit(out)
+            raise SystemExit(f"bench.py: outputs of a timed launch differ from the oracle in {bad_total} words" if bad_total else
+                             f"bench.py: the verification did not complete (checked, asked) by leg: {short}; first errors: {V.errors[:3]}")
         do_cpu = not args.no_cpu_baseline and world == 1
         if do_cpu:
             progress("CPU baseline (about 10 s on every usable core) and the C1 single solve")
@@ -738,15 +368,16 @@ def main():
                                              "contraction allowed, f32 fma-chain contractions; CPU restatement of SPEC.md, not the reference JAX path: that cannot run here); "
                                              f"|uopt - GPU uopt| over the sample (200-iteration solves; timing build, not the checker): median {mmed:.1e}, max {md:.1e}",
                                    "value_bit_exact_build": (rmain["done"] / rmain["cpu_s"] * 1.0) if rmain and rmain["cpu_s"] > 0 else None,
-                                   "value_bit_exact_build_note": "solves per second PER THREAD of the bit-exact checker in the arithmetic of this run (scalar; the matrix-instruction model is integer code)",
+                                   "value_bit_exact_build_note": "solves per second PER THREAD of the bit-exact checker in the arithmetic of this run (the matrix-instruction model is integer code)",
                                    "cpu_c1_single_solve_ms": c1["vec"][0], "cpu_c1_single_solve_ms_scalar_build": c1["scalar"][0],
                                    "cpu_c1_note": f"BASELINE config 1: c1_iris_posctrl_h20_p32.yaml H={c1cfg.horizon} P={c1cfg.num_particles}, one cold-start solve "
                                                   f"(N_it {c1['vec'][1]:.0f}) on ONE thread, median of 3: particle-vectorised build / bit-exact scalar -O2 build"}
-        print(json.dumps(out))
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     L.close()
+    return rc
 
 
 if __name__ == "__main__":

@@ -119,12 +119,12 @@ def config4_leg(L, cfg, blob, dev, dev_ord, world, reps, mlp_dtype, sync_all, fo
             gave_up += 1
             ok = False
         if r >= 0:
-            durs.append(d if ok else float("nan"))
+            durs.append(d if ok else float("inf"))
     kernel, fallbacks = s1.last_kernel_name(), s1.layout_fallbacks()
     if s1 is not L.solver:
         s1.close()
-    # a tick counts only if every rank measured it: NaN survives the MAX over the ranks
-    ticks = [t for t in max_over_ranks_each(durs, device=dev, force=force_dist, nan_propagates=True) if t == t]
+    # a tick counts only if every rank measured it: +inf marks a dropped one and survives the MAX over the ranks
+    ticks = [t for t in max_over_ranks_each(durs, device=dev, force=force_dist) if np.isfinite(t)]
     if not ticks:
         return {"instances": world, "ticks": 0, "value": None, "barrier_give_ups_rank0": gave_up, "kernel": kernel,
                 "note": "no tick completed on every rank without a barrier give-up"}

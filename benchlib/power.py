@@ -111,8 +111,8 @@ class PowerSampler(threading.Thread):
             v = [row[k] for row in sel if row[k] is not None]
             per.append((float(np.median([a for a, _ in v])), float(np.median([b for _, b in v]))) if v else None)
         if not per or per[0] is None:
-            return {"package_power_w_median": None, "sclk_mhz_median": None, "power_cap_w": self.cap, "samples": 0, "source": self.source,
-                    "note": "no sample inside the timed region"}
+            return dict({"package_power_w_median": None, "sclk_mhz_median": None, "power_cap_w": self.cap, "samples": 0, "source": self.source,
+                         "note": "no sample inside the timed region"}, **({"over_gpus": None} if len(self.ordinals) > 1 else {}))
         out = {"package_power_w_median": per[0][1], "sclk_mhz_median": per[0][0], "power_cap_w": self.cap, "samples": len(sel), "source": self.source,
                "note": "rank 0's GPU, one sample per second inside the timed region (performance level auto): at the cap the firmware lowers the shader "
                        "clock (2.4 GHz maximum) until the package fits — solves/s = cap / energy per solve"}

@@ -96,6 +96,9 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     // instance (one step each), published and read back after one more barrier — every workgroup reducing everything itself took
     // ~45 us per iteration, a third of the time of an iteration
     enum { PH_INIT, PH_GRAD, PH_PAR, PH_SEQ, PH_RED, PH_FINAL, PH_DONE };
+#ifndef SDEMPC_VAR_SPEC_CLK
+#define SDEMPC_VAR_SPEC_CLK 0
+#endif
     float* gtot_base = C.pp + (size_t)2 * SPEC_SLOTS * PS * C.Ppad;       // [2][PS] published totals, after the per-particle slots
     unsigned red_cnt = 0u, red_par = 0u; int red_slot = 0;
     int phase = PH_INIT;
@@ -106,7 +109,15 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     unsigned par_cnt = 0u, par_spec = 0u;
     bool spec = false, two = false, three = false;
     const bool has_ls = a.A.maxls > 0;
+#if SDEMPC_VAR_SPEC_CLK
+    // diagnostic build (tools/spec_clock.py): 10 ns ticks by phase kind and section, workgroup (group 3, first) -> over the mean trajectory
+    unsigned long long ck_acc[PH_DONE][3] = {}, ck_n[PH_DONE] = {};
+#endif
     while (phase != PH_DONE) {
+#if SDEMPC_VAR_SPEC_CLK
+        const int ck_phase = phase;
+        const unsigned long long ck_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
         // ---- this workgroup's work item of the phase ----
         const float* iu = xk; int islot = SLOT_SEQ; bool igrad = false, imean = false, iact = false;
         unsigned par = C.epoch & 1u;
@@ -161,7 +172,13 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 else lane2_rollout<false>(a, sm, L, io, lane);
             }
         }
+#if SDEMPC_VAR_SPEC_CLK
+        const unsigned long long ck_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
         coop_barrier(C, tid);
+#if SDEMPC_VAR_SPEC_CLK
+        const unsigned long long ck_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
         // ---- the optimiser (SPEC.md §8), advanced as far as the data of this phase allows ----
         bool head = false, tail = false, fin = false;
         if (phase == PH_INIT) {
@@ -250,10 +267,12 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             if (grp == 0 && C.wgi == 0) {
                 const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + SLOT_SEQ) * PS * C.Ppad;
                 float* xmean_out = a.xmean + (size_t)b * (H + 1) * NX;
+#if !SDEMPC_VAR_SPEC_CLK
                 for (int q = wave; q < (H + 1) * NX; q += 4) {
                     const float sv = coop_total(pbuf + (size_t)q * C.Ppad, a.P, a.G, lane);
                     if (lane == 0) xmean_out[q] = sv * a.invP;
                 }
+#endif
                 for (int e = tid; e < N; e += Team::NT) a.uopt[(size_t)b * N + e] = xk[e];
                 if (tid == 0) {
                     float* inf = a.info + (size_t)b * 8;
@@ -376,6 +395,23 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             __syncthreads();
             phase = PH_PAR;
         }
+#if SDEMPC_VAR_SPEC_CLK
+        {
+            const unsigned long long ck_t3 = __builtin_amdgcn_s_memrealtime();
+            ck_acc[ck_phase][0] += ck_t1 - ck_t0; ck_acc[ck_phase][1] += ck_t2 - ck_t1; ck_acc[ck_phase][2] += ck_t3 - ck_t2; ck_n[ck_phase] += 1;
+        }
+#endif
     }
+#if SDEMPC_VAR_SPEC_CLK
+    if (tid == 0 && r_ < 250) {      // every workgroup: mean work time of its parallel phases (us) and where it ran (XCC id * 100 + group)
+        float* o = a.xmean + (size_t)b * (H + 1) * NX + 100;
+        o[2 * r_] = (float)ck_acc[PH_PAR][0] * 0.01f / (float)(ck_n[PH_PAR] ? ck_n[PH_PAR] : 1);
+        o[2 * r_ + 1] = (float)((__builtin_amdgcn_s_getreg(63508) & 15) * 100 + grp);      // HW_REG_XCC_ID
+    }
+    if (grp == (ng > 3 ? 3 : 0) && C.wgi == 0 && tid == 0) {
+        float* o = a.xmean + (size_t)b * (H + 1) * NX + 64;
+        for (int ph = 0; ph < PH_DONE; ++ph) { for (int k = 0; k < 3; ++k) o[ph * 4 + k] = (float)ck_acc[ph][k]; o[ph * 4 + 3] = (float)ck_n[ph]; }
+    }
+#endif
 }
 

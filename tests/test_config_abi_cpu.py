@@ -208,15 +208,17 @@ def test_no_cpu_fallback_compute_fails_loudly_without_gpu():
 
 def test_entry_scripts_are_valid_python():
     import ast
-    for name in ("bench.py", "__graft_entry__.py", "tools/prof_solve.py", "tools/summarize_profile.py", "tests/golden/make_golden.py"):
+    for name in ("bench.py", "benchlib/counts.py", "benchlib/verify.py", "benchlib/power.py", "benchlib/ranks.py", "benchlib/legs.py", "__graft_entry__.py",
+                 "tools/prof_solve.py", "tools/summarize_profile.py", "tests/golden/make_golden.py"):
         ast.parse(open(os.path.join(ROOT, name)).read(), filename=name)
-    import bench
+    import bench      # noqa: F401  (imports benchlib; no GPU is touched at import time)
+    from benchlib import counts, power, verify
     cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml"))
-    nbytes, nflops, b_grad, b_ls = bench.algorithmic_counts(cfg, 200, 375)
+    nbytes, nflops, b_grad, b_ls = counts.algorithmic_counts(cfg, 200, 375)
     assert b_grad == 990364 and b_ls == 157052                      # SURVEY.md §8d formulas with n_w = 6
     assert nflops == 3520 * 128 * 50 * (2 * 200 + 375 + 2)
-    assert bench.checkpoint_bytes(cfg, 200) == 200 * 2 * 4 * 50 * 1280 * 4
-    assert bench.effective_cores() >= 1
+    assert counts.checkpoint_bytes(cfg, 200) == 200 * 2 * 4 * 50 * 1280 * 4
+    assert verify.effective_cores() >= 1
     # the background checker of timed launches: a live queue (jobs added after the start are picked up), mismatching words are counted
     import orc
     from sde4mbrl_px4_amd import MPCConfig as _Cfg, synthetic_iris as _iris, prng as _prng
@@ -228,32 +230,47 @@ def test_entry_scripts_are_valid_python():
     vO = orc.Oracle(vc, vb)
     vo = [vO.solve(vx0[b], vxr[b], orc.noise_from_key(vk[b], 16, 6), vu0[b], 0.01)[:3] for b in range(5)]
     got = tuple(np.stack([o[k] for o in vo]) for k in range(3))
-    V = bench.Verifier(3)
+    V = verify.Verifier(3)
     V.add("main", vc, vb, [0, 2], vx0, vxr, vk, vu0, 0.01, got)
     V.start()
     wrong = (got[0].copy(), got[1], got[2]); wrong[0][4, 0, 0] += 1e-3
     V.add("late", vc, vb, [1, 4], vx0, vxr, vk, vu0, 0.01, wrong)
     V.join()
     assert V.results["main"] == dict(V.results["main"], bad_words=0, done=2) and V.results["late"]["bad_words"] == 1 and V.results["late"]["done"] == 2
-    assert bench.Verifier(2).join() == 0.0                                   # never started (--verify 0)
-    # the power / clock sampler beside the timed launches: parses rocm-smi's text, keeps only samples inside the timed region, survives a missing tool
+    assert verify.Verifier(2).join() == 0.0                                   # never started (--verify 0)
+    assert V.incomplete() == {} and V.errors == []
+    # a worker that dies leaves its instance unchecked, which bench.py turns into a non-zero exit (the exception is kept for the message)
+    Vd = verify.Verifier(1)
+    Vd.add("main", vc, vb, [0], vx0, vxr, vk, vu0, 0.01, (got[0], got[1][:, :2], got[2]))          # a malformed xevol: the comparison raises
+    Vd.start(); Vd.join()
+    assert Vd.incomplete() == {"main": (0, 1)} and len(Vd.errors) == 1
+    # the power / clock sampler beside the timed launches (rank 0, every GPU of the job in one pass). No amdgpu card in sysfs here, so this is its
+    # rocm-smi path: ONE child per second for all devices, only samples inside the timed region count, a missing tool leaves nulls
     import subprocess, time, types
-    texts = {"--showmaxpower": "GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\n",
-             "--showpower": "GPU[0]\t\t: sclk clock level: 1: (1896Mhz)\nGPU[0]\t\t: Current Socket Graphics Package Power (W): 1399.0\n"}
-    real = subprocess.run
+    assert power.amdgpu_cards() == [] or all(len(c) == 3 for c in power.amdgpu_cards())
+    calls = []
+    def fake(cmd, **kw):
+        calls.append(cmd)
+        if "--showmaxpower" in cmd:
+            return types.SimpleNamespace(stdout="GPU[0]\t\t: Max Graphics Package Power (W): 1400.0\n", returncode=0)
+        return types.SimpleNamespace(stdout="".join(f"GPU[{g}]\t\t: sclk clock level: 1: ({1896 - 10 * g}Mhz)\nGPU[{g}]\t\t: Current Socket Graphics Package Power (W): {1399.0 - g}\n" for g in range(4)), returncode=0)
+    real, real_cards = subprocess.run, power.amdgpu_cards
     try:
-        subprocess.run = lambda cmd, **kw: types.SimpleNamespace(stdout=texts[cmd[3]], returncode=0)
-        ps = bench.PowerSampler(0)
+        subprocess.run = fake
+        power.amdgpu_cards = lambda: []
+        ps = power.PowerSampler([0, 1, 2, 3])
         t0 = time.perf_counter() - 1.5
         ps.start(); time.sleep(2.6)
         r = ps.summary(t0, time.perf_counter())
         assert r["power_cap_w"] == 1400.0 and r["package_power_w_median"] == 1399.0 and r["sclk_mhz_median"] == 1896.0 and r["samples"] >= 1
+        assert r["over_gpus"]["gpus_sampled"] == 4 and r["over_gpus"]["sclk_mhz_median_min"] == 1866.0 and r["over_gpus"]["package_power_w_median_min"] == 1396.0
+        assert all("-d" not in c for c in calls if "--showpower" in c)                  # one call covers all devices
         def missing(cmd, **kw): raise FileNotFoundError("rocm-smi")
         subprocess.run = missing
-        ps = bench.PowerSampler(0); ps.start(); time.sleep(0.2)
+        ps = power.PowerSampler([0]); ps.start(); time.sleep(0.2)
         assert ps.summary(0.0, 1e9)["samples"] == 0
     finally:
-        subprocess.run = real
+        subprocess.run, power.amdgpu_cards = real, real_cards
 
 
 def test_product_and_tools_never_touch_the_oracle():
@@ -269,13 +286,17 @@ def test_product_and_tools_never_touch_the_oracle():
                 if pat.search(line) and not line.lstrip().startswith(("#", "//", "*", '"')) and "oracle/prng_oracle.c" not in line:
                     offenders.append(f"{os.path.relpath(f, root)}:{i + 1}: {line.strip()[:100]}")
     assert not offenders, "\n".join(offenders)
-    # bench.py may load it in exactly one function, called only by its CPU legs (checker of the timed outputs + cpu_baseline)
-    src = open(os.path.join(root, "bench.py")).read()
+    # bench.py's CPU legs live in benchlib/verify.py: the oracle is loaded in exactly one function there, called only by the checker of the timed
+    # outputs and by cpu_baseline; nothing else of bench.py / benchlib mentions it, and nothing of it sits inside the timed region
+    src = open(os.path.join(root, "benchlib", "verify.py")).read()
     assert src.count("import orc") == 1 and src.split("import orc")[0].rsplit("\ndef ", 1)[-1].startswith("cpu_oracle()")
-    callers = {blk.split("(", 1)[0] for blk in src.split("\ndef ")[1:] if "cpu_oracle()" in blk.split("\n", 1)[1]}
-    assert callers == {"cpu_solve_instances", "cpu_c1_single_solve_ms"}, callers
-    timed = src.split("t0 = time.perf_counter()")[1].split("t1 = time.perf_counter()")[0]
-    assert "cpu_" not in timed and "orc" not in timed
+    callers = {blk.split("(", 1)[0].strip() for blk in re.split(r"\n(?:    )?def ", src)[1:] if "cpu_oracle()" in blk.split("\n", 1)[1]}
+    assert callers == {"cpu_solve_instances", "cpu_c1_single_solve_ms", "start"}, callers          # (start: Verifier.start)
+    for other in ("bench.py", "benchlib/counts.py", "benchlib/power.py", "benchlib/ranks.py", "benchlib/legs.py"):
+        assert not re.search(r"import orc\b|liborc|cpu_oracle\(", open(os.path.join(root, other)).read()), other
+    main_src = open(os.path.join(root, "bench.py")).read()
+    timed = main_src.split("t0 = time.perf_counter()")[1].split("t1 = time.perf_counter()")[0]
+    assert "cpu_" not in timed and "orc" not in timed and "Verifier" not in timed
 
 
 def test_state_constr_section_parses_in_penalty_form(tmp_path):

@@ -92,3 +92,36 @@ def test_bench_self_start_stops_all_ranks_when_one_fails():
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and r.stdout.strip() == "" and "needs a GPU" in r.stderr
     assert time.time() - t0 < 90
+    # the parent's own summary line names a failing rank and quotes what that rank said
+    assert "bench.py: rank " in r.stderr and "exited with code" in r.stderr and "Last lines of that rank's stderr" in r.stderr
+
+
+def _bench_env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1", **kw)
+    return env
+
+
+def test_bench_four_ranks_dry_run_over_gloo():
+    """The rank plumbing of `bench.py --gpus 4` on the CPU (SDEMPC_BENCH_DRY=1: self-start, rendezvous on 127.0.0.1, blob broadcast, all-reduce MAX
+    incl. a dropped tick, barriers, destroy) — what the first real multi-GPU run exercises before any kernel is launched. One JSON line, exit 0."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=_bench_env(SDEMPC_BENCH_DRY="1"), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out == {"dry_run": True, "n_gpus": 4, "blob_bytes": 4 * (16 + 2120), "max_over_ranks": 4.0, "ticks": [3.0, None]}
+
+
+def test_bench_four_ranks_one_fails_before_the_rendezvous():
+    """Rank 2 dies at start-up (what a rank whose GPU cannot be opened does) while the other three wait in the rendezvous: the parent stops them
+    within seconds, exits non-zero, prints nothing on stdout and says in ITS OWN last line which rank failed and why."""
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=_bench_env(SDEMPC_BENCH_DRY="1", SDEMPC_BENCH_FAIL_RANK="2"),
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert time.time() - t0 < 90
+    last = [l for l in r.stderr.splitlines() if l.startswith("bench.py: rank ")][-1]
+    assert "rank 2 exited with code" in last and "simulated start-up failure" in last

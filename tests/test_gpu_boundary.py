@@ -147,7 +147,7 @@ def test_bench_two_ranks_self_started_on_one_gpu():
     assert rec["verified_instances"] == 2 and rec["verified_bit_exact"] is True
     assert rec["roofline"]["frac"] > 0 and rec["roofline"]["kernel_ms"] > 0
     assert rec["cpu_baseline"].startswith("skipped")                      # stated, not silently absent, in N > 1 lines
-    assert "over_ranks" in rec["power"]                                   # every rank samples its GPU's clock / power; the spread is reported (None: region too short for a sample)
+    assert "over_gpus" in rec["power"]                                    # rank 0 samples every GPU of the job; the spread is reported (None: region too short for a sample)
     c4 = rec["c4_one_instance_per_gpu"]                                   # BASELINE config 4: one instance per rank, barrier-aligned ticks
     assert c4["instances"] == 2 and c4["ticks"] == 6 and c4["p50_tick_ms"] > 0 and c4["value"] > 0
 

@@ -60,6 +60,8 @@ struct sdempc_handle {
     KArgs base;
     unsigned ticket_total = 0;   // running value of the device ticket word (KArgs::ticket_host points here; sdempc_kernels.hip, launch_persistent)
     int ws_rows = 0;             // rows (instances or team slots) the trajectory / checkpoint / partial-sum / control-table workspaces hold
+    int traj_batch = 0;          // instances whose particle x horizon tensor the trajectory workspace holds (last rollout with store_traj); 0: none —
+                                 // any later launch that writes the workspace (gradient, solve) or a reallocation of it resets this
     bool last_ticketed = false;  // the last solve launch handed its instances out by ticket: sdempc_solve_status compares the word with the mirror
     // host tables
     std::vector<float> h_sdt, h_disc, h_beta;
@@ -242,7 +244,7 @@ int ensure_workspace(sdempc_handle* h, int rows) {
     if (rows <= h->ws_rows) return 0;
     HIPCHK(h, hipStreamSynchronize(h->stream));          // nothing may still be using the old rows (caller streams: the caller's business, as for every _dev entry point)
     for (DevBuf* b : {&h->d_traj, &h->d_act, &h->d_part, &h->d_ustg}) dev_free(*b);
-    h->ws_rows = 0; h->base.ws_rows = 0;
+    h->ws_rows = 0; h->base.ws_rows = 0; h->traj_batch = 0;
     h->base.traj = h->base.act = h->base.part = h->base.ustg = nullptr;
     const int H = h->H;
     int rc;
@@ -583,7 +585,10 @@ int sdempc_traj_to_canonical_dev(sdempc_handle* h, int32_t B, void* traj_out_dev
     if (rc) return rc;
     if (!traj_out_dev) return fail(h, SDEMPC_EINVAL, "NULL device pointer%s");
     if ((rc = ensure_device(h))) return rc;
-    if (B > h->ws_rows) return fail(h, SDEMPC_EINVAL, "no rollout with store_traj of this batch size has run on this handle%s");
+    if (B > h->traj_batch)
+        return fail(h, SDEMPC_EINVAL, h->traj_batch ? "the trajectory workspace holds fewer instances than asked for (last rollout with store_traj was smaller)%s"
+                                                     : "the trajectory workspace holds no rollout: run a rollout with store_traj first (a gradient evaluation, a solve or a "
+                                                       "workspace reallocation since then has overwritten it)%s");
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     HIPCHK(h, launch_relayout(false, (const float*)h->d_traj.p, (float*)traj_out_dev, B, h->P, h->G, (h->H + 1) * SDEMPC_NX, st));
     return SDEMPC_OK;
@@ -602,7 +607,10 @@ int sdempc_rollout_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, co
     a.x0 = (const float*)x0_dev; a.u = (const float*)u_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
     a.cost = (float*)cost_dev; a.xmean = (float*)xmean_dev; a.store_traj = store_traj;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    return timed_launch(h, st, [&] { return a.fast ? launch_rollout_fast(a, B, st) : launch_rollout(a, B, st); });
+    h->traj_batch = 0;
+    rc = timed_launch(h, st, [&] { return a.fast ? launch_rollout_fast(a, B, st) : launch_rollout(a, B, st); });
+    if (rc == SDEMPC_OK && store_traj) h->traj_batch = B;
+    return rc;
     });
 }
 
@@ -618,6 +626,7 @@ int sdempc_grad_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, const
     a.x0 = (const float*)x0_dev; a.u = (const float*)u_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
     a.cost = (float*)cost_dev; a.grad = (float*)grad_dev;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->traj_batch = 0;       // (the gradient's forward sweep streams x_t through the trajectory workspace)
     return timed_launch(h, st, [&] { return a.fast ? launch_grad_fast(a, B, st) : launch_grad(a, B, st); });
     });
 }
@@ -634,6 +643,7 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
         KArgs probe = h->base; probe.B = B;
         if ((rc = ensure_workspace(h, probe.fast ? solve_workspace_rows_fast(probe, B) : solve_workspace_rows(probe, B)))) return rc;
     }
+    h->traj_batch = 0;       // (a solve's gradient evaluations stream through the trajectory workspace, indexed by team slot)
     KArgs a = h->base;
     a.x0 = (const float*)x0_dev; a.u = (const float*)u_init_dev; a.xref = (const float*)xref_dev; a.noise = (const float*)noise_dev;
     a.stepsize_in = (const float*)stepsize_dev; a.uopt = (float*)uopt_dev; a.xmean = (float*)xevol_dev; a.info = (float*)info_dev;

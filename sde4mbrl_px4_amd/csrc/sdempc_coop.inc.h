@@ -38,9 +38,12 @@ DI void coop_barrier(CoopCtx& C, int tid) {
         __hip_atomic_fetch_add(C.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = C.epoch * (unsigned)C.nwg;
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        while (__hip_atomic_load(C.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (__hip_atomic_load(C.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;      // another workgroup gave up
-            __builtin_amdgcn_s_sleep(1);
+        // counter and error flag are the two halves of one aligned 64-bit word: ONE load per poll (two dependent round trips across the XCDs
+        // per poll made the poll period, and with it the mean time to notice the last arrival, twice as long)
+        const unsigned long long* both = reinterpret_cast<const unsigned long long*>(C.bar);
+        for (;;) {
+            const unsigned long long w = __hip_atomic_load(both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)w >= target || (unsigned)(w >> 32) != 0u) break;      // everyone arrived / another workgroup gave up
             if (__builtin_amdgcn_s_memrealtime() - t0 >= (uint64_t)C.spin_limit) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         }
         if (C.fence) {

@@ -1223,7 +1223,7 @@ int coop_max_instances(int P, int H, int m, const LaunchOpts& o) {
 }
 // per-instance workspace, sized for the speculative variant (7 output slots, 3 checkpoint regions); the plain cooperative kernel
 // uses a prefix of it
-size_t coop_pp_floats(int H, int G) { return (size_t)2 * SPEC_SLOTS * part_stride(H) * G * 32 + 2 * (size_t)part_stride(H); }
+size_t coop_pp_floats(int H, int G) { return (size_t)2 * SPEC_SLOTS * part_stride(H) * G * 32 + 4 * (size_t)part_stride(H); }      // (+ [2][PS] tagged 64-bit totals)
 size_t coop_ck_floats(int H, int P) { return (size_t)SPEC_CKS * P * (H + 1) * COOP_ROW; }
 int spec_max_instances(int P, int H, int m, const LaunchOpts& o) {
     if (!o.spec || !o.coop) return 0;      // SDEMPC_OPT_SPEC / SDEMPC_OPT_COOP = 0; P == 1 is welcome here (one wave per workgroup is active)

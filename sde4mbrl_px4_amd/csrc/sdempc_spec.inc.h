@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     CoopCtx C;
     C.nwg = per; C.wgi = r_ - grp * nwg; C.Ppad = a.G * 32; C.epoch = 0u; C.spin_limit = a.coop_spin; C.fence = a.opt.coop_fence;
     C.bar = a.coop_bar + 2 * b;
-    C.pp = a.coop_pp + (size_t)b * ((size_t)2 * SPEC_SLOTS * PS * C.Ppad + 2 * (size_t)PS);
+    C.pp = a.coop_pp + (size_t)b * ((size_t)2 * SPEC_SLOTS * PS * C.Ppad + 4 * (size_t)PS);
     C.ck = a.coop_ck + ((size_t)b * SPEC_CKS + (grp == 6 ? 3 : grp >= 2 && grp <= 4 ? grp - 2 : 0)) * a.P * (H + 1) * COOP_ROW;    // gradients run on groups 2..4 and 6 (or 0 when there are only two)
     Smem sm = carve(smem, H, m, 0, true);
     WaveW ww;
@@ -99,8 +99,15 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
 #ifndef SDEMPC_VAR_SPEC_CLK
 #define SDEMPC_VAR_SPEC_CLK 0
 #endif
-    float* gtot_base = C.pp + (size_t)2 * SPEC_SLOTS * PS * C.Ppad;       // [2][PS] published totals, after the per-particle slots
+    // [2][PS] published totals behind the per-particle slots, each a 64-bit word {value, tag}: the tag is the number of the reduction phase that
+    // produced it, so a consumer that reads the pair in one aligned 64-bit load knows the value is the one it waits for — the reduction phase needs
+    // no grid barrier of its own (a barrier costs 5 - 6 us of round trips across the XCDs: 5 % of an iteration), the hand-off is the datum itself
+    unsigned long long* gtot_base = reinterpret_cast<unsigned long long*>(C.pp + (size_t)2 * SPEC_SLOTS * PS * C.Ppad);
     unsigned red_cnt = 0u, red_par = 0u; int red_slot = 0;
+    // tags of an earlier launch must not be taken for this one's: the instance's first workgroup clears the words (the first reduction phase lies
+    // behind at least two grid barriers)
+    if (r_ == 0)
+        for (int i = tid; i < 2 * PS; i += Team::NT) __hip_atomic_store(gtot_base + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int phase = PH_INIT;
     float c_init = 0.0f, c_x = 0.0f, s = a.stepsize_in[b], gsq = 0.0f, sum_ls = 0.0f, sum_s = 0.0f, c_y = 0.0f, c_n = 0.0f;
     float gd_1 = 0.0f, gd_2 = 0.0f, rs_1 = 0.0f, rs_2 = 0.0f, cu_1 = 0.0f, cu_2 = 0.0f;      // of the parallel trials, known before they run
@@ -124,16 +131,14 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         if (phase == PH_RED) {
             constexpr int nq = M + 4;
             const float* pbuf = C.pp + (size_t)(red_par * SPEC_SLOTS + red_slot) * PS * C.Ppad;
-            float* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
-            for (int t = r_; t < H; t += per) {
-                for (int kq = wave; kq < nq; kq += 4) {
-                    const float sv = coop_total(pbuf + (size_t)(t * 12 + kq) * C.Ppad, a.P, a.G, lane);
-                    if (lane == 0) __hip_atomic_store(gt + t * 12 + kq, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            if (r_ == per - 1 && wave == 3) {      // the cost total: last workgroup (idle above unless per <= H)
-                const float sv = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, a.P, a.G, lane);
-                if (lane == 0) __hip_atomic_store(gt + PS - 1, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
+            const unsigned long long tag = (unsigned long long)(red_cnt + 1u) << 32;
+            // one total per wave, spread over every wave of the instance's workgroups (H * nq + 1 totals on up to 7 x 32 x 4 waves: a wave
+            // that reduced several of them paid one cross-XCD round trip after the other)
+            for (int item = r_ * 4 + wave; item <= H * nq; item += per * 4) {
+                const int t = item / nq, q = item < H * nq ? t * 12 + (item - t * nq) : PS - 1;       // the last item: the cost total
+                const float sv = coop_total(pbuf + (size_t)q * C.Ppad, a.P, a.G, lane);
+                if (lane == 0) __hip_atomic_store(gt + q, tag | (unsigned long long)__float_as_uint(sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         else if (phase == PH_INIT) { iact = grp == 0; }
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
 #if SDEMPC_VAR_SPEC_CLK
         const unsigned long long ck_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
-        coop_barrier(C, tid);
+        if (phase != PH_RED) coop_barrier(C, tid);      // (the totals of a reduction phase carry their own tag)
 #if SDEMPC_VAR_SPEC_CLK
         const unsigned long long ck_t2 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -191,11 +196,19 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             else phase = PH_RED;
         } else if (phase == PH_RED) {
             constexpr int nq = M + 4;
-            const float* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
+            const unsigned long long* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
             red_cnt += 1u;
+            const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
+            auto tagged = [&](const unsigned long long* p) {        // wait (bounded like a grid barrier) until the word carries this phase's tag
+                unsigned long long v;
+                while ((unsigned)((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != red_cnt) {
+                    if (__builtin_amdgcn_s_memrealtime() - t0w >= (uint64_t)C.spin_limit) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                return __uint_as_float((unsigned)v);
+            };
             for (int q = tid; q < H * 12; q += Team::NT)
-                if ((q % 12) < nq) sm.tot[q] = coop_load(gt + q);
-            if (tid == 0) sm.red[12] = coop_load(gt + PS - 1);
+                if ((q % 12) < nq) sm.tot[q] = tagged(gt + q);
+            if (tid == 0) sm.red[12] = tagged(gt + PS - 1);
             const float cu = block_ucost<Team>(a, sm, yk, tid);        // (contains the barriers that publish sm.tot / sm.red)
             __syncthreads();
             c_y = uni_f(FMA(sm.red[12], a.invP, cu));

@@ -382,6 +382,20 @@ def test_device_resident_api_equals_host_api():
     torch.cuda.synchronize()
     c_ref, traj_ref, _ = S.rollout(x0, u, xref, noise, True, True)
     assert bits_differ(cost.cpu().numpy(), c_ref) == 0 and bits_differ(traj.cpu().numpy(), traj_ref) == 0
+    # the conversion is refused once the trajectory workspace no longer holds that rollout: a rollout without store_traj, a smaller one, a solve
+    from sde4mbrl_px4_amd.solver import SdempcError
+    S.rollout_dev(2, tx0.data_ptr(), tu.data_ptr(), txr.data_ptr(), nd.data_ptr(), cost.data_ptr(), None, True, st)
+    S.traj_to_canonical_dev(2, traj.data_ptr(), st)
+    with pytest.raises(SdempcError, match="fewer instances"):
+        S.traj_to_canonical_dev(B, traj.data_ptr(), st)
+    S.rollout_dev(B, tx0.data_ptr(), tu.data_ptr(), txr.data_ptr(), nd.data_ptr(), cost.data_ptr(), None, False, st)
+    with pytest.raises(SdempcError, match="holds no rollout"):
+        S.traj_to_canonical_dev(B, traj.data_ptr(), st)
+    S.rollout_dev(B, tx0.data_ptr(), tu.data_ptr(), txr.data_ptr(), nd.data_ptr(), cost.data_ptr(), None, True, st)
+    S.solve_dev(B, tx0.data_ptr(), txr.data_ptr(), nd.data_ptr(), tu0.data_ptr(), ts0.data_ptr(), uopt.data_ptr(), xevol.data_ptr(), info.data_ptr(), st)
+    with pytest.raises(SdempcError, match="holds no rollout"):
+        S.traj_to_canonical_dev(B, traj.data_ptr(), st)
+    torch.cuda.synchronize()
     S.close()
 
 

@@ -15,6 +15,7 @@ struct CoopCtx {
     unsigned epoch, spin_limit;   // spin_limit: ticks of the 100 MHz s_memrealtime clock one barrier may wait (KArgs::coop_spin)
     int fence;              // KArgs::opt.coop_fence: agent-scope release / acquire fences around the barrier
     float* pp;              // [2][PS][Ppad] per-particle outputs, double-buffered by rollout parity
+    unsigned long long* gtot;   // [2][PS] published totals {value, tag} of the distributed reductions (behind the per-particle slots of the instance)
     float* ck;              // [P][H+1][COOP_ROW] checkpoint rows
 };
 
@@ -122,38 +123,28 @@ DI float coop_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, CoopCtx&
         lane2_grad<M>(a, sm, lane2_lds(a, sm, wave), io, lane);
     }
     coop_barrier(C, tid);
-    // particle sums of the nq adjoint outputs of every step -> LDS (wave w takes the steps t = w, w + 4, ...)
-    if (wave == 0) { const float t0 = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, P, G, lane); if (lane == 0) sm.red[12] = t0; }
-    // all nq sums of a step are reduced together: the 2 x nq loads of a pass are independent and in flight at once (a load that
-    // crosses XCDs takes about a microsecond; one at a time they would dominate the gradient evaluation)
+    // particle sums of the nq adjoint outputs of every step (+ the cost total): one total per wave, spread over every wave of the instance's
+    // workgroups, published as 64-bit words {value, tag = number of this barrier} and read back by everyone — no second barrier: the datum is
+    // the hand-off (sdempc_spec.inc.h). Every workgroup reducing all H * nq totals itself cost 18 % of a C5 gradient evaluation (H = 200, 32 groups).
     {
-        const int hh = lane >> 5, j = lane & 31;
-        for (int t = wave; t < H; t += 4) {
-            float Sa[nq], Sb[nq];
-#pragma unroll
-            for (int kq = 0; kq < nq; ++kq) { Sa[kq] = 0.0f; Sb[kq] = 0.0f; }
-            for (int g0 = 0; g0 < G; g0 += 4) {          // two passes (four groups) per chunk
-                float v0[nq], v1[nq];
-                const int pa = 32 * (g0 + hh) + j, pb = 32 * (g0 + 2 + hh) + j;
-                const bool oka = (g0 + hh < G) && pa < P, okb = (g0 + 2 + hh < G) && pb < P;
-#pragma unroll
-                for (int kq = 0; kq < nq; ++kq) {
-                    const float* pq = pbuf + (size_t)(t * 12 + kq) * C.Ppad;
-                    v0[kq] = oka ? coop_load(pq + pa) : 0.0f;
-                    v1[kq] = okb ? coop_load(pq + pb) : 0.0f;
-                }
-#pragma unroll
-                for (int kq = 0; kq < nq; ++kq) {
-                    Sa[kq] = Sa[kq] + group_bfly32(v0[kq]);                     // groups g0, g0+1 -> slots 0 / 1
-                    if (g0 + 2 < G) Sb[kq] = Sb[kq] + group_bfly32(v1[kq]);     // groups g0+2, g0+3 -> slots 2 / 3
-                }
-            }
-#pragma unroll
-            for (int kq = 0; kq < nq; ++kq) {
-                const float S0 = readlane_f(Sa[kq], 0), S1 = readlane_f(Sa[kq], 32), S2 = readlane_f(Sb[kq], 0), S3 = readlane_f(Sb[kq], 32);
-                if (lane == 0) sm.tot[t * 12 + kq] = ((S0 + S1) + S2) + S3;
-            }
+        unsigned long long* gt = C.gtot + (size_t)(C.epoch & 1u) * PS;
+        const unsigned long long tag = (unsigned long long)C.epoch << 32;
+        for (int item = C.wgi * 4 + wave; item <= H * nq; item += C.nwg * 4) {
+            const int t = item / nq, q = item < H * nq ? t * 12 + (item - t * nq) : PS - 1;
+            const float sv = coop_total(pbuf + (size_t)q * C.Ppad, P, G, lane);
+            if (lane == 0) __hip_atomic_store(gt + q, tag | (unsigned long long)__float_as_uint(sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
+        auto tagged = [&](const unsigned long long* pw) {
+            unsigned long long v;
+            while ((unsigned)((v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != C.epoch) {
+                if (__builtin_amdgcn_s_memrealtime() - t0w >= (uint64_t)C.spin_limit) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            return __uint_as_float((unsigned)v);
+        };
+        for (int q = tid; q < H * 12; q += Team::NT)
+            if ((q % 12) < nq) sm.tot[q] = tagged(gt + q);
+        if (tid == 0) sm.red[12] = tagged(gt + PS - 1);
     }
     Team::sync();
     const float tot = sm.red[12];

@@ -174,6 +174,11 @@ constexpr int NZ_STAGE = 6 * 64;                       // floats per wave
 constexpr int UST = 36;
 constexpr int REC = 64, NZL = 8;                       // cooperative layouts: floats per step record / per noise row in LDS (sdempc_lane2.inc.h)
 constexpr int COOP_ROW = 172;                          // floats per (particle, step) checkpoint row of the cooperative layouts (sdempc_lane2.inc.h)
+// per-instance output workspace of the cooperative layouts (KArgs::coop_pp), floats: 2 x SPEC_SLOTS slots of [part_stride(H)][Ppad] per-particle
+// outputs (the plain cooperative kernel uses the first two), then [2][part_stride(H)] 64-bit tagged totals
+constexpr int SPEC_SLOTS = 9;
+__host__ __device__ inline size_t coop_gtot_offset(int H, int Ppad) { return (size_t)2 * SPEC_SLOTS * part_stride(H) * Ppad; }
+__host__ __device__ inline size_t coop_pp_stride(int H, int Ppad) { return coop_gtot_offset(H, Ppad) + 4 * (size_t)part_stride(H); }
 
 DI Smem carve(float* base, int H, int m, int team, bool coop = false, bool ust_lds = true) {
     Smem s;
@@ -771,7 +776,8 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
         b_ = blockIdx.x / a.coop_nwg;                                                \
         CC.nwg = a.coop_nwg; CC.wgi = blockIdx.x - b_ * a.coop_nwg; CC.Ppad = a.G * 32; CC.epoch = 0u; CC.spin_limit = a.coop_spin; CC.fence = a.opt.coop_fence; \
         CC.bar = a.coop_bar + 2 * b_;                                                \
-        CC.pp = a.coop_pp + (size_t)b_ * 2 * part_stride(a.H) * CC.Ppad;             \
+        CC.pp = a.coop_pp + (size_t)b_ * coop_pp_stride(a.H, CC.Ppad);               \
+        CC.gtot = reinterpret_cast<unsigned long long*>(CC.pp + coop_gtot_offset(a.H, CC.Ppad)); \
         CC.ck = a.coop_ck + (size_t)b_ * a.P * (a.H + 1) * COOP_ROW;                 \
     } else {                                                                         \
         b_ = blockIdx.x * Team::IPB + Team::team();                                  \
@@ -785,7 +791,11 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     if (b >= a.B) return; /* no workgroup-wide barrier below this line in TeamWave */ \
     if constexpr (MODE == 1) load_lane_weights(a, LW, threadIdx.x & 63);              \
     load_common<Team>(a, sm, b, tid);                                                \
-    if constexpr (MODE == 2) { __syncthreads(); lane2_stage<Team>(a, sm, b, CC.wgi, tid); }
+    if constexpr (MODE == 2) {                                                       \
+        __syncthreads(); lane2_stage<Team>(a, sm, b, CC.wgi, tid);                   \
+        if (CC.wgi == 0)   /* tags of an earlier launch must not be taken for this one's (first use: behind a grid barrier) */ \
+            for (int i = tid; i < 2 * part_stride(a.H); i += Team::NT) __hip_atomic_store(CC.gtot + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    }
 
 template <class Team, int F16, int MODE = 0>
 __global__ void __launch_bounds__(Team::BNT, (MODE ? 2 : 3)) sdempc_rollout_kernel(KArgs a) {
@@ -1223,7 +1233,7 @@ int coop_max_instances(int P, int H, int m, const LaunchOpts& o) {
 }
 // per-instance workspace, sized for the speculative variant (7 output slots, 3 checkpoint regions); the plain cooperative kernel
 // uses a prefix of it
-size_t coop_pp_floats(int H, int G) { return (size_t)2 * SPEC_SLOTS * part_stride(H) * G * 32 + 4 * (size_t)part_stride(H); }      // (+ [2][PS] tagged 64-bit totals)
+size_t coop_pp_floats(int H, int G) { return coop_pp_stride(H, G * 32); }
 size_t coop_ck_floats(int H, int P) { return (size_t)SPEC_CKS * P * (H + 1) * COOP_ROW; }
 int spec_max_instances(int P, int H, int m, const LaunchOpts& o) {
     if (!o.spec || !o.coop) return 0;      // SDEMPC_OPT_SPEC / SDEMPC_OPT_COOP = 0; P == 1 is welcome here (one wave per workgroup is active)

@@ -13,7 +13,7 @@
 // Written as a state machine with ONE call site of the particle work, so that the rollout and the gradient sweep are each
 // instantiated once (the first version inlined them at seven sites: 140 KB of code, 2x slower sweeps).
 // ================================================================================================
-constexpr int SPEC_GROUPS = 7, SPEC_SLOTS = 9, SPEC_CKS = 4;
+constexpr int SPEC_GROUPS = 7, SPEC_CKS = 4;      // (SPEC_SLOTS = 9: sdempc_kernels.hip, with the workspace layout)
 constexpr int SLOT_SEQ = 6, SLOT_GRAD = 5;        // slots 0..4 and 7, 8: the items of a parallel phase
 constexpr int SLOT_T3 = 7, SLOT_Y3 = 8;           // third parallel trial and the candidate gradient behind it (groups 5, 6)
 
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     CoopCtx C;
     C.nwg = per; C.wgi = r_ - grp * nwg; C.Ppad = a.G * 32; C.epoch = 0u; C.spin_limit = a.coop_spin; C.fence = a.opt.coop_fence;
     C.bar = a.coop_bar + 2 * b;
-    C.pp = a.coop_pp + (size_t)b * ((size_t)2 * SPEC_SLOTS * PS * C.Ppad + 4 * (size_t)PS);
+    C.pp = a.coop_pp + (size_t)b * coop_pp_stride(H, C.Ppad);
     C.ck = a.coop_ck + ((size_t)b * SPEC_CKS + (grp == 6 ? 3 : grp >= 2 && grp <= 4 ? grp - 2 : 0)) * a.P * (H + 1) * COOP_ROW;    // gradients run on groups 2..4 and 6 (or 0 when there are only two)
     Smem sm = carve(smem, H, m, 0, true);
     WaveW ww;
@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     // [2][PS] published totals behind the per-particle slots, each a 64-bit word {value, tag}: the tag is the number of the reduction phase that
     // produced it, so a consumer that reads the pair in one aligned 64-bit load knows the value is the one it waits for — the reduction phase needs
     // no grid barrier of its own (a barrier costs 5 - 6 us of round trips across the XCDs: 5 % of an iteration), the hand-off is the datum itself
-    unsigned long long* gtot_base = reinterpret_cast<unsigned long long*>(C.pp + (size_t)2 * SPEC_SLOTS * PS * C.Ppad);
+    unsigned long long* gtot_base = reinterpret_cast<unsigned long long*>(C.pp + coop_gtot_offset(H, C.Ppad));
+    C.gtot = gtot_base;
     unsigned red_cnt = 0u, red_par = 0u; int red_slot = 0;
     // tags of an earlier launch must not be taken for this one's: the instance's first workgroup clears the words (the first reduction phase lies
     // behind at least two grid barriers)

@@ -31,6 +31,7 @@
 #include "../include/sdempc.h"
 #if !defined(ORC_DOUBLE) && !defined(ORC_VEC)
 #include "mfma16_model.c"      /* SPEC.md §9a: the 16-bit-operand matrix instruction, as the checker models it (same translation unit: the group addition inlines) */
+#include "transc_model.c"      /* SPEC.md §10a: v_exp_f32 / v_rcp_f32 / v_rsq_f32, as the checker models them (math_mode: fast) */
 #define ORC_MFMA16 1
 #endif
 
@@ -162,6 +163,7 @@ double NAME(sigmoid)(double x) { return 1.0 / (1.0 + exp(-x)); }
 typedef struct {
     int m;
     int f16;   /* mlp_dtype: 1 = SPEC.md §9 fp16-operand MLP contractions, 2 = §9b three-limb bf16 split of the layer-2 contractions */
+    int fast;  /* math_mode fast (SPEC.md §10): tanh / sigmoid / rsqrt through the hardware's transcendental instructions, modelled in transc_model.c */
 #ifdef ORC_MFMA16
     /* operands of the matrix instruction, decoded once, in k-slot order: slot k of K-half hf is hidden unit u(hf,k) = rowmap(8 hf + (k & 7), k >> 3) */
     orc_op16 h1[2 * HID][16];            /* f16 mode, layer 1: row r, slots 0..5 = W1z[r][k], the rest zero */
@@ -243,6 +245,29 @@ void NAME(contract32)(int mode, const float* W, const float* v, const float* c, 
     }
 }
 #endif
+
+/* activations of a step: SPEC.md §3 (default) or, in math_mode fast, §10 on the modelled instructions (float32 checker build only) */
+static inline void act_tanh4(const model_t* M, const preal* x, preal* y) {
+#ifdef ORC_MFMA16
+    if (M->fast) {
+        for (int i = 0; i < 4; ++i) y[i] = fmaf(-2.0f, orc_hw_rcp(1.0f + orc_hw_exp2(x[i] * 2.885390043258667f)), 1.0f);
+        return;
+    }
+#endif
+    NAME(tanh4)(x, y);
+}
+static inline preal act_sigmoid(const model_t* M, preal x) {
+#ifdef ORC_MFMA16
+    if (M->fast) return orc_hw_rcp(1.0f + orc_hw_exp2(x * -1.4426950216293335f));
+#endif
+    return NAME(sigmoid)(x);
+}
+static inline preal act_rsqrt(const model_t* M, preal a) {
+#ifdef ORC_MFMA16
+    if (M->fast) return orc_hw_rsq(a);
+#endif
+    return NAME(rsqrt)(a);
+}
 
 static int parse_blob(const void* blob, model_t* M, int f16) {
     const int32_t* hd = (const int32_t*)blob;
@@ -401,7 +426,7 @@ static void step_fwd(const model_t* M, const ustep_t* U, const preal* x, const p
         for (int k = 0; k < NN; ++k) { a = PFMA(M->W1z[r][k], z[k], a); b = PFMA(M->W1z[HID + r][k], z[k], b); }
         pre_d[r] = a; pre_n[r] = b;
     }
-    for (int r = 0; r < HID; r += 4) { NAME(tanh4)(pre_d + r, A->h1d + r); NAME(tanh4)(pre_n + r, A->h1n + r); }
+    for (int r = 0; r < HID; r += 4) { act_tanh4(M, pre_d + r, A->h1d + r); act_tanh4(M, pre_n + r, A->h1n + r); }
     /* layer 2 (drift): k visited in rowmap order */
 #ifdef ORC_MFMA16
     if (M->f16 == 1) {      /* SPEC.md §9: TWO chained v_mfma_f32_32x32x16_f16 (hf = 0, 1) from C = b2[i] */
@@ -426,7 +451,7 @@ static void step_fwd(const model_t* M, const ustep_t* U, const preal* x, const p
         for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int k = rowmap(r, h); a = PFMA(M->W2[i][k], F16Q(M->f16 == 1, A->h1d[k]), a); }
         pre_2[i] = a;
     }
-    for (int r = 0; r < HID; r += 4) NAME(tanh4)(pre_2 + r, A->h2 + r);
+    for (int r = 0; r < HID; r += 4) act_tanh4(M, pre_2 + r, A->h2 + r);
     /* output layers: two half-sums (h = 0, 1) over r, then (P0 + P1) + bias */
     for (int i = 0; i < 6; ++i) {
         preal P0 = pbroadcast(R(0)), P1 = pbroadcast(R(0));
@@ -436,7 +461,7 @@ static void step_fwd(const model_t* M, const ustep_t* U, const preal* x, const p
     {
         preal P0 = pbroadcast(R(0)), P1 = pbroadcast(R(0));
         for (int r = 0; r < 16; ++r) { P0 = PFMA(M->w3n[rowmap(r, 0)], A->h1n[rowmap(r, 0)], P0); P1 = PFMA(M->w3n[rowmap(r, 1)], A->h1n[rowmap(r, 1)], P1); }
-        A->eta = NAME(sigmoid)((P0 + P1) + M->b3n);
+        A->eta = act_sigmoid(M, (P0 + P1) + M->b3n);
     }
     /* rigid body */
     A->Fb[0] = M->sF[0] * A->o[0]; A->Fb[1] = M->sF[1] * A->o[1]; A->Fb[2] = PFMA(M->sF[2], A->o[2], U->Tz);
@@ -469,7 +494,7 @@ static void step_fwd(const model_t* M, const ustep_t* U, const preal* x, const p
     }
     for (int i = 0; i < 4; ++i) A->qt[i] = PFMA(dq[i], dt, q[i]);
     preal n2 = PFMA(A->qt[3], A->qt[3], PFMA(A->qt[2], A->qt[2], PFMA(A->qt[1], A->qt[1], A->qt[0] * A->qt[0])));
-    A->rn = NAME(rsqrt)(n2);
+    A->rn = act_rsqrt(M, n2);
     for (int i = 0; i < 4; ++i) { A->qn[i] = A->qt[i] * A->rn; xn[6 + i] = A->qn[i]; }
 }
 
@@ -701,6 +726,15 @@ static int ctx_init(ctx_t* X, const sdempc_cfg* C, const void* blob) {
     if (C->mlp_dtype != 0) return SDEMPC_EINVAL;   /* the timing build has the f32 arithmetic only */
 #endif
     if (parse_blob(blob, &X->M, C->mlp_dtype)) return SDEMPC_EBLOB;
+    X->M.fast = 0;
+    if (C->math_mode) {
+#ifdef ORC_MFMA16
+        if (!orc_transc_ready()) return SDEMPC_EINVAL;      /* tests/orc.py maps the instruction tables (orc_transc_open) before a fast-mode oracle is made */
+        X->M.fast = 1;
+#else
+        return SDEMPC_EINVAL;                               /* the float64 and the timing builds have the SPEC §3 functions only */
+#endif
+    }
     X->C = C; X->H = C->horizon; X->P = C->num_particles; X->m = C->num_motors;
     if (X->H < 1 || X->P < 1 || X->m != X->M.m) return SDEMPC_EINVAL;
     X->dt = (real*)malloc(sizeof(real) * X->H);

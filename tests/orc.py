@@ -124,6 +124,49 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+TRANSC_DIR = os.path.join(ROOT, "tests", "golden", "transc")
+TRANSC_BIN = os.path.join(ORC_DIR, "_transc", "transc_tables.bin")
+TRANSC_BLOCKS = ["rcp_s0_e127", "rsq_s0_e127", "rsq_s0_e128"] + [f"exp_s{s}_e{e}" for e in range(97, 128) for s in (0, 1)]
+
+
+def transc_tables(L=None):
+    """Maps the recorded answers of v_exp_f32 / v_rcp_f32 / v_rsq_f32 into the oracle (oracle/transc_model.c, SPEC.md §10a). The committed form is
+    tests/golden/transc/<block>.i8.xz (2^23 differences of -1 / 0 / +1 ulp per block, 1.9 MB in all); the model reads them two bits per answer
+    from one file (65 blocks x 2 MiB), written here on first use and whenever a committed block is newer."""
+    import lzma
+    L = L or lib()
+    if L.orc_transc_ready():
+        return
+    src = [os.path.join(TRANSC_DIR, b + ".i8.xz") for b in TRANSC_BLOCKS]
+    stale = (not os.path.exists(TRANSC_BIN)) or os.path.getsize(TRANSC_BIN) != len(src) << 21 or any(os.path.getmtime(f) > os.path.getmtime(TRANSC_BIN) for f in src)
+    if stale:
+        os.makedirs(os.path.dirname(TRANSC_BIN), exist_ok=True)
+        tmp = TRANSC_BIN + f".{os.getpid()}.tmp"
+        with open(tmp, "wb") as out:
+            for f in src:
+                d = np.frombuffer(lzma.decompress(open(f, "rb").read()), dtype=np.int8)
+                assert d.size == 1 << 23 and d.min() >= -1 and d.max() <= 1, f
+                q = (d + 1).astype(np.uint8).reshape(-1, 4)
+                out.write((q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8).tobytes())
+        os.replace(tmp, TRANSC_BIN)
+    L.orc_transc_open.argtypes = [C.c_char_p]
+    rc = L.orc_transc_open(TRANSC_BIN.encode())
+    if rc != 0:
+        raise RuntimeError(f"orc_transc_open({TRANSC_BIN}) failed: {rc}")
+
+
+def hw_eval(func, x):
+    """v_rcp_f32 (0) / v_rsq_f32 (1) / v_exp_f32 (2) of a float32 array through the model"""
+    L = lib()
+    transc_tables(L)
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    L.orc_hw_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.orc_hw_eval.restype = None
+    L.orc_hw_eval(func, x.ctypes.data, y.ctypes.data, x.size)
+    return y
+
+
 class Oracle:
     """Oracle bound to one (config, model blob). double=True selects the float64 build."""
 
@@ -134,6 +177,8 @@ class Oracle:
         self._blobbuf = C.create_string_buffer(self.blob, len(self.blob))
         self.pre = "orcv_" if vec else ("orcd_" if double else "orc_")
         self._lib = lib_vec() if vec else (lib_fast() if fast else lib())
+        if getattr(mpc_cfg, "math_mode", "exact") == "fast":
+            transc_tables(self._lib)          # (the float64 and the timing builds refuse math_mode fast)
         self.H, self.P, self.m = mpc_cfg.horizon, mpc_cfg.num_particles, mpc_cfg.num_motors
 
     def _fn(self, name):

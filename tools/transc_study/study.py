@@ -291,5 +291,101 @@ def main_gather():
     print("done", f"{time.time() - t0:.0f}s")
 
 
-if __name__ == "__main__":
-    {"gather": main_gather}[sys.argv[1]]()
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gather":
+    main_gather()
+
+
+def main_tables():
+    """Phase 2 (SPEC.md §10a): the complete description of v_exp_f32 the oracle needs.
+      * every binade with |x| in [2^-30, 2) (exponent fields 97 .. 127, both signs): all 2^23 answers as int8 differences from ref_exp_bits -> exp_s<s>_e<e>.i8.xz
+      * exhaustive checks of the rules that cover everything else: |x| >= 2 reduces to the binade [1, 2) / (-2, -1] by an exponent shift,
+        tiny |x| gives exactly 1, overflow / underflow thresholds, specials."""
+    import torch
+    os.makedirs(OUT, exist_ok=True)
+    L = lib()
+    dev = torch.device("cuda:0")
+    N = 1 << 23
+    buf = torch.zeros(N, dtype=torch.int32, device=dev)
+    rep = {"device": torch.cuda.get_device_name(0)}
+    t0 = time.time()
+    blocks = []
+    for fld in range(97, 128):
+        for sign in (0, 1):
+            start = (sign << 31) | (fld << 23)
+            assert L.transc_eval_range(EXP, start, 1, N, buf.data_ptr()) == 0
+            hb = buf.cpu().numpy().view(np.uint32).copy()
+            xb = (np.arange(N, dtype=np.uint64) + start).astype(np.uint32)
+            blocks.append(save_delta(f"exp_s{sign}_e{fld}", xb, hb, EXP))
+            print(blocks[-1]["name"], blocks[-1]["hist"], blocks[-1]["bytes"], f"{time.time() - t0:.0f}s", flush=True)
+    rep["blocks"] = blocks
+    # canonical binades on the device: result(1 + f) and result(-(1 + g))
+    assert L.transc_eval_range(EXP, 127 << 23, 1, N, buf.data_ptr()) == 0
+    Tp = (buf.to(torch.int64) & 0xFFFFFFFF).clone()
+    assert L.transc_eval_range(EXP, (1 << 31) | (127 << 23), 1, N, buf.data_ptr()) == 0
+    Tn = (buf.to(torch.int64) & 0xFFFFFFFF).clone()
+    CH = 1 << 26
+    outb = torch.zeros(CH, dtype=torch.int32, device=dev)
+    res = {}
+    for sign in (0, 1):
+        cats, ex = {}, {}
+        for fld in range(128, 136):
+            for part in range((1 << 23) // CH if CH < (1 << 23) else 1):
+                start = (sign << 31) | (fld << 23)
+                n = N
+                assert L.transc_eval_range(EXP, start, 1, n, outb.data_ptr()) == 0
+                hb = outb[:n].to(torch.int64) & 0xFFFFFFFF
+                m = torch.arange(n, dtype=torch.int64, device=dev) | 0x800000
+                sh = fld - 127                         # |x| = m * 2^(sh - 23)
+                fixed = m << sh
+                k = (fixed >> 23) - 1                   # integer part minus one: |x| = (1 + frac) + k
+                frac = fixed & 0x7FFFFF
+                t = (Tn if sign else Tp)[frac]
+                ef = ((t >> 23) & 0xFF) + (-k if sign else k)
+                expect = (ef << 23) | (t & 0x7FFFFF)
+                inr = (ef >= 1) & (ef <= 254)
+                bad = inr & (hb != expect)
+                key = f"e{fld}"
+                c = cats.setdefault(key, {"checked": 0, "mismatch": 0, "outside": 0, "outside_values": {}})
+                c["checked"] += int(inr.sum().item()); c["mismatch"] += int(bad.sum().item()); c["outside"] += int((~inr).sum().item())
+                if int((~inr).sum().item()):
+                    u, cn = torch.unique(hb[~inr], return_counts=True)
+                    if u.numel() <= 8:
+                        for a, b in zip(u.tolist(), cn.tolist()):
+                            c["outside_values"][f"{a:08x}"] = c["outside_values"].get(f"{a:08x}", 0) + b
+                    else:
+                        c["outside_values"]["many"] = int(u.numel())
+                if int(bad.sum().item()) and len(ex) < 12:
+                    for i in torch.nonzero(bad)[:3, 0].tolist():
+                        ex[f"{start + i:08x}"] = [f"{int(hb[i]):08x}", f"{int(expect[i]):08x}"]
+        res[f"sign{sign}"] = {"by_binade": cats, "examples": ex}
+        print("reduction to the canonical binade, sign", sign, json.dumps(res[f"sign{sign}"])[:1500], flush=True)
+    rep["reduction"] = res
+    # tiny arguments: the distinct answers per exponent field below 97, both signs (incl. zero / sub-normal inputs at field 0)
+    tiny = {}
+    for sign in (0, 1):
+        for fld in list(range(0, 4)) + list(range(80, 97)):
+            start = (sign << 31) | (fld << 23)
+            assert L.transc_eval_range(EXP, start, 1, N, buf.data_ptr()) == 0
+            u, cn = torch.unique(buf.to(torch.int64) & 0xFFFFFFFF, return_counts=True)
+            tiny[f"s{sign}_e{fld}"] = {f"{a:08x}": b for a, b in zip(u.tolist()[:6], cn.tolist()[:6])}
+    rep["tiny"] = tiny
+    # the underflow edge: where do results leave the normal range, and what are they there (negative arguments -120 .. -160)
+    edge = {}
+    for x in np.concatenate([np.arange(-124.0, -128.5, -0.25), np.arange(-129.0, -152.0, -1.0)]).astype(np.float32):
+        xb = int(np.array([x], np.float32).view(np.uint32)[0])
+        assert L.transc_eval_range(EXP, xb, 1, 4, buf.data_ptr()) == 0
+        edge[f"{float(x)}"] = [f"{int(v) & 0xFFFFFFFF:08x}" for v in buf[:4].cpu().numpy()]
+    rep["underflow_edge"] = edge
+    over = {}
+    for x in (127.0, 127.5, 127.99999, 128.0, 128.00002, 200.0):
+        xb = int(np.array([x], np.float32).view(np.uint32)[0])
+        assert L.transc_eval_range(EXP, xb, 1, 2, buf.data_ptr()) == 0
+        over[f"{x}"] = [f"{int(v) & 0xFFFFFFFF:08x}" for v in buf[:2].cpu().numpy()]
+    rep["overflow_edge"] = over
+    with open(os.path.join(OUT, "tables.json"), "w") as f:
+        json.dump(rep, f, indent=1)
+    print("done", f"{time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tables":
+    main_tables()

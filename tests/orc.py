@@ -125,7 +125,8 @@ def _f32(a):
 
 
 TRANSC_DIR = os.path.join(ROOT, "tests", "golden", "transc")
-TRANSC_BIN = os.path.join(ORC_DIR, "_transc", "transc_tables.bin")
+import tempfile
+TRANSC_BIN = os.path.join(tempfile.gettempdir(), f"sdempc_oracle_{os.getuid()}", "transc_tables.bin")      # 130 MiB, derived: kept out of the repository tree
 TRANSC_BLOCKS = ["rcp_s0_e127", "rsq_s0_e127", "rsq_s0_e128"] + [f"exp_s{s}_e{e}" for e in range(97, 128) for s in (0, 1)]
 
 

@@ -62,7 +62,9 @@ def lib_hash():
     return hashlib.sha256(open(_abi.lib_path(), "rb").read()).hexdigest()[:16]
 
 
-DEFAULT_MLP = "f32x3"      # the reported arithmetic: f32 operands and accumulation, layer-2 contractions as three-limb bf16 splits (SPEC.md 9b)
+DEFAULT_MLP = "f32x3"      # the reported arithmetic: f32 operands and accumulation, layer-2 contractions as three-limb bf16 splits (SPEC.md 9b) ...
+DEFAULT_MATH = "fast"      # ... and tanh / sigmoid / rsqrt on the hardware's transcendental instructions (SPEC.md 10), which the oracle evaluates
+                           # through its exact model of v_exp_f32 / v_rcp_f32 / v_rsq_f32 (SPEC.md 10a): every figure of the line is checked bit for bit
 
 DTYPE_NOTE = {
     "f32": "f32",
@@ -71,6 +73,8 @@ DTYPE_NOTE = {
              "(tests/test_mfma16_model_cpu.py), bit-identical to the CPU oracle)",
     "f16": "f16 MLP operands / f32 accumulate and state",
 }
+MATH_NOTE = {"exact": "activations by the software forms of SPEC.md 3", "fast": "activations on v_exp_f32 / v_rcp_f32 (1 ulp), quaternion renormalisation on v_rsq_f32: SPEC.md 10, "
+             "bit-identical to the CPU oracle through its model of the three instructions (SPEC.md 10a)"}
 
 
 def dry_run(args, rank, world):
@@ -110,6 +114,8 @@ def main():
     ap.add_argument("--mlp-dtype", default=DEFAULT_MLP, choices=["f32", "f16", "f32x3"],
                     help="f32x3 (default, the reported metric): f32 arithmetic with the layer-2 contractions as three-limb bf16 splits on the matrix pipe "
                          "(SPEC.md 9b), bit-identical to the oracle; f32: every contraction an f32 fma chain; f16: fp16-operand MLP contractions (SPEC.md 9)")
+    ap.add_argument("--math-mode", default=DEFAULT_MATH, choices=["exact", "fast"],
+                    help="fast (default): hardware transcendentals (SPEC.md 10), checked bit for bit through the oracle's instruction model (10a); exact: the software forms of SPEC.md 3")
     ap.add_argument("--max-iter", type=int, default=0, help="override the YAML's apg_mpc.max_iter (0: keep; profiling runs of the long-horizon config)")
     ap.add_argument("--no-tolerance-modes", action="store_true", help="skip the extra launches in the tolerance-parity mode (math_mode: fast)")
     ap.add_argument("--c4-reps", type=int, default=100, help="N > 1: barrier-aligned ticks of the one-instance-per-GPU leg (BASELINE config 4); 0 skips it")
@@ -161,7 +167,7 @@ def main():
             raise SystemExit(f"bench.py: rank {rank} of {world}: init_process_group({backend!r}) on device {dev_ord} failed: {type(e).__name__}: {e}")
 
     def cfg_of(path, mlp, **kw):
-        return load_mpc_config(path).replace(mlp_dtype=mlp, **kw)
+        return load_mpc_config(path).replace(**dict({"mlp_dtype": mlp, "math_mode": args.math_mode}, **kw))
 
     cfg = cfg_of(args.config, args.mlp_dtype)
     if args.max_iter:
@@ -237,7 +243,7 @@ def main():
         build = lib_hash()
         if os.path.exists(pmc):
             try:
-                rec = json.load(open(pmc)).get(f"{os.path.basename(args.config)}:B{B}:{args.mlp_dtype}", {})
+                rec = json.load(open(pmc)).get(f"{os.path.basename(args.config)}:B{B}:{args.mlp_dtype}:{args.math_mode}", {})
                 traffic_build = rec.get("traffic_build")
                 if traffic_build == build:
                     traffic, traffic_src, valu_issue = rec.get("hbm_bytes_per_launch"), rec.get("source"), rec.get("valu_issue")
@@ -262,17 +268,17 @@ def main():
             lat_same, same_kernel, _ = latency_of(L, L.solver, min(args.latency_reps, 30), min(args.latency_warmup, 2))
         arith = {"f32": "f32 fma chains", "f32x3": "f32 with three-limb bf16 split contractions (f32x3)", "f16": "f16 MLP operands"}[args.mlp_dtype]
         out = {
-            "metric": (f"MPC solves/sec, Iris H=50 P=128, arithmetic {args.mlp_dtype} (p50 solve latency in p50_solve_latency_ms: arithmetic f32; same-arithmetic pairs in by_arithmetic)"
-                       if c2_run else f"MPC solves/sec, {os.path.basename(args.config)}, arithmetic {args.mlp_dtype}"),
+            "metric": (f"MPC solves/sec, Iris H=50 P=128, arithmetic {args.mlp_dtype}/{args.math_mode} (p50 solve latency in p50_solve_latency_ms: arithmetic f32/{args.math_mode}; "
+                       "same-arithmetic pairs in by_arithmetic)" if c2_run else f"MPC solves/sec, {os.path.basename(args.config)}, arithmetic {args.mlp_dtype}/{args.math_mode}"),
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": DTYPE_NOTE[args.mlp_dtype], "mlp_dtype": args.mlp_dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_NOTE[args.mlp_dtype] + "; " + MATH_NOTE[args.math_mode], "mlp_dtype": args.mlp_dtype, "math_mode": args.math_mode, "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.config)}: H={H} P={P} m={m}, {B} independent MPC instances per GPU per step, "
                                    f"cold-start solves from the hover guess, max_iter={cfg.max_iter} maxls={cfg.ls_maxls}",
                        "instances_per_gpu": B, "noise": "threefry2x32 keys (seed 10 split per instance), normal draws generated on the device", "N_it_mean": n_it, "N_ls_mean": n_ls, "N_grad_evaluated_mean": n_grad, "N_forward_rollouts_mean": n_fwd, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "p50_solve_latency_ms": float(np.median(lat)) if lat else None,
             "p95_solve_latency_ms": float(np.percentile(lat, 95)) if lat else None,
-            "latency_reps": len(lat), "latency_layout_fallbacks": fallbacks, "latency_kernel": single_kernel, "latency_mlp_dtype": "f32",
+            "latency_reps": len(lat), "latency_layout_fallbacks": fallbacks, "latency_kernel": single_kernel, "latency_mlp_dtype": "f32", "latency_math_mode": args.math_mode,
             "p50_solve_latency_ms_in_the_throughput_arithmetic": float(np.median(lat_same)) if lat_same else None,
             "latency_kernel_in_the_throughput_arithmetic": same_kernel, "latency_reps_in_the_throughput_arithmetic": len(lat_same),
             "p50_solve_latency_note": "one instance alone on the GPU (B = 1 launch of the same C-ABI entry point) on a handle in mlp_dtype f32: the library spreads it over ceil(P/4) x 7 "
@@ -311,15 +317,20 @@ def main():
         others = {}
         if world == 1 and not args.no_other_configs and c2_run and not args.max_iter:
             others = other_config_legs(ROOT, args.mlp_dtype, B, dev, dev_ord, cfg_of, V, args.verify, progress)
-        if world == 1 and cfg.math_mode == "exact" and not args.no_tolerance_modes and c2_run and not args.max_iter:
-            out["tolerance_modes"] = tolerance_mode_legs(L, cfg, blob, dev_ord, uopt_h)
+        if world == 1 and not args.no_tolerance_modes and c2_run and not args.max_iter:
+            out["other_math_mode"] = tolerance_mode_legs(L, cfg, blob, dev_ord, uopt_h)
         # the two same-arithmetic pairs of the headline configuration side by side (a handle has ONE mlp_dtype)
         if c2_run and not args.max_iter:
             p50 = out["p50_solve_latency_ms"]
-            by = {args.mlp_dtype: {"solves_per_s": value, "p50_ms": out["p50_solve_latency_ms_in_the_throughput_arithmetic"],
-                                   "layouts": "persistent duo tiles / " + ("speculative one-particle-per-wave" if args.mlp_dtype == "f32" else "tile layout on one workgroup")}}
+            mm = args.math_mode
+            by = {f"{args.mlp_dtype}/{mm}": {"solves_per_s": value, "p50_ms": out["p50_solve_latency_ms_in_the_throughput_arithmetic"],
+                                             "layouts": "persistent duo tiles / " + ("speculative one-particle-per-wave" if args.mlp_dtype == "f32" else "tile layout on one workgroup")}}
             if args.mlp_dtype != "f32":
-                by["f32"] = {"solves_per_s": others.get("c2_f32_chain", {}).get("value"), "p50_ms": p50, "layouts": "persistent duo tiles / speculative one-particle-per-wave"}
+                by[f"f32/{mm}"] = {"solves_per_s": others.get("c2_f32_chain", {}).get("value"), "p50_ms": p50, "layouts": "persistent duo tiles / speculative one-particle-per-wave"}
+            om = out.get("other_math_mode", {})
+            for k, v in om.items():
+                if isinstance(v, dict):
+                    by[k] = {"solves_per_s": v.get("value"), "p50_ms": v.get("p50_ms"), "layouts": "persistent duo tiles / " + ("speculative one-particle-per-wave" if v.get("p50_ms") else "-")}
             out["by_arithmetic"] = by
         progress("waiting for the CPU verification threads")
         V.join()

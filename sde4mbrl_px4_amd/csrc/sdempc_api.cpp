@@ -650,7 +650,7 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     // Small batches of multi-particle instances: one instance over ceil(P/4) workgroups, one particle per wave (latency path).
     // Same results bit for bit; only taken when every workgroup of the grid is resident at once.
-    const bool coop_ok = !a.fast && !a.f16 && !h->coop_off && a.C.sc_n == 0;     // lane layouts are built without the state-bound terms
+    const bool coop_ok = !a.f16 && !h->coop_off && a.C.sc_n == 0;     // lane layouts: f32 contractions (either math mode), built without the state-bound terms
     const int smax = coop_ok ? spec_max_instances(h->P, h->H, h->m, a.opt) : 0;
     int cmax = coop_ok ? coop_max_instances(h->P, h->H, h->m, a.opt) : 0;
     if (smax > cmax) cmax = smax;
@@ -667,8 +667,8 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
             a.coop_bar = (unsigned*)h->d_coop_bar.p; a.coop_pp = (float*)h->d_coop_pp.p; a.coop_ck = (float*)h->d_coop_ck.p;
             a.coop_spin = coop_spin_ticks(h);
             h->last_coop_B = B; h->last_ticketed = false;
-            if (B <= smax) return timed_launch(h, st, [&] { return launch_solve_spec(a, B, st); });
-            if (B <= coop_max_instances(h->P, h->H, h->m, a.opt)) return timed_launch(h, st, [&] { return launch_solve_coop(a, B, st); });
+            if (B <= smax) return timed_launch(h, st, [&] { return a.fast ? launch_solve_spec_fast(a, B, st) : launch_solve_spec(a, B, st); });
+            if (B <= coop_max_instances(h->P, h->H, h->m, a.opt)) return timed_launch(h, st, [&] { return a.fast ? launch_solve_coop_fast(a, B, st) : launch_solve_coop(a, B, st); });
             h->last_coop_B = 0;
         }
     }

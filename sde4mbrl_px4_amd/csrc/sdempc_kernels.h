@@ -121,6 +121,8 @@ int solve_workspace_rows_fast(const KArgs& a, int B);
 hipError_t launch_rollout_fast(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_grad_fast(const KArgs& a, int B, hipStream_t st);
 hipError_t launch_solve_fast(const KArgs& a, int B, hipStream_t st);
+hipError_t launch_solve_coop_fast(const KArgs& a, int B, hipStream_t st);      // the cooperative latency layouts in math_mode fast (same grid rules)
+hipError_t launch_solve_spec_fast(const KArgs& a, int B, hipStream_t st);
 // canonical [B][P][C] <-> device [B][G][C][32] (to_dev: zero-pads particles >= P)
 hipError_t launch_relayout(bool to_dev, const float* in, float* out, int B, int P, int G, int C, hipStream_t st);
 // SPEC.md §7: noise of B instances from their threefry keys (device u32[B][2]) straight into the device layout [B][G][H][6][32]

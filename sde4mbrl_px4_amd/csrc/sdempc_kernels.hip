@@ -1201,14 +1201,11 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
     if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, F16>, a, st, Team::IPB);
     return launch_k(sdempc_solve_kernel<Team, 8, F16>, a, st, Team::IPB);
 }
-// Single-particle lane layout: exact f32 arithmetic only, one wave per instance (SDEMPC_OPT_LANE = 0 forces the tile layout: A/B, tests)
+// Single-particle lane layout: f32 contractions only, one wave per instance (SDEMPC_OPT_LANE = 0 forces the tile layout: A/B, tests)
 static bool use_lane(const KArgs& k) {
-    if (FAST || k.f16 || k.P != 1 || k.C.sc_n != 0 || !use_wave_team(k.G, k.H, k.m)) return false;   // (state bounds: tile layouts only)
+    if (k.f16 || k.P != 1 || k.C.sc_n != 0 || !use_wave_team(k.G, k.H, k.m)) return false;   // (state bounds: tile layouts only)
     return k.opt.lane != 0;
 }
-#if SDEMPC_FAST
-static hipError_t launch_lane_m(int, const KArgs&, hipStream_t) { return hipErrorInvalidValue; }   // never selected (use_lane)
-#else
 template <int M>
 static hipError_t launch_lane(int what, const KArgs& k, hipStream_t st) {
     if (what == 0) return launch_k(sdempc_rollout_kernel<TeamWave, false, 1>, k, st, TeamWave::IPB);
@@ -1220,9 +1217,7 @@ static hipError_t launch_lane_m(int what, const KArgs& k, hipStream_t st) {
     if (k.m == 6) return launch_lane<6>(what, k, st);
     return launch_lane<8>(what, k, st);
 }
-#endif
-#if !SDEMPC_FAST
-// ---- cooperative latency path (exact arithmetic only) ----
+// ---- cooperative latency path (f32 contractions; both math modes) ----
 int coop_nwg(int P) { return (P + 3) / 4; }
 int coop_max_instances(int P, int H, int m, const LaunchOpts& o) {
     if (!o.coop || P < 2 || o.cus < 16) return 0;               // SDEMPC_OPT_COOP = 0 disables the path (A/B, tests)
@@ -1300,7 +1295,6 @@ hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st) {
     if (k.m == 6) return launch_coop_m<6>(k, st);
     return launch_coop_m<8>(k, st);
 }
-#endif
 
 // Rows of the per-instance / per-slot workspaces (KArgs::traj, act, part, ustg) a solve launch of B instances touches: B for the
 // layouts that run one workgroup (or wave) per instance, the number of team slots for the persistent duo launches (at most six teams
@@ -1387,6 +1381,8 @@ hipError_t launch_rollout_fast(const KArgs& a, int B, hipStream_t st) { return f
 hipError_t launch_grad_fast(const KArgs& a, int B, hipStream_t st) { return fastm::launch_grad(a, B, st); }
 hipError_t launch_solve_fast(const KArgs& a, int B, hipStream_t st) { return fastm::launch_solve(a, B, st); }
 int solve_workspace_rows_fast(const KArgs& a, int B) { return fastm::solve_workspace_rows(a, B); }
+hipError_t launch_solve_coop_fast(const KArgs& a, int B, hipStream_t st) { return fastm::launch_solve_coop(a, B, st); }
+hipError_t launch_solve_spec_fast(const KArgs& a, int B, hipStream_t st) { return fastm::launch_solve_spec(a, B, st); }
 #else
 }  // namespace exact
 static thread_local const void* g_last_kernel_fn = nullptr;

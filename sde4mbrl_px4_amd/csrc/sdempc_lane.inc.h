@@ -113,6 +113,7 @@ DI float sel_f(float a, float b, unsigned m) {      // m all ones: a, zero: b   
 struct LaneSel { unsigned q1, q2; };                // all ones where lane & 1 / lane & 2
 DI LaneSel lane_sel(int lane) { LaneSel s; s.q1 = (lane & 1) ? ~0u : 0u; s.q2 = (lane & 2) ? ~0u : 0u; return s; }
 DI float lane_tanh(float av, const LaneSel& ls) {
+    if constexpr (FAST) return FMA(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(av * 2.885390043258667f)), 1.0f);      // SPEC.md §10, as tanh16_hw
     const float d = 1.0f + exp2_spec(clampf(av, -9.0f, 9.0f), 2.885390043258667f);
     const float d0 = dppq_f<0x00>(d), d1 = dppq_f<0x55>(d), d2 = dppq_f<0xAA>(d), d3 = dppq_f<0xFF>(d);
     const float p2 = d0 * d1, p3 = p2 * d2, p4 = p3 * d3;

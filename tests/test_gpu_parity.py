@@ -529,9 +529,10 @@ def test_solve_with_keys_equals_solve_with_oracle_noise():
 
 
 # ---- math_mode: fast (SPEC.md §10): hardware transcendentals, checked bit for bit through the model of the three instructions (§10a) ------
-@pytest.mark.parametrize("mlp", ["f32", "f16", "f32x3"])
-def test_fast_math_mode_matches_oracle_bit_for_bit(mlp):
-    cfg = MPCConfig(horizon=24, num_short_dt=24, num_particles=70, u_slew_coeff=1.0, max_iter=8, max_no_improvement_iter=8, mlp_dtype=mlp, math_mode="fast")
+@pytest.mark.parametrize("mlp,P", [("f32", 70), ("f16", 70), ("f32x3", 70), ("f32", 1), ("f32", 33)])
+def test_fast_math_mode_matches_oracle_bit_for_bit(mlp, P, layout):
+    """(f32 contractions: the `layout` fixture also takes the mode through the lane layouts — single-particle lanes, speculative and plain cooperative kernels)"""
+    cfg = MPCConfig(horizon=24 if P == 70 else 9, num_short_dt=9, long_step_dt=0.1, num_particles=P, u_slew_coeff=1.0, max_iter=8, max_no_improvement_iter=8, mlp_dtype=mlp, math_mode="fast")
     model = synthetic_iris()
     B = 4
     x0, xref, noise, u = _problem(cfg, B, 11)
@@ -780,6 +781,28 @@ def test_c2_full_size_fast_math_mode_in_the_duo_layout_bit_exact():
         for b, (uo, xe, io) in res:
             assert bits_differ(uopt[b], uo) == 0 and bits_differ(xevol[b], xe) == 0 and bits_differ(info[b], io) == 0, (mlp, b)
             assert np.abs(uopt[b] - 0.71).max() > 1e-4                              # the iterations moved the controls
+
+
+@pytest.mark.parametrize("mlp", ["f16", "f32x3"])
+def test_c5_full_length_solve_matches_the_committed_oracle_result(mlp):
+    """BASELINE config 5 end to end in its own mode (`mlp_dtype: f16`; and in f32x3): ONE full-length solve — H = 200, P = 1024, 200 iterations, ~400
+    line-search rollouts — against what the CPU oracle computed for the same instance (tests/golden/make_c5_fullsize.py: 10 - 30 minutes on one core,
+    hence committed rather than recomputed), bit for bit: uopt, xevol, the eight telemetry words."""
+    import importlib.util
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"c5_fullsize_{mlp}.npz")
+    if not os.path.exists(f):
+        pytest.skip(f"{os.path.basename(f)} not generated yet (python tests/golden/make_c5_fullsize.py {mlp})")
+    spec = importlib.util.spec_from_file_location("make_c5_fullsize", os.path.join(os.path.dirname(f), "make_c5_fullsize.py"))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    g = np.load(f)
+    cfg, x0, xref, key = mk.problem(mlp)
+    S = _solver(cfg, synthetic_iris(), 1)
+    yk, i0 = S.reset()
+    assert bits_differ(yk, g["u0"]) == 0 and np.float32(i0["stepsize"]) == g["stepsize"]
+    uopt, xevol, info = S.solve_keys(x0, xref, key, yk[None], np.array([i0["stepsize"]], np.float32))
+    assert info[0, 2] == 200 and info[0, 7] > 300
+    assert bits_differ(uopt[0], g["uopt"]) == 0 and bits_differ(xevol[0], g["xevol"]) == 0 and bits_differ(info[0], g["info"]) == 0
+    S.close()
 
 
 def test_ticketed_persistent_launch_matches_striped_launches_bit_for_bit():

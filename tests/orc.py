@@ -130,7 +130,16 @@ TRANSC_BIN = os.path.join(tempfile.gettempdir(), f"sdempc_oracle_{os.getuid()}",
 TRANSC_BLOCKS = ["rcp_s0_e127", "rsq_s0_e127", "rsq_s0_e128"] + [f"exp_s{s}_e{e}" for e in range(97, 128) for s in (0, 1)]
 
 
+import threading
+_TRANSC_LOCK = threading.Lock()
+
+
 def transc_tables(L=None):
+    with _TRANSC_LOCK:          # (bench.py's verifier threads all arrive here at once)
+        return _transc_tables(L)
+
+
+def _transc_tables(L=None):
     """Maps the recorded answers of v_exp_f32 / v_rcp_f32 / v_rsq_f32 into the oracle (oracle/transc_model.c, SPEC.md §10a). The committed form is
     tests/golden/transc/<block>.i8.xz (2^23 differences of -1 / 0 / +1 ulp per block, 1.9 MB in all); the model reads them two bits per answer
     from one file (65 blocks x 2 MiB), written here on first use and whenever a committed block is newer."""
@@ -142,7 +151,8 @@ def transc_tables(L=None):
     stale = (not os.path.exists(TRANSC_BIN)) or os.path.getsize(TRANSC_BIN) != len(src) << 21 or any(os.path.getmtime(f) > os.path.getmtime(TRANSC_BIN) for f in src)
     if stale:
         os.makedirs(os.path.dirname(TRANSC_BIN), exist_ok=True)
-        tmp = TRANSC_BIN + f".{os.getpid()}.tmp"
+        import uuid
+        tmp = TRANSC_BIN + f".{os.getpid()}.{uuid.uuid4().hex}.tmp"       # (other PROCESSES may be writing their own copy: the rename is atomic, the contents identical)
         with open(tmp, "wb") as out:
             for f in src:
                 d = np.frombuffer(lzma.decompress(open(f, "rb").read()), dtype=np.int8)

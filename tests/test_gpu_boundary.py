@@ -149,7 +149,8 @@ def test_bench_two_ranks_self_started_on_one_gpu():
     assert rec["cpu_baseline"].startswith("skipped")                      # stated, not silently absent, in N > 1 lines
     assert "over_gpus" in rec["power"]                                    # rank 0 samples every GPU of the job; the spread is reported (None: region too short for a sample)
     c4 = rec["c4_one_instance_per_gpu"]                                   # BASELINE config 4: one instance per rank, barrier-aligned ticks
-    assert c4["instances"] == 2 and c4["ticks"] == 6 and c4["p50_tick_ms"] > 0 and c4["value"] > 0
+    # (the two ranks share ONE GPU here: their cooperative grids cannot be co-resident, a tick whose barrier gave up is dropped, not timed)
+    assert c4["instances"] == 2 and c4["ticks"] + c4["ticks_dropped"] == 6 and c4["ticks"] >= 1 and c4["p50_tick_ms"] > 0 and c4["value"] > 0
 
 
 def test_bench_rccl_branch_on_one_gpu():

@@ -8,10 +8,10 @@ import numpy as np, torch
 from sde4mbrl_px4_amd import load_mpc_config, synthetic_iris, synthetic_hexa, prng
 from sde4mbrl_px4_amd import workload as W
 from sde4mbrl_px4_amd.solver import SdeMpcSolver
-ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=7); ap.add_argument("--batches", default="1"); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--reps", type=int, default=7); ap.add_argument("--batches", default="1"); ap.add_argument("--math-mode", default="exact", choices=["exact", "fast"]); a = ap.parse_args()
 torch.cuda.init()
 for name in ("iris_traj_shipped_h20_p1", "c1_iris_posctrl_h20_p32", "c2_iris_traj_h50_p128", "c3_hexa_traj_h50_p256"):
-    cfg = load_mpc_config(os.path.join(ROOT, "configs", name + ".yaml"))
+    cfg = load_mpc_config(os.path.join(ROOT, "configs", name + ".yaml")).replace(math_mode=a.math_mode)
     H, P, m = cfg.horizon, cfg.num_particles, cfg.num_motors
     for B in [int(b) for b in a.batches.split(",")]:
         S = SdeMpcSolver(cfg, synthetic_iris() if m == 4 else synthetic_hexa(), max_batch=B)

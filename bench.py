@@ -365,7 +365,7 @@ def main():
             # reported baseline: the particle-vectorised build (f32 fma-chain arithmetic), one solve at a time per thread on every usable core, on
             # 40 instances per thread of the same workload (first instances of the GPU batch; ~10 s of wall time)
             n_cpu = min(40 * nthr, B)
-            cfg32 = cfg.replace(mlp_dtype="f32")
+            cfg32 = cfg.replace(mlp_dtype="f32", math_mode="exact")      # (the timing build has the f32 fma chains and the software activations of SPEC.md 3 only)
             v, dt, outs_f = cpu_solve_instances(cfg32, blob, nthr, L.x0_h[:n_cpu], L.xref_h[:n_cpu], L.keys[:n_cpu], L.u0_h[:n_cpu], L.s0, fast=True)
             devs = np.array([float(np.max(np.abs(outs_f[i][0] - uopt_h[i]))) for i in range(n_cpu)])
             md, mmed = float(devs.max()), float(np.median(devs))
@@ -376,7 +376,7 @@ def main():
                                    "sample": f"{n_cpu} solves of the same workload (the first {n_cpu} instances of the GPU batch, one solve at a time per thread, "
                                              f"{nthr} threads = usable host cores: os.cpu_count {os.cpu_count()}, cgroup/affinity limit {effective_cores()}; {dt:.1f} s wall) "
                                              "by the particle-vectorised build of the C oracle (oracle/sde_mpc_oracle.c -DORC_VEC: 16 particles per call, -O3 -march=native, "
-                                             "contraction allowed, f32 fma-chain contractions; CPU restatement of SPEC.md, not the reference JAX path: that cannot run here); "
+                                             "contraction allowed, f32 fma-chain contractions, software activations of SPEC.md 3; CPU restatement of SPEC.md, not the reference JAX path: that cannot run here); "
                                              f"|uopt - GPU uopt| over the sample (200-iteration solves; timing build, not the checker): median {mmed:.1e}, max {md:.1e}",
                                    "value_bit_exact_build": (rmain["done"] / rmain["cpu_s"] * 1.0) if rmain and rmain["cpu_s"] > 0 else None,
                                    "value_bit_exact_build_note": "solves per second PER THREAD of the bit-exact checker in the arithmetic of this run (the matrix-instruction model is integer code)",

@@ -188,8 +188,8 @@ class Oracle:
         self._blobbuf = C.create_string_buffer(self.blob, len(self.blob))
         self.pre = "orcv_" if vec else ("orcd_" if double else "orc_")
         self._lib = lib_vec() if vec else (lib_fast() if fast else lib())
-        if getattr(mpc_cfg, "math_mode", "exact") == "fast":
-            transc_tables(self._lib)          # (the float64 and the timing builds refuse math_mode fast)
+        if getattr(mpc_cfg, "math_mode", "exact") == "fast" and not vec:
+            transc_tables(self._lib)          # (the float64 and the timing builds refuse math_mode fast: their entry points return SDEMPC_EINVAL)
         self.H, self.P, self.m = mpc_cfg.horizon, mpc_cfg.num_particles, mpc_cfg.num_motors
 
     def _fn(self, name):

@@ -310,7 +310,9 @@ def main():
         nthr = args.cpu_threads or min(effective_cores(), 64)
         V = Verifier(max(1, nthr - 1))
         if args.verify != 0:
-            idx = sample_indices(B, L.slots()) if args.verify < 0 else list(range(min(args.verify, B)))
+            # 24 instances: the teams' first six assignments, seventeen that the tickets hand out across the batch, the last (about 60 s each for the
+            # checker in this arithmetic with the 16-lane group addition of oracle/mfma16_model.c: two rounds on 15 threads beside the GPU legs)
+            idx = sample_indices(B, L.slots(), n_initial=6, n_drawn=17) if args.verify < 0 else list(range(min(args.verify, B)))
             V.add("main", cfg, blob, idx, L.x0_h, L.xref_h, L.keys, L.u0_h, L.s0, (uopt_h, xevol_h, info_h))
             V.start()                          # (after the latency loop, whose host timestamps must not compete with the checker threads; beside every leg below)
             progress(f"CPU verification of {len(idx)} instances of the timed launch started in the background")

@@ -169,6 +169,7 @@ typedef struct {
     orc_op16 h1[2 * HID][16];            /* f16 mode, layer 1: row r, slots 0..5 = W1z[r][k], the rest zero */
     orc_op16 h2[HID][2][16];             /* f16 mode, layer 2: row i, K-half hf */
     int32_t x2m[2][3][HID][2][16], x2x[2][3][HID][2][16];       /* f32x3 mode: significands / exponents of the bf16 limbs, [0 = W2 rows, 1 = W2^T rows][limb][row][K-half][slot] */
+    int32_t x2mT[2][3][2][16][HID], x2xT[2][3][2][16][HID];     /* the same, row index last: sixteen rows per vector in the 16-lane group addition (mfma16_model.c) */
 #endif
     real inv_mass, grav, J[3], iJ[3], ct2, ct1, ct0, cm2, cm1;
     real rx[MAXM], ry[MAXM], dir[MAXM];
@@ -200,8 +201,12 @@ static void bf16_limbs(float x, uint16_t* lb) {
         x = x - h;
     }
 }
-/* out[i] = c[i] + sum_k W[i][k] v[k] as the twelve instructions of SPEC.md §9b; Wm / Wx: M->x2m[tr], M->x2x[tr] */
-static void x3_contract(const int32_t (*Wm)[HID][2][16], const int32_t (*Wx)[HID][2][16], const float* v, const float* c, float* out) {
+/* out[i] = c[i] + sum_k W[i][k] v[k] as the twelve instructions of SPEC.md §9b; Wm / Wx: M->x2m[tr], M->x2x[tr]; WmT / WxT: the row-last copies
+ * (or NULL: scalar evaluation only). vec: 1 takes the 16-lane form of the group addition where the CPU has it, 0 forces the scalar (normative) one */
+static int x3_scalar_only = 0;
+void NAME(x3_force_scalar)(int on) { x3_scalar_only = on; }
+static void x3_contract(const int32_t (*Wm)[HID][2][16], const int32_t (*Wx)[HID][2][16], const int32_t (*WmT)[2][16][HID], const int32_t (*WxT)[2][16][HID],
+                        const float* v, const float* c, float* out) {
     static const int WA[6] = {2, 1, 1, 0, 0, 0}, VB[6] = {0, 1, 0, 2, 1, 0};
     int32_t vm[3][2][16], vx[3][2][16];
     int special = 0;
@@ -209,6 +214,16 @@ static void x3_contract(const int32_t (*Wm)[HID][2][16], const int32_t (*Wx)[HID
         uint16_t lb[3];
         bf16_limbs(v[slot_unit(hf, k)], lb);
         for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); vm[l][hf][k] = o.m; vx[l][hf][k] = o.ex; special |= o.kind; }
+    }
+    if (!special && WmT && !x3_scalar_only && orc_mfma16_vec_available()) {
+        for (int blk = 0; blk < HID; blk += 16) {
+            float acc[16];
+            for (int l = 0; l < 16; ++l) acc[l] = c ? c[blk + l] : 0.0f;       /* (a non-finite start value stays as it is: the group addition keeps it) */
+            for (int s6 = 0; s6 < 6; ++s6) for (int hf = 0; hf < 2; ++hf) for (int g8 = 0; g8 < 16; g8 += 8)
+                orc_mfma16_group8_bf16_x16(&WmT[WA[s6]][hf][g8][blk], &WxT[WA[s6]][hf][g8][blk], HID, &vm[VB[s6]][hf][g8], &vx[VB[s6]][hf][g8], acc);
+            for (int l = 0; l < 16; ++l) out[blk + l] = acc[l];
+        }
+        return;
     }
     for (int i = 0; i < HID; ++i) {
         float acc = c ? c[i] : 0.0f;
@@ -229,13 +244,13 @@ static void x3_contract(const int32_t (*Wm)[HID][2][16], const int32_t (*Wx)[HID
  * f32 fma chain of SPEC.md §4 (mode 0) or as the twelve instructions of §9b (mode 2) — the two arithmetics of layer 2, without a model around them */
 void NAME(contract32)(int mode, const float* W, const float* v, const float* c, float* out) {
     if (mode == 2) {
-        static int32_t Wm[3][HID][2][16], Wx[3][HID][2][16];
+        static int32_t Wm[3][HID][2][16], Wx[3][HID][2][16], WmT[3][2][16][HID], WxT[3][2][16][HID];
         for (int i = 0; i < HID; ++i) for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k) {
             uint16_t lb[3];
             bf16_limbs(W[i * HID + slot_unit(hf, k)], lb);
-            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); Wm[l][i][hf][k] = o.m; Wx[l][i][hf][k] = o.ex; }
+            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); Wm[l][i][hf][k] = WmT[l][hf][k][i] = o.m; Wx[l][i][hf][k] = WxT[l][hf][k][i] = o.ex; }
         }
-        x3_contract(Wm, Wx, v, c, out);
+        x3_contract(Wm, Wx, WmT, WxT, v, c, out);
         return;
     }
     for (int i = 0; i < HID; ++i) {
@@ -318,7 +333,7 @@ static int parse_blob(const void* blob, model_t* M, int f16) {
             const int un = slot_unit(hf, k);
             uint16_t lb[3];
             bf16_limbs(tr ? M->W2[un][i] : M->W2[i][un], lb);
-            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); M->x2m[tr][l][i][hf][k] = o.m; M->x2x[tr][l][i][hf][k] = o.ex; }
+            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); M->x2m[tr][l][i][hf][k] = M->x2mT[tr][l][hf][k][i] = o.m; M->x2x[tr][l][i][hf][k] = M->x2xT[tr][l][hf][k][i] = o.ex; }
         }
     }
 #endif
@@ -443,7 +458,7 @@ static void step_fwd(const model_t* M, const ustep_t* U, const preal* x, const p
             pre_2[i] = acc;
         }
     } else if (M->f16 == 2) {
-        x3_contract(M->x2m[0], M->x2x[0], A->h1d, M->b2, pre_2);
+        x3_contract(M->x2m[0], M->x2x[0], M->x2mT[0], M->x2xT[0], A->h1d, M->b2, pre_2);
     } else
 #endif
     for (int i = 0; i < HID; ++i) {
@@ -593,7 +608,7 @@ static void step_vjp(const model_t* M, const preal* x, const preal* xi, real dt,
     }
 #ifdef ORC_MFMA16
     float hb_x3[HID];
-    if (M->f16 == 2) x3_contract(M->x2m[1], M->x2x[1], a2b, NULL, hb_x3);       /* SPEC.md §9b: W2^T abar2 as the three-limb split */
+    if (M->f16 == 2) x3_contract(M->x2m[1], M->x2x[1], M->x2mT[1], M->x2xT[1], a2b, NULL, hb_x3);       /* SPEC.md §9b: W2^T abar2 as the three-limb split */
 #endif
     for (int k = 0; k < HID; ++k) {
         preal hb = pbroadcast(R(0));

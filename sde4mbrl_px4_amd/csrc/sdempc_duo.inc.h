@@ -62,6 +62,17 @@ DI void duo_reform_rotation(const float* x, float* Rm) {
     rot_from_q(xq, Rm);
 }
 
+// TIMING-ONLY diagnostic (tools/build_variant.sh ckl2 "-DSDEMPC_VAR_CKPT_CACHED=1"; results are WRONG): every step's layer-2 activation rows alias the rows of
+// step 0, so the checkpoint stream of the gradient evaluations stays in the caches instead of crossing HBM twice — the upper bound of what removing the
+// stream (recomputing layer 2 in the adjoint) could buy at the power cap, before the recompute is paid for (profiles/r4_ab.txt).
+#ifndef SDEMPC_VAR_CKPT_CACHED
+#define SDEMPC_VAR_CKPT_CACHED 0
+#endif
+#if SDEMPC_VAR_CKPT_CACHED
+#define CKPT_T(t) 0
+#else
+#define CKPT_T(t) (t)
+#endif
 // One Euler-Maruyama step for the wave's 64 particles. CKPT: stream the second hidden layer of both passes to the groups' checkpoint
 // rows (acA / acB: this step's rows of group A / group B).
 // Issue priority, rotated among the waves of a SIMD. The arbiter serves the higher s_setprio first and, among equals, the OLDER wave slot:
@@ -325,7 +336,7 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
                     for (int i = 0; i < NN; ++i) xin[i] = nzb[nzo + (unsigned)(((t + 1) * NN + i) * 32)];
                 }
             }
-            duo_step_fwd<F16, true, NZS>(a, sm, ww, t, h, lane, pr.hasB, x, xi, xn, A, acA + (size_t)t * ACT_STRIDE, acB + (size_t)t * ACT_STRIDE);
+            duo_step_fwd<F16, true, NZS>(a, sm, ww, t, h, lane, pr.hasB, x, xi, xn, A, acA + (size_t)CKPT_T(t) * ACT_STRIDE, acB + (size_t)CKPT_T(t) * ACT_STRIDE);
             if constexpr (NZS) { if (t + 1 < H) duo_noise_request(nzb, nzo, t + 1, sm.nzs); }   // before this step's scalar / trajectory stores: older than they are
             if (pr.own) {
                 const unsigned so = aso + (unsigned)(t * ACT_STRIDE);
@@ -362,8 +373,8 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             // (the 25 loads below are requested at the top of their own step. A register prefetch a step ahead spills; the LDS staging rows
             // have room for 6 of the 24 dwords. A timing-only build that redirected these loads to cache-resident rows bounds what a perfect
             // prefetch could buy: 12 % of the adjoint sweep, 4 % of the launch.)
-            const float* apA = acA + (size_t)t * ACT_STRIDE;
-            const float* apB = acB + (size_t)t * ACT_STRIDE;
+            const float* apA = acA + (size_t)CKPT_T(t) * ACT_STRIDE;
+            const float* apB = acB + (size_t)CKPT_T(t) * ACT_STRIDE;
             float4 hA[4], hB[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) hA[q] = *reinterpret_cast<const float4*>(apA + (q * 64 + lane) * 4);

@@ -205,3 +205,39 @@ def test_model_keeps_a_non_finite_running_value():
     a[3], b[3] = big, _bf(-1.0); a[12], b[12] = big, _bf(-1.0)
     assert _dot(1, a, b, np.inf) == np.float32(np.inf) and _dot(1, a, b, -np.inf) == np.float32(-np.inf)
     assert _dot(0, z, z, np.inf) == np.float32(np.inf)
+
+
+def test_sixteen_lane_group_addition_equals_the_scalar_statement():
+    """oracle/mfma16_model.c: orc_mfma16_group8_bf16_x16 (sixteen output rows of a contraction per pass, AVX-512 where the CPU has it) against the
+    scalar group addition, which stays the normative statement of SPEC.md §9a — whole §9b contractions on ordinary operands and on the families that
+    reach the rare paths: wide dynamic range, sub-normal results, overflow, exact cancellations, zeros with dominant accumulators; then full solves."""
+    L = orc.lib()
+    L.orc_x3_force_scalar.argtypes = [C.c_int]
+    if not L.orc_mfma16_vec_available():
+        pytest.skip("this CPU has no AVX-512 (F, DQ, VL, BW): the oracle evaluates the scalar statement only")
+    rng = np.random.default_rng(0)
+    gens = [lambda: (rng.standard_normal((32, 32)) / np.sqrt(32), np.tanh(rng.standard_normal(32)), 0.1 * rng.standard_normal(32)),
+            lambda: (rng.standard_normal((32, 32)) * np.exp2(rng.integers(-40, 40, (32, 32))), rng.standard_normal(32) * np.exp2(rng.integers(-40, 40, 32)),
+                     rng.standard_normal(32) * np.exp2(rng.integers(-60, 60, 32))),
+            lambda: (rng.standard_normal((32, 32)) * np.exp2(rng.integers(-70, -50, (32, 32))), rng.standard_normal(32) * np.exp2(rng.integers(-70, -55, 32)),
+                     rng.standard_normal(32) * np.exp2(rng.integers(-140, -100, 32))),
+            lambda: (rng.standard_normal((32, 32)) * np.exp2(60), rng.standard_normal(32) * np.exp2(60), rng.standard_normal(32) * 1e38),
+            lambda: (np.where(rng.random((32, 32)) < 0.7, 0, rng.standard_normal((32, 32))), np.where(rng.random(32) < 0.5, 0, rng.standard_normal(32)),
+                     np.where(rng.random(32) < 0.5, 0.0, rng.standard_normal(32) * np.exp2(rng.integers(-80, 80, 32))))]
+    try:
+        with np.errstate(all="ignore"):
+            for gi, g in enumerate(gens):
+                for _ in range(120):
+                    Wm, v, c = (np.asarray(t, np.float64).astype(np.float32) for t in g())
+                    if gi == 4 and rng.random() < 0.3:
+                        Wm[:, ::2] = -Wm[:, 1::2]; v[::2] = v[1::2]
+                    L.orc_x3_force_scalar(1); a = _contract(2, Wm, v, c)
+                    L.orc_x3_force_scalar(0); b = _contract(2, Wm, v, c)
+                    assert np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(a)]) and np.array_equal(np.isnan(a), np.isnan(b)), gi
+        cfg, x0, xref, noise, u = _small("f32x3", H=12, P=48)
+        O = orc.Oracle(cfg, synthetic_iris())
+        L.orc_x3_force_scalar(1); s1 = O.solve(x0, xref, noise, u, 0.01)
+        L.orc_x3_force_scalar(0); s2 = O.solve(x0, xref, noise, u, 0.01)
+        assert all(np.array_equal(np.asarray(p).view(np.uint32), np.asarray(q).view(np.uint32)) for p, q in zip(s1[:3], s2[:3]))
+    finally:
+        L.orc_x3_force_scalar(0)

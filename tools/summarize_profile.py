@@ -14,6 +14,7 @@ ap.add_argument("--batch", type=int, default=2048)
 ap.add_argument("--config", default="c2_iris_traj_h50_p128.yaml")
 ap.add_argument("--mfma-per-eval", type=float, default=0.0, help="f32 MFMAs of one forward sweep of one instance (C2: 2 pairs x 50 steps x 44 = 4400); enables the SQ sum check")
 ap.add_argument("--mlp-dtype", default="f32x3", help="arithmetic of the profiled launches (key of profiles/pmc_traffic.json)")
+ap.add_argument("--math-mode", default="fast", help="math mode of the profiled launches (key of profiles/pmc_traffic.json)")
 ap.add_argument("--sq-batch", type=int, default=0, help="batch of the SQ_* / GRBM passes (pmc_3, pmc_4) when it differs from --batch (tools/profile_round.sh)")
 a = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,8 +62,14 @@ if "FETCH_SIZE" in solve and "WRITE_SIZE" in solve:
     sha = os.path.join(a.src, "lib_sha.txt")          # written by tools/profile_round.sh on the GPU box: sha256 of the library the counters were taken on
     build = open(sha).read().split()[0][:16] if os.path.exists(sha) else None
     res["library_build"] = build
-    rec[f"{a.config}:B{a.batch}:{a.mlp_dtype}"] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "source": f"profiles/{a.tag}_pmc.json",
-                                                  "traffic_build": build}
+    key = f"{a.config}:B{a.batch}:{a.mlp_dtype}:{a.math_mode}"
+    rec[key] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "source": f"profiles/{a.tag}_pmc.json", "traffic_build": build}
+    if "GRBM_GUI_ACTIVE" in solve and "SQ_INSTS_VALU" in solve:       # what binds the kernel, for bench.py's roofline.valu_issue (same build gate as the traffic)
+        cyc = solve["GRBM_GUI_ACTIVE"] / 8.0
+        rec[key]["valu_issue"] = {"insts_per_simd": solve["SQ_INSTS_VALU"] / 1024, "cycles": cyc, "frac_at_best_issue": solve["SQ_INSTS_VALU"] / 1024 * 2.8 / cyc,
+                                  "best_issue_cycles_per_inst": 2.8, "mfma_busy_frac": solve.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / cyc,
+                                  "instances_per_launch": a.sq_batch or a.batch,
+                                  "source": f"profiles/{a.tag}_pmc.json: SQ_INSTS_VALU / 1024 SIMDs, GRBM_GUI_ACTIVE / 8 XCDs; 2.8 cycles per wave-instruction is the best a SIMD issues with three waves (tools/valu_probe.hip)"}
     json.dump(rec, open(tf, "w"), indent=1)
 if cal_r:
     res["calibration"] = {"rollout_kernel_FETCH_SIZE_KiB": cal_r.get("FETCH_SIZE"), "rollout_kernel_WRITE_SIZE_KiB": cal_r.get("WRITE_SIZE"),

@@ -15,6 +15,7 @@ LAYOUTS = [("auto", {}), ("coop", {"spec": 0}), ("coop-rt", {"coop_launch": 1}),
            ("tile-pk", {"coop": 0, "pk": 1}), ("tile", {"coop": 0, "pk": 0}), ("tile-duo", {"coop": 0, "pk": 0, "duo": 1}), ("tile-gtab", {"coop": 0, "pk": 0, "ustg": 1, "duo": 1}),
            ("tile-nolane", {"coop": 0, "lane": 0, "pk": 0}), ("tile-noduo", {"coop": 0, "pk": 0, "duo": 0}), ("tile-noduo-gtab", {"coop": 0, "pk": 0, "duo": 0, "ustg": 1})]
 MLPS = (sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32", "f32", "f16", "f32x3", "f32x3"])     # contraction modes to draw from (SPEC.md 9, 9b): all bit-exact
+FAST_SHARE = float(sys.argv[4]) if len(sys.argv) > 4 else 0.4
 used = {}
 for it in range(n):
     rng = np.random.default_rng(seed0 + it)
@@ -33,10 +34,12 @@ for it in range(n):
         ids = sorted(int(i) for i in rng.choice(13, size=int(rng.integers(1, 7)), replace=False))
         kw.update(state_id=ids, state_penalty=[float(rng.uniform(0.1, 30)) for _ in ids], constr_pen=float(rng.choice([1.0, 0.1])),
                   state_bound=[[-float(rng.uniform(0.05, 1.0)), float(rng.uniform(0.05, 1.0))] for _ in ids])
+    if FAST_SHARE and rng.random() < FAST_SHARE: kw.update(math_mode="fast")          # SPEC.md 10: the hardware-instruction arithmetic, checked against oracle/transc_model.c
     cfg = MPCConfig(**kw); model = synthetic_multirotor(m, seed=it)
     lname, lopts = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
     if cfg.mlp_dtype != "f32":
         lname += "/" + cfg.mlp_dtype          # (the lane / cooperative layouts and the packed-tanh instantiation exist for the f32 chain: the library falls back to tiles by itself)
+    if cfg.math_mode != "exact": lname += "/" + cfg.math_mode
     used[lname] = used.get(lname, 0) + 1
     B = int(rng.integers(1, 6))
     x0 = W.random_initial_states(B, 1000 + it); xref = np.stack([W.reference_window(0.2 * b, cfg.time_steps) for b in range(B)]); noise = W.make_noise(B, P, H, it)

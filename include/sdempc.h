@@ -96,8 +96,9 @@ typedef struct sdempc_cfg {
     int32_t mlp_dtype;
     /* extension (not a reference YAML key): 0 = exact (default): tanh / sigmoid / reciprocal square root in the bit-reproducible
      * software forms of SPEC.md §3, results identical to the CPU oracle bit for bit. 1 = fast: the same kernels with the
-     * hardware transcendentals (v_exp_f32, v_rcp_f32, v_rsq_f32); about 1e-7 relative per operation away from the exact path,
-     * deterministic on a given GPU, not reproducible on a CPU. SPEC.md §10. */
+     * hardware transcendentals (v_exp_f32, v_rcp_f32, v_rsq_f32) and the hidden activation kept as 1 / (1 + 2^a') with its affine maps folded into the
+     * weights by sdempc_create (SPEC.md §10, §10b); about 1e-7 relative per operation away from the exact path, and — through the oracle's model of the three
+     * instructions (SPEC.md §10a) — compared with the CPU oracle bit for bit as well. */
     int32_t math_mode;
     /* state_constr (launch/iris_sitl_traj_mpc.yaml:16-29; commented out in every YAML the reference ships), penalty form
      * (slack_proximal: False): stage cost += sum_k state_w[k] * (max(0, x[id_k] - hi_k)^2 + max(0, lo_k - x[id_k])^2) at x_{t+1},

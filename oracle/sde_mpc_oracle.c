@@ -174,7 +174,8 @@ typedef struct {
     real inv_mass, grav, J[3], iJ[3], ct2, ct1, ct0, cm2, cm1;
     real rx[MAXM], ry[MAXM], dir[MAXM];
     real sF[3], sT[3], sigma[NN];
-    real W1z[2 * HID][NN], b1[2 * HID], W1u[HID][MAXM], W2[HID][HID], b2[HID], W3[6][HID], b3[6], w3n[HID], b3n;
+    real W1z[2 * HID][NN], b1[2 * HID], W1u[HID][MAXM], W2[HID][HID], b2[HID], W3[6][HID], b3[6], w3n[HID], b3n;     /* what the forward pass uses */
+    real vW1z[2 * HID][NN], vW1u[HID][MAXM], vW2[HID][HID], vW3[6][HID], vw3n[HID];   /* what the vector-Jacobian products use: the same values, except in math_mode fast (SPEC.md §10b) */
 } model_t;
 
 static real f16_rtz(real xv);
@@ -261,11 +262,13 @@ void NAME(contract32)(int mode, const float* W, const float* v, const float* c, 
 }
 #endif
 
+/* derivative of the activation from what the forward pass keeps: h = tanh: 1 - h^2; math_mode fast keeps r (tanh = 1 - 2 r): r - r^2, its factor 4 is in the transposed weights */
+#define DACT(M, h) ((M)->fast ? PFMA(-(h), (h), (h)) : PFMA(-(h), (h), R(1)))
 /* activations of a step: SPEC.md §3 (default) or, in math_mode fast, §10 on the modelled instructions (float32 checker build only) */
 static inline void act_tanh4(const model_t* M, const preal* x, preal* y) {
 #ifdef ORC_MFMA16
     if (M->fast) {
-        for (int i = 0; i < 4; ++i) y[i] = fmaf(-2.0f, orc_hw_rcp(1.0f + orc_hw_exp2(x[i] * 2.885390043258667f)), 1.0f);
+        for (int i = 0; i < 4; ++i) y[i] = orc_hw_rcp(1.0f + orc_hw_exp2(x[i]));       /* SPEC.md §10b: r, with tanh = 1 - 2 r folded into the weights */
         return;
     }
 #endif
@@ -284,7 +287,7 @@ static inline preal act_rsqrt(const model_t* M, preal a) {
     return NAME(rsqrt)(a);
 }
 
-static int parse_blob(const void* blob, model_t* M, int f16) {
+static int parse_blob(const void* blob, model_t* M, int f16, int fast) {
     const int32_t* hd = (const int32_t*)blob;
     if (hd[0] != SDEMPC_BLOB_MAGIC || hd[1] != 1) return -1;
     M->m = hd[2];
@@ -322,7 +325,43 @@ static int parse_blob(const void* blob, model_t* M, int f16) {
         for (int r = 0; r < 2 * HID; ++r) for (int k = 0; k < NN; ++k) M->W1z[r][k] = f16_rtz(M->W1z[r][k]);
         for (int r = 0; r < HID; ++r) for (int k = 0; k < HID; ++k) M->W2[r][k] = f16_rtz(M->W2[r][k]);
     }
+    memcpy(M->vW1z, M->W1z, sizeof M->W1z); memcpy(M->vW1u, M->W1u, sizeof M->W1u); memcpy(M->vW2, M->W2, sizeof M->W2);
+    memcpy(M->vW3, M->W3, sizeof M->W3); memcpy(M->vw3n, M->w3n, sizeof M->w3n);
+    M->fast = 0;
 #ifdef ORC_MFMA16
+    if (fast) {
+        /* SPEC.md §10b (the same float32 statements as sdempc_create's): the hardware tanh is kept as r = rcp(1 + exp2(a')), a' = (2 log2 e) a, tanh = 1 - 2 r.
+         * Weights and biases that feed a tanh take the pre-scale (one rounding each); those that consume one take the affine map (factor -2 exact, biases by
+         * sequential sums); 1 - tanh^2 = 4 (r - r^2) leaves its 4 in the transposed weights. */
+        const float c = 2.885390043258667f;
+        M->fast = 1;
+        for (int r = 0; r < 2 * HID; ++r) for (int k = 0; k < NN; ++k) { float w = c * M->vW1z[r][k]; M->W1z[r][k] = f16 == 1 ? f16_rtz(w) : w; }
+        for (int r = 0; r < 2 * HID; ++r) M->b1[r] = c * M->b1[r];
+        for (int r = 0; r < HID; ++r) for (int j = 0; j < MAXM; ++j) M->W1u[r][j] = c * M->vW1u[r][j];
+        for (int j = 0; j < HID; ++j) {
+            float sum = c * M->b2[j];
+            for (int k = 0; k < HID; ++k) {
+                float w = c * M->vW2[j][k];
+                if (f16 == 1) w = f16_rtz(w);
+                sum = sum + w;
+                M->W2[j][k] = -2.0f * w;
+            }
+            M->b2[j] = sum;
+        }
+        for (int i = 0; i < 6; ++i) {
+            float sum = M->b3[i];
+            for (int k = 0; k < HID; ++k) { sum = sum + M->vW3[i][k]; M->W3[i][k] = -2.0f * M->vW3[i][k]; }
+            M->b3[i] = sum;
+        }
+        {
+            float sum = M->b3n;
+            for (int k = 0; k < HID; ++k) { sum = sum + M->vw3n[k]; M->w3n[k] = -2.0f * M->vw3n[k]; }
+            M->b3n = sum;
+        }
+        for (int j = 0; j < HID; ++j) for (int k = 0; k < HID; ++k) M->vW2[j][k] = 4.0f * M->vW2[j][k];
+        for (int i = 0; i < 6; ++i) for (int k = 0; k < HID; ++k) M->vW3[i][k] = 4.0f * M->vW3[i][k];
+        for (int k = 0; k < HID; ++k) M->vw3n[k] = 4.0f * M->vw3n[k];
+    }
     if (f16 == 1) {
         for (int r = 0; r < 2 * HID; ++r) for (int k = 0; k < 16; ++k) orc_mfma16_decode(0, k < NN ? f16_bits(M->W1z[r][k]) : 0, &M->h1[r][k]);
         for (int i = 0; i < HID; ++i) for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k)
@@ -332,7 +371,7 @@ static int parse_blob(const void* blob, model_t* M, int f16) {
         for (int tr = 0; tr < 2; ++tr) for (int i = 0; i < HID; ++i) for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k) {
             const int un = slot_unit(hf, k);
             uint16_t lb[3];
-            bf16_limbs(tr ? M->W2[un][i] : M->W2[i][un], lb);
+            bf16_limbs(tr ? M->vW2[un][i] : M->W2[i][un], lb);
             for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); M->x2m[tr][l][i][hf][k] = M->x2mT[tr][l][hf][k][i] = o.m; M->x2x[tr][l][i][hf][k] = M->x2xT[tr][l][hf][k][i] = o.ex; }
         }
     }
@@ -603,8 +642,8 @@ static void step_vjp(const model_t* M, const preal* x, const preal* xi, real dt,
     preal a2b[HID], a1d[HID], a1n[HID];
     for (int k = 0; k < HID; ++k) {
         preal hb = pbroadcast(R(0));
-        for (int i = 0; i < 6; ++i) hb = PFMA(M->W3[i][k], ob[i], hb);
-        a2b[k] = hb * PFMA(-A->h2[k], A->h2[k], R(1));
+        for (int i = 0; i < 6; ++i) hb = PFMA(M->vW3[i][k], ob[i], hb);
+        a2b[k] = hb * DACT(M, A->h2[k]);
     }
 #ifdef ORC_MFMA16
     float hb_x3[HID];
@@ -615,20 +654,20 @@ static void step_vjp(const model_t* M, const preal* x, const preal* xi, real dt,
 #ifdef ORC_MFMA16
         if (M->f16 == 2) hb = hb_x3[k]; else
 #endif
-        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int i = rowmap(r, h); hb = PFMA(M->W2[i][k], a2b[i], hb); }
-        a1d[k] = hb * PFMA(-A->h1d[k], A->h1d[k], R(1));
-        a1n[k] = (M->w3n[k] * ebraw) * PFMA(-A->h1n[k], A->h1n[k], R(1));
+        for (int r = 0; r < 16; ++r) for (int h = 0; h < 2; ++h) { int i = rowmap(r, h); hb = PFMA(M->vW2[i][k], a2b[i], hb); }
+        a1d[k] = hb * DACT(M, A->h1d[k]);
+        a1n[k] = (M->vw3n[k] * ebraw) * DACT(M, A->h1n[k]);
     }
     preal zb[NN];
     for (int k = 0; k < NN; ++k) {
         preal P0 = pbroadcast(R(0)), P1 = pbroadcast(R(0));
-        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->W1z[HID + rowmap(r, 0)][k], a1n[rowmap(r, 0)], P0); P1 = PFMA(M->W1z[HID + rowmap(r, 1)][k], a1n[rowmap(r, 1)], P1); }
-        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->W1z[rowmap(r, 0)][k], a1d[rowmap(r, 0)], P0); P1 = PFMA(M->W1z[rowmap(r, 1)][k], a1d[rowmap(r, 1)], P1); }
+        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->vW1z[HID + rowmap(r, 0)][k], a1n[rowmap(r, 0)], P0); P1 = PFMA(M->vW1z[HID + rowmap(r, 1)][k], a1n[rowmap(r, 1)], P1); }
+        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->vW1z[rowmap(r, 0)][k], a1d[rowmap(r, 0)], P0); P1 = PFMA(M->vW1z[rowmap(r, 1)][k], a1d[rowmap(r, 1)], P1); }
         zb[k] = P0 + P1;
     }
     for (int j = 0; j < M->m; ++j) {
         preal P0 = pbroadcast(R(0)), P1 = pbroadcast(R(0));
-        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->W1u[rowmap(r, 0)][j], a1d[rowmap(r, 0)], P0); P1 = PFMA(M->W1u[rowmap(r, 1)][j], a1d[rowmap(r, 1)], P1); }
+        for (int r = 0; r < 16; ++r) { P0 = PFMA(M->vW1u[rowmap(r, 0)][j], a1d[rowmap(r, 0)], P0); P1 = PFMA(M->vW1u[rowmap(r, 1)][j], a1d[rowmap(r, 1)], P1); }
         gu[j] = P0 + P1;
     }
     for (int i = 0; i < 3; ++i) omb[i] = omb[i] + zb[3 + i];
@@ -740,12 +779,10 @@ static int ctx_init(ctx_t* X, const sdempc_cfg* C, const void* blob) {
 #ifdef ORC_VEC
     if (C->mlp_dtype != 0) return SDEMPC_EINVAL;   /* the timing build has the f32 arithmetic only */
 #endif
-    if (parse_blob(blob, &X->M, C->mlp_dtype)) return SDEMPC_EBLOB;
-    X->M.fast = 0;
+    if (parse_blob(blob, &X->M, C->mlp_dtype, C->math_mode != 0)) return SDEMPC_EBLOB;
     if (C->math_mode) {
 #ifdef ORC_MFMA16
         if (!orc_transc_ready()) return SDEMPC_EINVAL;      /* tests/orc.py maps the instruction tables (orc_transc_open) before a fast-mode oracle is made */
-        X->M.fast = 1;
 #else
         return SDEMPC_EINVAL;                               /* the float64 and the timing builds have the SPEC §3 functions only */
 #endif

@@ -410,6 +410,43 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
         for (int i = 0; i < 64 * 6; ++i) h->blob_f[56 + i] = f16_rtz_host(h->blob_f[56 + i]);
         for (int i = 0; i < 32 * 32; ++i) h->blob_f[760 + i] = f16_rtz_host(h->blob_f[760 + i]);
     }
+    if (cfg->math_mode == 1) {
+        // SPEC.md §10b: the hardware tanh is evaluated as r = rcp(1 + exp2(a')), a' = (2 log2 e) a, tanh(a) = 1 - 2 r. The pre-scale goes into the weights
+        // and biases that feed a tanh (one rounding each), the affine map 1 - 2 r into the weights and biases that consume one (exact factors, biases by
+        // sequential sums), and the derivative 1 - tanh^2 = 4 (r - r^2) leaves its factor 4 in the transposed weights (exact). The device blob becomes
+        // two blocks of the same layout: [forward weights][weights of the vector-Jacobian products]; float32 host arithmetic, no contraction.
+        const float c = 2.885390043258667f;
+        const std::vector<float> o = h->blob_f;
+        std::vector<float> F = o, V = o;
+        for (int i = 0; i < 64 * 6; ++i) { float w = c * o[56 + i]; F[56 + i] = cfg->mlp_dtype == 1 ? f16_rtz_host(w) : w; }
+        for (int i = 0; i < 64; ++i) F[440 + i] = c * o[440 + i];
+        for (int i = 0; i < 32 * 8; ++i) F[504 + i] = c * o[504 + i];
+        for (int j = 0; j < 32; ++j) {
+            float sum = c * o[1784 + j];
+            for (int k = 0; k < 32; ++k) {
+                float w = c * o[760 + j * 32 + k];
+                if (cfg->mlp_dtype == 1) w = f16_rtz_host(w);
+                sum = sum + w;
+                F[760 + j * 32 + k] = -2.0f * w;
+            }
+            F[1784 + j] = sum;
+        }
+        for (int i = 0; i < 6; ++i) {
+            float sum = o[2072 + i];
+            for (int k = 0; k < 32; ++k) { sum = sum + o[1816 + i * 32 + k]; F[1816 + i * 32 + k] = -2.0f * o[1816 + i * 32 + k]; }
+            F[2072 + i] = sum;
+        }
+        {
+            float sum = o[2112];
+            for (int k = 0; k < 32; ++k) { sum = sum + o[2080 + k]; F[2080 + k] = -2.0f * o[2080 + k]; }
+            F[2112] = sum;
+        }
+        for (int i = 0; i < 32 * 32; ++i) V[760 + i] = 4.0f * o[760 + i];
+        for (int i = 0; i < 6 * 32; ++i) V[1816 + i] = 4.0f * o[1816 + i];
+        for (int k = 0; k < 32; ++k) V[2080 + k] = 4.0f * o[2080 + k];
+        h->blob_f = F;
+        h->blob_f.insert(h->blob_f.end(), V.begin(), V.end());
+    }
     // tables (SPEC.md §5: float32 host arithmetic)
     const float* sigma = f + 48;
     h->h_sdt.resize((size_t)h->H * SDEMPC_NNOISE);
@@ -439,8 +476,8 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     for (int j = 0; j < 8; ++j) { a.M.rx[j] = f[16 + j]; a.M.ry[j] = f[24 + j]; a.M.dir[j] = f[32 + j]; }
     for (int i = 0; i < 3; ++i) { a.M.sF[i] = f[40 + i]; a.M.sT[i] = f[43 + i]; }
     const int off_b3 = 56 + 384 + 64 + 256 + 1024 + 32 + 256;
-    for (int i = 0; i < 6; ++i) a.M.b3[i] = f[off_b3 + i];
-    a.M.b3n = f[off_b3 + 8 + 32];
+    for (int i = 0; i < 6; ++i) a.M.b3[i] = h->blob_f[off_b3 + i];      // (math_mode fast: the forward block's, SPEC.md §10b)
+    a.M.b3n = h->blob_f[off_b3 + 8 + 32];
     for (int i = 0; i < 3; ++i) { a.C.perr[i] = cfg->perr[i]; a.C.verr[i] = cfg->verr[i]; a.C.qerr[i] = cfg->qerr[i]; a.C.werr[i] = cfg->werr[i]; }
     a.C.res_mult = cfg->res_mult; a.C.uerr = cfg->uerr; a.C.slew = cfg->u_slew_coeff; a.C.slew_cc = cfg->u_slew_constr_coeff;
     a.C.has_sc = cfg->has_slew_constr;

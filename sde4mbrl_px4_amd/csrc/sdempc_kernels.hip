@@ -227,6 +227,16 @@ constexpr int OFF_SF = 40;     // sF[3], sT[3]
 constexpr int OFF_W1Z = 56, OFF_B1 = OFF_W1Z + 384, OFF_W1U = OFF_B1 + 64, OFF_W2 = OFF_W1U + 256, OFF_B2 = OFF_W2 + 1024,
               OFF_W3 = OFF_B2 + 32, OFF_B3 = OFF_W3 + 256, OFF_W3N = OFF_B3 + 8, OFF_B3N = OFF_W3N + 32;
 
+// math_mode fast (SPEC.md §10b): the blob is two blocks of this layout — [0]: what the forward pass uses (pre-scale and affine map of the hardware
+// activation folded in), [VJP_BASE]: what the vector-Jacobian products use (W1z, W1u as given; 4 W2, 4 W3, 4 w3n). One block otherwise.
+constexpr int BLOB_FLOATS = OFF_B3N + 8;
+static_assert(BLOB_FLOATS == 2120, "blob layout (include/sdempc.h: SDEMPC_BLOB_FLOATS)");
+constexpr int VJP_BASE = FAST ? BLOB_FLOATS : 0;
+// The LDS images W1zT / W1uT and W3 / w3n serve both directions. They hold the VJP block's layer-1 weights (the forward uses take the pre-scale on the
+// fly: one rounding, as sdempc_create's) and the forward block's output weights -2 W (the adjoint uses take the exact factor -2 on the fly).
+DI float fwd_w1(float w) { return FAST ? TANH_PRESCALE * w : w; }
+DI float vjp_w3(float w) { return FAST ? -2.0f * w : w; }
+
 // MFMA A operands kept in registers for the whole kernel
 struct WaveW {
     float w1d[3], w1n[3];   // f32 mode: layer-1 A operands (3 k-steps per tile)
@@ -248,8 +258,8 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid, int BNT
         sm.b1n[i] = w[OFF_B1 + HID + i];
         sm.b2[i] = w[OFF_B2 + i];
     }
-    for (int i = tid; i < NN * 2 * HID; i += BNT) { int k = i / (2 * HID), r = i % (2 * HID); sm.W1zT[i] = w[OFF_W1Z + r * NN + k]; }
-    for (int i = tid; i < a.m * HID; i += BNT) { int j = i / HID, r = i % HID; sm.W1uT[i] = w[OFF_W1U + r * 8 + j]; }
+    for (int i = tid; i < NN * 2 * HID; i += BNT) { int k = i / (2 * HID), r = i % (2 * HID); sm.W1zT[i] = w[VJP_BASE + OFF_W1Z + r * NN + k]; }
+    for (int i = tid; i < a.m * HID; i += BNT) { int j = i / HID, r = i % HID; sm.W1uT[i] = w[VJP_BASE + OFF_W1U + r * 8 + j]; }
     for (int i = tid; i < a.H; i += BNT) sm.dt[i] = a.dt[i];
     for (int i = tid; i < a.H * NN; i += BNT) sm.sdt[i] = a.sdt[i];
     for (int i = tid; i <= a.H; i += BNT) sm.disc[i] = a.disc[i];
@@ -262,7 +272,7 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid, int BNT
         unsigned short* axt = reinterpret_cast<unsigned short*>(sm.A2xT);
         for (int i = tid; i < 2 * 64 * 8; i += BNT) {
             const int e = i & 7, l = (i >> 3) & 63, hf = i >> 9, jj = l & 31, hh = l >> 5, un = rowmap(8 * hf + e, hh);
-            float wv[2] = {w[OFF_W2 + jj * HID + un], w[OFF_W2 + un * HID + jj]};
+            float wv[2] = {w[OFF_W2 + jj * HID + un], w[VJP_BASE + OFF_W2 + un * HID + jj]};
 #pragma unroll
             for (int tr = 0; tr < 2; ++tr) {
                 unsigned short* dst = tr ? axt : ax;
@@ -280,7 +290,7 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid, int BNT
     for (int i = tid; i < HID * HID; i += BNT) {
         int c = i & 3, l = (i >> 2) & 63, q = i >> 8, jj = l & 31, hh = l >> 5, r = 4 * q + c;
         sm.A2[i] = w[OFF_W2 + jj * HID + rowmap(r, hh)];
-        sm.A2T[i] = w[OFF_W2 + rowmap(r, hh) * HID + jj];
+        sm.A2T[i] = w[VJP_BASE + OFF_W2 + rowmap(r, hh) * HID + jj];
     }
     if (a.f16 == 1) {   // weights are already fp16-representable (quantised on the host): the casts are exact
         _Float16* ah = reinterpret_cast<_Float16*>(sm.A2h);
@@ -411,7 +421,7 @@ DI void block_prepass(const KArgs& a, const Smem& sm, const float* u, int tid) {
     for (int e = tid; e < H * HID; e += Team::NT) {
         int t = e >> 5, r = e & 31;
         float c = sm.b1d[r];
-        for (int j = 0; j < m; ++j) c = FMA(sm.W1uT[j * HID + r], u[t * m + j], c);
+        for (int j = 0; j < m; ++j) c = FMA(fwd_w1(sm.W1uT[j * HID + r]), u[t * m + j], c);
         sm.ust[t * UST + r] = c;
     }
     for (int t = tid; t < H; t += Team::NT) {

@@ -77,10 +77,10 @@ DI void load_lane_weights(const KArgs& a, LaneW& W, int lane) {
     W.c1n = w[OFF_B1 + HID + k];
     W.b2k = w[OFF_B2 + k];
 #pragma unroll
-    for (int i = 0; i < HID; ++i) { W.w2row[i] = w[OFF_W2 + k * HID + i]; W.w2col[i] = w[OFF_W2 + i * HID + k]; }
+    for (int i = 0; i < HID; ++i) { W.w2row[i] = w[OFF_W2 + k * HID + i]; W.w2col[i] = w[VJP_BASE + OFF_W2 + i * HID + k]; }      // (VJP_BASE: math_mode fast keeps the weights of the vector-Jacobian products in a second block, SPEC.md §10b)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) W.w3col[i] = w[OFF_W3 + i * HID + k];
-    W.w3nk = w[OFF_W3N + k];
+    for (int i = 0; i < 6; ++i) W.w3col[i] = w[VJP_BASE + OFF_W3 + i * HID + k];
+    W.w3nk = w[VJP_BASE + OFF_W3N + k];
     const int c = lane & 7, hs = (lane >> 3) & 1;
     const bool row0 = lane < 16, row1 = lane >= 16 && lane < 32;
     W.bo = lane < 6 ? a.M.b3[lane < 6 ? lane : 0] : lane == 6 ? a.M.b3n : 0.0f;
@@ -95,8 +95,8 @@ DI void load_lane_weights(const KArgs& a, LaneW& W, int lane) {
         if (row0 && c == 6) v = w[OFF_W3N + unit];
         W.wo[r] = v;
         float zd = 0.0f, zf = 0.0f;
-        if (row0 && c < 6) { zd = w[OFF_W1Z + (HID + unit) * NN + c]; zf = w[OFF_W1Z + unit * NN + c]; }
-        if (row1 && c < a.m) zf = w[OFF_W1U + unit * 8 + c];
+        if (row0 && c < 6) { zd = w[VJP_BASE + OFF_W1Z + (HID + unit) * NN + c]; zf = w[VJP_BASE + OFF_W1Z + unit * NN + c]; }
+        if (row1 && c < a.m) zf = w[VJP_BASE + OFF_W1U + unit * 8 + c];
         W.wz[r] = zd; W.wz[16 + r] = zf;
     }
 }
@@ -113,7 +113,7 @@ DI float sel_f(float a, float b, unsigned m) {      // m all ones: a, zero: b   
 struct LaneSel { unsigned q1, q2; };                // all ones where lane & 1 / lane & 2
 DI LaneSel lane_sel(int lane) { LaneSel s; s.q1 = (lane & 1) ? ~0u : 0u; s.q2 = (lane & 2) ? ~0u : 0u; return s; }
 DI float lane_tanh(float av, const LaneSel& ls) {
-    if constexpr (FAST) return FMA(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(av * 2.885390043258667f)), 1.0f);      // SPEC.md §10, as tanh16_hw
+    if constexpr (FAST) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(av));      // SPEC.md §10b, as tanh16_hw
     const float d = 1.0f + exp2_spec(clampf(av, -9.0f, 9.0f), 2.885390043258667f);
     const float d0 = dppq_f<0x00>(d), d1 = dppq_f<0x55>(d), d2 = dppq_f<0xAA>(d), d3 = dppq_f<0xFF>(d);
     const float p2 = d0 * d1, p3 = p2 * d2, p4 = p3 * d3;
@@ -168,7 +168,7 @@ DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp&
     float hb = 0.0f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) hb = FMA(W.w3col[i], T.ob[i], hb);
-    const float a2b = hb * FMA(-h2, h2, 1.0f);
+    const float a2b = hb * dact(h2);
     float accB = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; r += 4) {
@@ -180,7 +180,7 @@ DI void lane_vjp_mlp(const LaneW& W, int lane, float h1, float h2, const VjpTmp&
         for (int e = 0; e < 8; ++e) accB = FMA(W.w2col[rowmap(r + (e >> 1), e & 1)], sv[e], accB);
         __builtin_amdgcn_sched_barrier(0);
     }
-    const float g1 = FMA(-h1, h1, 1.0f);
+    const float g1 = dact(h1);
     const float ad = accB * g1;
     const float an = (W.w3nk * T.ebraw) * g1;
     const float Abar = hh ? an : ad;

@@ -91,7 +91,7 @@ DI void lane2_prepass(const KArgs& a, const Smem& sm, const float* u, int tid) {
     for (int e = tid; e < H * HID; e += Team::NT) {
         int t = e >> 5, r = e & 31;
         float c = sm.b1d[r];
-        for (int j = 0; j < m; ++j) c = FMA(sm.W1uT[j * HID + r], u[t * m + j], c);
+        for (int j = 0; j < m; ++j) c = FMA(fwd_w1(sm.W1uT[j * HID + r]), u[t * m + j], c);
         sm.rec[t * REC + r] = c;
     }
     for (int t = tid; t < H; t += Team::NT) {
@@ -135,7 +135,7 @@ DI void image_row(const float* img, int k, float* row) {
 DI void lane2_load_fwd(const KArgs& a, const Smem& sm, L2FwdW& W, int lane) {
     const int k = lane & 31, hh = lane >> 5, row = 32 * hh + k;
 #pragma unroll
-    for (int j = 0; j < NN; ++j) W.w1[j] = sm.W1zT[j * 2 * HID + row];
+    for (int j = 0; j < NN; ++j) W.w1[j] = fwd_w1(sm.W1zT[j * 2 * HID + row]);
     W.c1n = sm.b1n[k];
     W.b2k = sm.b2[k];
     image_row(sm.A2, k, W.w2row);
@@ -158,8 +158,8 @@ DI void lane2_load_adj(const KArgs& a, const Smem& sm, L2AdjW& W, int lane) {
     const int k = lane & 31;
     image_row(sm.A2T, k, W.w2col);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) W.w3col[i] = sm.W3[i * HID + k];
-    W.w3nk = sm.w3n[k];
+    for (int i = 0; i < 6; ++i) W.w3col[i] = vjp_w3(sm.W3[i * HID + k]);
+    W.w3nk = vjp_w3(sm.w3n[k]);
     const int c = lane & 7, hs = (lane >> 3) & 1;
     const bool row0 = lane < 16, row1 = lane >= 16 && lane < 32;
     W.zbase = 4 * hs;
@@ -214,7 +214,7 @@ DI float lane2_vjp_mlp(const L2AdjW& W, int hh, float h1, float h2, const VjpTmp
     float hb = 0.0f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) hb = FMA(W.w3col[i], T.ob[i], hb);
-    const float a2b = hb * FMA(-h2, h2, 1.0f);
+    const float a2b = hb * dact(h2);
     float accB = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; r += 4) {
@@ -226,7 +226,7 @@ DI float lane2_vjp_mlp(const L2AdjW& W, int hh, float h1, float h2, const VjpTmp
         for (int e = 0; e < 8; ++e) accB = FMA(W.w2col[rowmap(r + (e >> 1), e & 1)], sv[e], accB);
         __builtin_amdgcn_sched_barrier(0);
     }
-    const float g1 = FMA(-h1, h1, 1.0f);
+    const float g1 = dact(h1);
     const float ad = accB * g1;
     const float an = (W.w3nk * T.ebraw) * g1;
     const float Abar = hh ? an : ad;

@@ -373,7 +373,12 @@ DI void vjp_head(const KArgs& a, const Smem& sm, int t, const float* x, const fl
 // ---- MLP part in the MFMA tile layout: zb[6] = adjoint of z, gq[0..M-1] = W1u^T abar1 (per particle) ----
 // vjp_mlp_partials leaves the per-half partial chains Pz[6], Pu[M]; vjp_mlp_tiles adds the halves.
 template <int M, int F16 = 0>
-DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, float ebraw, const float* ob, float* Pz, float* Pu) {
+DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, float ebraw_in, const float* ob_in, float* Pz, float* Pu) {
+    // (math_mode fast: sm.W3 / sm.w3n hold the forward pass's -2 W3 / -2 w3n, the adjoint wants 4 W3: the exact factor -2 goes onto the seven output adjoints)
+    float ob[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ob[i] = FAST ? -2.0f * ob_in[i] : ob_in[i];
+    const float ebraw = FAST ? -2.0f * ebraw_in : ebraw_in;
     // MLP VJP. Order chosen to keep few tiles live: density tile first (frees h1n), then the drift
     // tile: abar2 on the VALU, W2^T abar2 by MFMA in the accumulator layout.
     {
@@ -385,10 +390,10 @@ DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, floa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
-            float an0 = (wn4.x * ebraw) * FMA(-A.h1n[4 * q], A.h1n[4 * q], 1.0f);
-            float an1 = (wn4.y * ebraw) * FMA(-A.h1n[4 * q + 1], A.h1n[4 * q + 1], 1.0f);
-            float an2 = (wn4.z * ebraw) * FMA(-A.h1n[4 * q + 2], A.h1n[4 * q + 2], 1.0f);
-            float an3 = (wn4.w * ebraw) * FMA(-A.h1n[4 * q + 3], A.h1n[4 * q + 3], 1.0f);
+            float an0 = (wn4.x * ebraw) * dact(A.h1n[4 * q]);
+            float an1 = (wn4.y * ebraw) * dact(A.h1n[4 * q + 1]);
+            float an2 = (wn4.z * ebraw) * dact(A.h1n[4 * q + 2]);
+            float an3 = (wn4.w * ebraw) * dact(A.h1n[4 * q + 3]);
 #pragma unroll
             for (int k = 0; k < NN; ++k) {
                 float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + HID + 8 * q + 4 * h);
@@ -406,10 +411,10 @@ DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, floa
                 float4 w4 = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
                 hb0 = FMA(w4.x, ob[i], hb0); hb1 = FMA(w4.y, ob[i], hb1); hb2 = FMA(w4.z, ob[i], hb2); hb3 = FMA(w4.w, ob[i], hb3);
             }
-            a2b[4 * q] = hb0 * FMA(-A.h2[4 * q], A.h2[4 * q], 1.0f);
-            a2b[4 * q + 1] = hb1 * FMA(-A.h2[4 * q + 1], A.h2[4 * q + 1], 1.0f);
-            a2b[4 * q + 2] = hb2 * FMA(-A.h2[4 * q + 2], A.h2[4 * q + 2], 1.0f);
-            a2b[4 * q + 3] = hb3 * FMA(-A.h2[4 * q + 3], A.h2[4 * q + 3], 1.0f);
+            a2b[4 * q] = hb0 * dact(A.h2[4 * q]);
+            a2b[4 * q + 1] = hb1 * dact(A.h2[4 * q + 1]);
+            a2b[4 * q + 2] = hb2 * dact(A.h2[4 * q + 2]);
+            a2b[4 * q + 3] = hb3 * dact(A.h2[4 * q + 3]);
             SCHED_PHASE();
         }
         f32x16 accB;
@@ -432,10 +437,10 @@ DI void vjp_mlp_partials(const Smem& sm, int h, int lane, const StepAux& A, floa
         SCHED_PHASE();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float ad0 = accB[4 * q] * FMA(-A.h1d[4 * q], A.h1d[4 * q], 1.0f);
-            float ad1 = accB[4 * q + 1] * FMA(-A.h1d[4 * q + 1], A.h1d[4 * q + 1], 1.0f);
-            float ad2 = accB[4 * q + 2] * FMA(-A.h1d[4 * q + 2], A.h1d[4 * q + 2], 1.0f);
-            float ad3 = accB[4 * q + 3] * FMA(-A.h1d[4 * q + 3], A.h1d[4 * q + 3], 1.0f);
+            float ad0 = accB[4 * q] * dact(A.h1d[4 * q]);
+            float ad1 = accB[4 * q + 1] * dact(A.h1d[4 * q + 1]);
+            float ad2 = accB[4 * q + 2] * dact(A.h1d[4 * q + 2]);
+            float ad3 = accB[4 * q + 3] * dact(A.h1d[4 * q + 3]);
 #pragma unroll
             for (int k = 0; k < NN; ++k) {
                 float4 w4 = *reinterpret_cast<const float4*>(sm.W1zT + k * 2 * HID + 8 * q + 4 * h);
@@ -485,7 +490,11 @@ DI void layer1_tile(const Smem& sm, const WaveW& ww, const float* ust, int h, co
 // vjp_mlp_partials (density tile first, then the drift tile: SPEC.md §5.4), hence the same bits; peak 32 tile registers instead of 64.
 template <int M, int F16>
 DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, const float4* h2c,
-                     float ebraw, const float* ob, float* Pz, float* Pu) {
+                     float ebraw_in, const float* ob_in, float* Pz, float* Pu) {
+    float ob[6];       // (math_mode fast: -2 onto the output adjoints, see vjp_mlp_partials)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ob[i] = FAST ? -2.0f * ob_in[i] : ob_in[i];
+    const float ebraw = FAST ? -2.0f * ebraw_in : ebraw_in;
 #pragma unroll
     for (int k = 0; k < NN; ++k) Pz[k] = 0.0f;
 #pragma unroll
@@ -505,10 +514,10 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
                 for (int k = 0; k < 3; ++k) wz[k] = *reinterpret_cast<const float4*>(sm.W1zT + (k0 + k) * 2 * HID + HID + 8 * q + 4 * h);
                 SCHED_PHASE();
                 if (k0 == 0) {
-                    an0 = (wn4.x * ebraw) * FMA(-hn[4 * q], hn[4 * q], 1.0f);
-                    an1 = (wn4.y * ebraw) * FMA(-hn[4 * q + 1], hn[4 * q + 1], 1.0f);
-                    an2 = (wn4.z * ebraw) * FMA(-hn[4 * q + 2], hn[4 * q + 2], 1.0f);
-                    an3 = (wn4.w * ebraw) * FMA(-hn[4 * q + 3], hn[4 * q + 3], 1.0f);
+                    an0 = (wn4.x * ebraw) * dact(hn[4 * q]);
+                    an1 = (wn4.y * ebraw) * dact(hn[4 * q + 1]);
+                    an2 = (wn4.z * ebraw) * dact(hn[4 * q + 2]);
+                    an3 = (wn4.w * ebraw) * dact(hn[4 * q + 3]);
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -536,10 +545,10 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
                 }
             }
             const float4 hq = h2c[q];
-            a2b[4 * q] = hb0 * FMA(-hq.x, hq.x, 1.0f);
-            a2b[4 * q + 1] = hb1 * FMA(-hq.y, hq.y, 1.0f);
-            a2b[4 * q + 2] = hb2 * FMA(-hq.z, hq.z, 1.0f);
-            a2b[4 * q + 3] = hb3 * FMA(-hq.w, hq.w, 1.0f);
+            a2b[4 * q] = hb0 * dact(hq.x);
+            a2b[4 * q + 1] = hb1 * dact(hq.y);
+            a2b[4 * q + 2] = hb2 * dact(hq.z);
+            a2b[4 * q + 3] = hb3 * dact(hq.w);
             SCHED_PHASE();
         }
 #pragma unroll
@@ -565,10 +574,10 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
         layer1_tile<F16, true>(sm, ww, ust, h, z, hd);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float ad0 = accB[4 * q] * FMA(-hd[4 * q], hd[4 * q], 1.0f);
-            float ad1 = accB[4 * q + 1] * FMA(-hd[4 * q + 1], hd[4 * q + 1], 1.0f);
-            float ad2 = accB[4 * q + 2] * FMA(-hd[4 * q + 2], hd[4 * q + 2], 1.0f);
-            float ad3 = accB[4 * q + 3] * FMA(-hd[4 * q + 3], hd[4 * q + 3], 1.0f);
+            float ad0 = accB[4 * q] * dact(hd[4 * q]);
+            float ad1 = accB[4 * q + 1] * dact(hd[4 * q + 1]);
+            float ad2 = accB[4 * q + 2] * dact(hd[4 * q + 2]);
+            float ad3 = accB[4 * q + 3] * dact(hd[4 * q + 3]);
 #pragma unroll
             for (int k0 = 0; k0 < NN; k0 += 3) {
                 float4 wz[3];

@@ -44,6 +44,7 @@ for r in range(a.reps):
     if a.mode == "solve":
         ih = info.cpu().numpy(); extra = f" N_it {ih[:,2].mean():.1f} N_ls {ih[:,7].mean():.1f} -> {B/ms*1e3:.1f} solves/s"
         wc = S.work_counters(reset=True)
+        extra += f"  work: {wc[1]/B:.1f} gradients + {wc[2]/B:.1f} rollouts per solve -> {(2*wc[1]+wc[2])*H*P/ms*1e3/1e9:.2f} G particle-steps/s"
         if wc[0] != B: extra += f"  [work counters: {wc[0]} solves for a batch of {B}]"
     else:
         extra = f" -> {B*H*P/ms*1e3/1e9:.3f} G particle-steps/s"

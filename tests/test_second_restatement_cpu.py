@@ -162,3 +162,54 @@ def test_matrix_pipe_modes_bit_identical_to_the_c_oracle(mlp):
     uo, _, info_o, _ = O.solve(x0, xref, noise, u, 0.01)
     un, info_n = N.solve_own(x0, xref, noise, u, 0.01)
     assert bits_differ(un, uo) == 0 and bits_differ(info_n, info_o) == 0
+
+
+def _hw():
+    return R2.HwTransc(orc.TRANSC_DIR)
+
+
+@pytest.mark.parametrize("func", ["rcp", "rsq", "exp2"])
+def test_second_model_of_the_transcendental_instructions_equals_the_c_model(func):
+    """SPEC.md §10a in NumPy (whole arrays, blocks read straight from the committed files) against oracle/transc_model.c: every special class, the
+    edges of every rule, and 300,000 random bit patterns per function — bit for bit (NaN payloads included)."""
+    rng = np.random.default_rng({"rcp": 1, "rsq": 2, "exp2": 3}[func])
+    u = rng.integers(0, 2 ** 32, size=300_000, dtype=np.uint64).astype(np.uint32)
+    edge = np.array([0x00000000, 0x80000000, 0x00000001, 0x007FFFFF, 0x00800000, 0x3F800000, 0xBF800000, 0x7F7FFFFF, 0xFF7FFFFF, 0x7F800000, 0xFF800000,
+                     0x7FC00000, 0x7F800001, 0xFFC12345, 0x7E800000, 0x7F000000, 0x7E000000, 0x42FE0000, 0x42FFFFFF, 0x43000000, 0xC2FC0000, 0xC2FE0000, 0xC3000000,
+                     0xC3150000, 0x30800000, 0x307FFFFF, 0xB0800000, 0x3FFFFFFF, 0x40000000, 0xC0000000, 0x40000001], np.uint32)
+    near = (np.array([0x3F800000, 0x40000000, 0x42FE0000, 0x30800000, 0x00800000], np.uint32)[:, None] + np.arange(-64, 64, dtype=np.int64)[None, :]).astype(np.uint32).ravel()
+    if func == "exp2":      # (most random patterns are huge: add arguments of the size the activations see)
+        u = np.concatenate([u, (rng.standard_normal(200_000) * 8).astype(np.float32).view(np.uint32)])
+    x = np.concatenate([u, edge, near]).view(np.float32)
+    got = getattr(_hw(), func)(x)
+    want = orc.hw_eval({"rcp": 0, "rsq": 1, "exp2": 2}[func], x)
+    assert bits_differ(got, want) == 0
+
+
+@pytest.mark.parametrize("mlp", ["f32", "f32x3", "f16"])
+def test_fast_math_mode_bit_identical_to_the_c_oracle(mlp):
+    """math_mode fast written a second time (SPEC.md §10b: the weight sets built in NumPy float32, the activation kept as r, the three instructions
+    through the NumPy statement of §10a): rollout, gradient and a short full solve equal the C oracle bit for bit, in every contraction arithmetic."""
+    big = mlp == "f32"
+    H, P = (6, 9) if big else (3, 2)
+    cfg = MPCConfig(horizon=H, num_short_dt=2, long_step_dt=0.1, num_particles=P, u_slew_coeff=1.0, res_mult=0.5, max_iter=3 if big else 2, max_no_improvement_iter=3,
+                    mlp_dtype=mlp, math_mode="fast")
+    model = synthetic_iris()
+    x0 = W.random_initial_states(1, 3)[0]
+    xref = W.reference_window(0.1, cfg.time_steps)
+    noise = W.make_noise(1, P, H, 2)[0]
+    u = np.clip(0.71 + 0.1 * np.random.default_rng(1).standard_normal((H, 4)), 1e-4, 1).astype(np.float32)
+    O, N = orc.Oracle(cfg, model), R2.Restatement(cfg, model, hw=_hw())
+    c_o, traj_o, mean_o = O.rollout(x0, u, xref, noise, want_traj=True, want_mean=True)
+    c_n, traj_n, mean_n = N.rollout(x0, u, xref, noise)
+    assert np.float32(c_o) == c_n and bits_differ(traj_n, traj_o) == 0 and bits_differ(mean_n, mean_o) == 0
+    c_o, g_o = O.grad(x0, u, xref, noise)
+    c_n, g_n = N.cost_grad(x0, u, xref, noise)
+    assert np.float32(c_o) == c_n and bits_differ(g_n, g_o.astype(np.float32)) == 0
+    uo, _, info_o, _ = O.solve(x0, xref, noise, u, 0.01)
+    un, info_n = N.solve_own(x0, xref, noise, u, 0.01)
+    assert bits_differ(un, uo) == 0 and bits_differ(info_n, info_o) == 0
+    # and the mode stays what it claims to be: the exact arithmetic's gradient to 1e-5 of its largest entry (f16: the operands are quantised differently)
+    E = orc.Oracle(cfg.replace(math_mode="exact"), model)
+    _, g_e = E.grad(x0, u, xref, noise)
+    assert np.abs(g_e - g_o).max() <= (2e-3 if mlp == "f16" else 1e-5) * np.abs(g_e).max()

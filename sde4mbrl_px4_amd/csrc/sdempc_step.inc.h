@@ -65,6 +65,24 @@ DI void mfma_x3(const float* Aimg, int lane, const Limbs3& L, f32x16& acc) {
     }
 }
 
+// the same contraction with all six weight-limb fragments requested up front (24 registers): math_mode fast's forward sweeps have the room, and
+// the requests then fly under the activation split instead of ahead of each group of matrix instructions
+struct LimbW { u32x4 w[3][2]; };
+DI void mfma_x3_request(const float* Aimg, int lane, LimbW& W) {
+#pragma unroll
+    for (int lb = 0; lb < 3; ++lb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) W.w[lb][hf] = *reinterpret_cast<const u32x4*>(Aimg + ((lb * 2 + hf) * 64 + lane) * 4);
+}
+DI void mfma_x3_run(const LimbW& W, const Limbs3& L, f32x16& acc) {
+    constexpr int WA[6] = {2, 1, 1, 0, 0, 0}, VB[6] = {0, 1, 0, 2, 1, 0};
+#pragma unroll
+    for (int s6 = 0; s6 < 6; ++s6)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W.w[WA[s6]][hf]), __builtin_bit_cast(bf16x8, L.l[VB[s6]][hf]), acc, 0, 0, 0);
+}
+
 // ---- MLPs of a step in the MFMA tile layout (32 particles per wave) ----
 // fwd_mlp_partials: the hidden tiles (A.h1d, A.h1n, A.h2) and the per-half partial chains of the seven output-layer dot products
 // (Po[0..5]: residual force / torque, Po[6]: density pre-activation); fwd_mlp_tiles adds the halves: (P0 + P1) + bias (SPEC.md §5.2).
@@ -135,8 +153,17 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
         }
     } else if constexpr (F16 == 2) {
         Limbs3 L;
-        split3_tile(accD, L);
-        mfma_x3(sm.A2x, lane, L, acc2);
+        if constexpr (FAST) {       // (the forward sweeps of math_mode fast have 24 registers to spare: + 0.5 %, tools/ab_power.sh)
+            LimbW LW;
+            mfma_x3_request(sm.A2x, lane, LW);
+            SCHED_PHASE();
+            split3_tile(accD, L);
+            SCHED_PHASE();
+            mfma_x3_run(LW, L, acc2);
+        } else {
+            split3_tile(accD, L);
+            mfma_x3(sm.A2x, lane, L, acc2);
+        }
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -149,6 +176,36 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
     }
     SCHED_PHASE();
 
+    // math_mode fast: the seven weight quads of quarter q + 1 are requested before the fmas of quarter q (quarter 0: before the layer-2 activation) —
+    // a second buffer of 28 registers the exact mode's loops do not have; + 0.3 % (tools/ab_power.sh), same operations in the same order
+    if constexpr (FAST) {
+        float4 wb[2][7];
+        auto req = [&](int q, float4* w) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i] = *reinterpret_cast<const float4*>(sm.W3 + i * HID + 8 * q + 4 * h);
+            w[6] = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
+        };
+        req(0, wb[0]);
+        SCHED_PHASE();
+        tanh_tile<PK>(acc2);
+        A.h2 = acc2;
+        SCHED_PHASE();
+#pragma unroll
+        for (int i = 0; i < 7; ++i) Po[i] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < 3) req(q + 1, wb[(q + 1) & 1]);
+            SCHED_PHASE();
+            const float4* w = wb[q & 1];
+#pragma unroll
+            for (int io = 0; io < 6; ++io) {
+                Po[io] = FMA(w[io].x, acc2[4 * q], Po[io]); Po[io] = FMA(w[io].y, acc2[4 * q + 1], Po[io]); Po[io] = FMA(w[io].z, acc2[4 * q + 2], Po[io]); Po[io] = FMA(w[io].w, acc2[4 * q + 3], Po[io]);
+            }
+            Po[6] = FMA(w[6].x, accN[4 * q], Po[6]); Po[6] = FMA(w[6].y, accN[4 * q + 1], Po[6]); Po[6] = FMA(w[6].z, accN[4 * q + 2], Po[6]); Po[6] = FMA(w[6].w, accN[4 * q + 3], Po[6]);
+            SCHED_PHASE();
+        }
+        return;
+    }
     tanh_tile<PK>(acc2);
     A.h2 = acc2;
     SCHED_PHASE();

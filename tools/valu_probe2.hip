@@ -3,6 +3,7 @@
 //   0 v_fmac_f32_e32 (VOP2, 4-byte encoding)      1 v_fma_f32 (VOP3, 8 bytes)      2 v_fmaak_f32 (VOP2 + 32-bit literal, 8 bytes)
 //   3 v_pk_fma_f32 (VOP3P, two FMAs per lane)      4 v_med3_f32 (VOP3)             5 v_lshl_add_u32 (VOP3)
 //   6 v_mul_f32_e32 (VOP2)                         7 v_add_f32_e32 (VOP2)          8 v_fma_f32 with an SGPR operand
+//   9 v_exp_f32                                    10 v_rcp_f32                    11 the mix of the math_mode fast rollout step: one transcendental per 3.8 plain
 // 24 independent accumulators per wave: dependent-issue distance 24 instructions.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -28,6 +29,12 @@ __global__ void __launch_bounds__(256) probe(float* out, int iters, float seed, 
 #define F6(i) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(c));
 #define F7(i) asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(c));
 #define F8(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(sc), "v"(d));
+#define F9(i) asm volatile("v_exp_f32_e32 %0, %0" : "+v"(a[i]));
+#define F10(i) asm volatile("v_rcp_f32_e32 %0, %0" : "+v"(a[i]));
+#define F11(i) if ((i) % 5 == 0) { if ((i) % 10 == 0) { F9(i) } else { F10(i) } } else { F0(i) }
+        if (MODE == 9) { REP24(F9) }
+        if (MODE == 10) { REP24(F10) }
+        if (MODE == 11) { REP24(F11) }
         if (MODE == 0) { REP24(F0) }
         if (MODE == 1) { REP24(F1) }
         if (MODE == 2) { REP24(F2) }
@@ -66,6 +73,7 @@ int main() {
     for (int wps : {1, 2, 3, 4}) {
         run<0>("v_fmac_e32", d, wps); run<1>("v_fma VOP3", d, wps); run<2>("v_fmaak literal", d, wps); run<3>("v_pk_fma", d, wps);
         run<4>("v_med3", d, wps); run<5>("v_lshl_add", d, wps); run<6>("v_mul_e32", d, wps); run<7>("v_add_e32", d, wps); run<8>("v_fma VOP3 sgpr", d, wps);
+        run<9>("v_exp_f32", d, wps); run<10>("v_rcp_f32", d, wps); run<11>("5 trans + 19 fmac", d, wps);
     }
     return 0;
 }

@@ -8,7 +8,9 @@ void orc_mfma16_decode(int bf16, uint16_t bits, orc_op16* out);
 float orc_mfma16_group(const orc_op16* a, const orc_op16* b, int n, float acc);
 /* eight finite bf16 products, structure-of-arrays operands (significands ma / mb, exponents xa / xb as in orc_op16.ex) */
 float orc_mfma16_group8_bf16(const int32_t* ma, const int32_t* xa, const int32_t* mb, const int32_t* xb, float acc);
+float orc_mfma16_group8_f16(const int32_t* ma, const int32_t* xa, const int32_t* mb, const int32_t* xb, float acc);
 float orc_mfma16_dot_bf16_soa(const uint16_t* a16, const uint16_t* b16, float c);
+float orc_mfma16_dot_f16_soa(const uint16_t* a16, const uint16_t* b16, float c);
 float orc_mfma16_dot(int bf16, const uint16_t* a16, const uint16_t* b16, float c);
 void orc_mfma16_tiles(int bf16, int ntiles, const uint16_t* A, const uint16_t* B, const float* C, float* D);
 #endif

@@ -371,6 +371,32 @@ def x3_contract(W, v, c):
     return out
 
 
+def f16_limbs(x):
+    """SPEC.md §10c: two roundings to nearest even to binary16 (NumPy's float16 conversion), the subtraction exact; -> two uint16 patterns"""
+    x = F(x)
+    with np.errstate(all="ignore"):
+        h1 = np.float16(x)
+        h2 = np.float16(F(x - F(h1)))
+    return [int(np.asarray(h1, np.float16).view(np.uint16)), int(np.asarray(h2, np.float16).view(np.uint16))]
+
+
+def h2_contract(W, v, c):
+    """out[i] = c[i] + sum_k W[i][k] v[k] as the eight f16 instructions of SPEC.md §10c: limb products (w2,v2) (w2,v1) (w1,v2) (w1,v1)"""
+    WA, VB = (1, 1, 0, 0), (1, 0, 1, 0)
+    vl = [f16_limbs(v[k]) for k in range(32)]
+    out = np.zeros(32, F)
+    for i in range(32):
+        wl = [f16_limbs(W[i, k]) for k in range(32)]
+        acc = F(c[i]) if c is not None else F(0.0)
+        for s4 in range(4):
+            for hf in range(2):
+                a16 = [wl[slot_unit(hf, k)][WA[s4]] for k in range(16)]
+                b16 = [vl[slot_unit(hf, k)][VB[s4]] for k in range(16)]
+                acc = mfma16_dot(False, a16, b16, acc)
+        out[i] = acc
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 class Model:
     """SPEC.md §2 blob."""
@@ -506,7 +532,7 @@ class Restatement:
         a2 = np.broadcast_to(M.b2, (x.shape[0], 32)).astype(F).copy()
         if self.mlp == "f32x3":
             for p_ in range(x.shape[0]):
-                a2[p_] = x3_contract(M.W2, h1d[p_], M.b2)
+                a2[p_] = h2_contract(M.W2, h1d[p_], M.b2) if self.fast else x3_contract(M.W2, h1d[p_], M.b2)       # (§10c: math_mode fast's forward contraction)
         elif self.mlp == "f16":                      # TWO chained instructions (hf = 0, 1)
             for p_ in range(x.shape[0]):
                 hb = [f16_rtz_bits(h1d[p_, k]) for k in range(32)]

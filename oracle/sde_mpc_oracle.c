@@ -202,26 +202,63 @@ static void bf16_limbs(float x, uint16_t* lb) {
         x = x - h;
     }
 }
-/* out[i] = c[i] + sum_k W[i][k] v[k] as the twelve instructions of SPEC.md §9b; Wm / Wx: M->x2m[tr], M->x2x[tr]; WmT / WxT: the row-last copies
- * (or NULL: scalar evaluation only). vec: 1 takes the 16-lane form of the group addition where the CPU has it, 0 forces the scalar (normative) one */
+/* SPEC.md §10c: round to nearest even to binary16 (sub-normals kept, overflow to infinity, NaN stays NaN): what v_cvt_pk_f16_f32 returns in the
+ * kernels' FP mode; and the value of a binary16 pattern */
+static uint16_t f16_rne_bits(float x) {
+    uint32_t u; memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u, mag = u & 0x7FFFFFFFu;
+    if (mag > 0x7F800000u) return (uint16_t)(sign | 0x7E00u);
+    if (mag >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                  /* >= 65520 rounds to infinity */
+    if (mag < 0x33000000u) return (uint16_t)sign;                                /* < 2^-25: zero (2^-25 itself ties to even = 0) */
+    const int e = (int)(mag >> 23) - 127;
+    uint32_t m = (mag & 0x7FFFFFu) | 0x800000u;                                 /* 24-bit significand */
+    int shift = e >= -14 ? 13 : 13 + (-14 - e);                                  /* bits to drop: 13 for normals, more for sub-normals */
+    if (shift > 24) { if (mag == 0x33000000u) return (uint16_t)sign; shift = 25; m = m; }
+    uint32_t q = shift >= 32 ? 0u : (m >> shift);
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q += 1u;
+    uint32_t bits;
+    if (e >= -14) bits = ((uint32_t)(e + 15) << 10) + (q - 0x400u);             /* a carry out of the significand moves into the exponent by itself */
+    else bits = q;                                                              /* sub-normal (q == 0x400: the smallest normal) */
+    return (uint16_t)(sign | bits);
+}
+static float f16_value(uint16_t h) {
+    const int s = h >> 15, ef = (h >> 10) & 31, f = h & 1023;
+    float v;
+    if (ef == 31) v = f ? NAN : INFINITY;
+    else if (ef == 0) v = ldexpf((float)f, -24);
+    else v = ldexpf((float)(f | 1024), ef - 25);
+    return s ? -v : v;
+}
+uint16_t NAME(f16_rne)(float x) { return f16_rne_bits(x); }       /* test entry */
+/* out[i] = c[i] + sum_k W[i][k] v[k] on the matrix pipe. kind 0: the twelve bf16 instructions of SPEC.md §9b (three limbs by truncation, six limb
+ * products); kind 1: the eight f16 instructions of §10c (two limbs, round to nearest even, four limb products: math_mode fast's forward contraction,
+ * whose activations lie in [0, 1]). Wm / Wx: M->x2m[tr], M->x2x[tr]; WmT / WxT: the row-last copies (or NULL: scalar evaluation only).
+ * The 16-lane form of the group addition is taken where the CPU has it; x3_scalar_only forces the scalar (normative) one */
 static int x3_scalar_only = 0;
 void NAME(x3_force_scalar)(int on) { x3_scalar_only = on; }
-static void x3_contract(const int32_t (*Wm)[HID][2][16], const int32_t (*Wx)[HID][2][16], const int32_t (*WmT)[2][16][HID], const int32_t (*WxT)[2][16][HID],
+static void x3_contract(int kind, const int32_t (*Wm)[HID][2][16], const int32_t (*Wx)[HID][2][16], const int32_t (*WmT)[2][16][HID], const int32_t (*WxT)[2][16][HID],
                         const float* v, const float* c, float* out) {
-    static const int WA[6] = {2, 1, 1, 0, 0, 0}, VB[6] = {0, 1, 0, 2, 1, 0};
+    static const int WA3[6] = {2, 1, 1, 0, 0, 0}, VB3[6] = {0, 1, 0, 2, 1, 0}, WA2[4] = {1, 1, 0, 0}, VB2[4] = {1, 0, 1, 0};
+    const int np = kind ? 4 : 6;
+    const int *WA = kind ? WA2 : WA3, *VB = kind ? VB2 : VB3;
     int32_t vm[3][2][16], vx[3][2][16];
     int special = 0;
     for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k) {
         uint16_t lb[3];
-        bf16_limbs(v[slot_unit(hf, k)], lb);
-        for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); vm[l][hf][k] = o.m; vx[l][hf][k] = o.ex; special |= o.kind; }
+        const float x = v[slot_unit(hf, k)];
+        if (kind) { lb[0] = f16_rne_bits(x); lb[1] = f16_rne_bits(x - f16_value(lb[0])); lb[2] = 0; }       /* (x - limb is exact; a NaN stays one) */
+        else bf16_limbs(x, lb);
+        for (int l = 0; l < (kind ? 2 : 3); ++l) { orc_op16 o; orc_mfma16_decode(!kind, lb[l], &o); vm[l][hf][k] = o.m; vx[l][hf][k] = o.ex; special |= o.kind; }
     }
     if (!special && WmT && !x3_scalar_only && orc_mfma16_vec_available()) {
         for (int blk = 0; blk < HID; blk += 16) {
             float acc[16];
             for (int l = 0; l < 16; ++l) acc[l] = c ? c[blk + l] : 0.0f;       /* (a non-finite start value stays as it is: the group addition keeps it) */
-            for (int s6 = 0; s6 < 6; ++s6) for (int hf = 0; hf < 2; ++hf) for (int g8 = 0; g8 < 16; g8 += 8)
-                orc_mfma16_group8_bf16_x16(&WmT[WA[s6]][hf][g8][blk], &WxT[WA[s6]][hf][g8][blk], HID, &vm[VB[s6]][hf][g8], &vx[VB[s6]][hf][g8], acc);
+            for (int s6 = 0; s6 < np; ++s6) for (int hf = 0; hf < 2; ++hf) for (int g8 = 0; g8 < 16; g8 += 8) {
+                if (kind) orc_mfma16_group8_f16_x16(&WmT[WA[s6]][hf][g8][blk], &WxT[WA[s6]][hf][g8][blk], HID, &vm[VB[s6]][hf][g8], &vx[VB[s6]][hf][g8], acc);
+                else orc_mfma16_group8_bf16_x16(&WmT[WA[s6]][hf][g8][blk], &WxT[WA[s6]][hf][g8][blk], HID, &vm[VB[s6]][hf][g8], &vx[VB[s6]][hf][g8], acc);
+            }
             for (int l = 0; l < 16; ++l) out[blk + l] = acc[l];
         }
         return;
@@ -232,10 +269,10 @@ static void x3_contract(const int32_t (*Wm)[HID][2][16], const int32_t (*Wx)[HID
             acc = NAN;
         } else if (!isfinite(acc)) {          /* finite products on a non-finite start value leave it as it is */
         } else {
-            for (int s6 = 0; s6 < 6; ++s6) for (int hf = 0; hf < 2; ++hf) {
+            for (int s6 = 0; s6 < np; ++s6) for (int hf = 0; hf < 2; ++hf) {
                 const int32_t *wm = Wm[WA[s6]][i][hf], *wx = Wx[WA[s6]][i][hf], *am = vm[VB[s6]][hf], *ax = vx[VB[s6]][hf];
-                acc = orc_mfma16_group8_bf16(wm, wx, am, ax, acc);
-                acc = orc_mfma16_group8_bf16(wm + 8, wx + 8, am + 8, ax + 8, acc);
+                if (kind) { acc = orc_mfma16_group8_f16(wm, wx, am, ax, acc); acc = orc_mfma16_group8_f16(wm + 8, wx + 8, am + 8, ax + 8, acc); }
+                else { acc = orc_mfma16_group8_bf16(wm, wx, am, ax, acc); acc = orc_mfma16_group8_bf16(wm + 8, wx + 8, am + 8, ax + 8, acc); }
             }
         }
         out[i] = acc;
@@ -244,14 +281,16 @@ static void x3_contract(const int32_t (*Wm)[HID][2][16], const int32_t (*Wx)[HID
 /* Test entry (tests/test_mfma16_model_cpu.py): one 32x32 contraction out[i] = c[i] + sum_k W[i][k] v[k] on caller-supplied operands, in the
  * f32 fma chain of SPEC.md §4 (mode 0) or as the twelve instructions of §9b (mode 2) — the two arithmetics of layer 2, without a model around them */
 void NAME(contract32)(int mode, const float* W, const float* v, const float* c, float* out) {
-    if (mode == 2) {
+    if (mode == 2 || mode == 3) {          /* 3: the f16 two-limb form of SPEC.md §10c */
         static int32_t Wm[3][HID][2][16], Wx[3][HID][2][16], WmT[3][2][16][HID], WxT[3][2][16][HID];
         for (int i = 0; i < HID; ++i) for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k) {
             uint16_t lb[3];
-            bf16_limbs(W[i * HID + slot_unit(hf, k)], lb);
-            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); Wm[l][i][hf][k] = WmT[l][hf][k][i] = o.m; Wx[l][i][hf][k] = WxT[l][hf][k][i] = o.ex; }
+            const float w = W[i * HID + slot_unit(hf, k)];
+            if (mode == 3) { lb[0] = f16_rne_bits(w); lb[1] = f16_rne_bits(w - f16_value(lb[0])); lb[2] = 0; }
+            else bf16_limbs(w, lb);
+            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(mode == 2, lb[l], &o); Wm[l][i][hf][k] = WmT[l][hf][k][i] = o.m; Wx[l][i][hf][k] = WxT[l][hf][k][i] = o.ex; }
         }
-        x3_contract(Wm, Wx, WmT, WxT, v, c, out);
+        x3_contract(mode == 3, Wm, Wx, WmT, WxT, v, c, out);
         return;
     }
     for (int i = 0; i < HID; ++i) {
@@ -371,8 +410,10 @@ static int parse_blob(const void* blob, model_t* M, int f16, int fast) {
         for (int tr = 0; tr < 2; ++tr) for (int i = 0; i < HID; ++i) for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k) {
             const int un = slot_unit(hf, k);
             uint16_t lb[3];
-            bf16_limbs(tr ? M->vW2[un][i] : M->W2[i][un], lb);
-            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(1, lb[l], &o); M->x2m[tr][l][i][hf][k] = M->x2mT[tr][l][hf][k][i] = o.m; M->x2x[tr][l][i][hf][k] = M->x2xT[tr][l][hf][k][i] = o.ex; }
+            const int h2 = !tr && M->fast;          /* SPEC.md §10c: the forward contraction of math_mode fast takes two f16 limbs (round to nearest even) */
+            if (h2) { const float w = M->W2[i][un]; lb[0] = f16_rne_bits(w); lb[1] = f16_rne_bits(w - f16_value(lb[0])); lb[2] = 0; }
+            else bf16_limbs(tr ? M->vW2[un][i] : M->W2[i][un], lb);
+            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(!h2, lb[l], &o); M->x2m[tr][l][i][hf][k] = M->x2mT[tr][l][hf][k][i] = o.m; M->x2x[tr][l][i][hf][k] = M->x2xT[tr][l][hf][k][i] = o.ex; }
         }
     }
 #endif
@@ -497,7 +538,7 @@ static void step_fwd(const model_t* M, const ustep_t* U, const preal* x, const p
             pre_2[i] = acc;
         }
     } else if (M->f16 == 2) {
-        x3_contract(M->x2m[0], M->x2x[0], M->x2mT[0], M->x2xT[0], A->h1d, M->b2, pre_2);
+        x3_contract(M->fast, M->x2m[0], M->x2x[0], M->x2mT[0], M->x2xT[0], A->h1d, M->b2, pre_2);
     } else
 #endif
     for (int i = 0; i < HID; ++i) {
@@ -647,7 +688,7 @@ static void step_vjp(const model_t* M, const preal* x, const preal* xi, real dt,
     }
 #ifdef ORC_MFMA16
     float hb_x3[HID];
-    if (M->f16 == 2) x3_contract(M->x2m[1], M->x2x[1], M->x2mT[1], M->x2xT[1], a2b, NULL, hb_x3);       /* SPEC.md §9b: W2^T abar2 as the three-limb split */
+    if (M->f16 == 2) x3_contract(0, M->x2m[1], M->x2x[1], M->x2mT[1], M->x2xT[1], a2b, NULL, hb_x3);       /* SPEC.md §9b: W2^T abar2 as the three-limb split */
 #endif
     for (int k = 0; k < HID; ++k) {
         preal hb = pbroadcast(R(0));

@@ -273,8 +273,14 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid, int BNT
         for (int i = tid; i < 2 * 64 * 8; i += BNT) {
             const int e = i & 7, l = (i >> 3) & 63, hf = i >> 9, jj = l & 31, hh = l >> 5, un = rowmap(8 * hf + e, hh);
             float wv[2] = {w[OFF_W2 + jj * HID + un], w[VJP_BASE + OFF_W2 + un * HID + jj]};
+            if constexpr (FAST) {       // SPEC.md §10c: the forward operand as two binary16 limbs, round to nearest even (the casts), w - limb exact
+                const _Float16 h1 = (_Float16)wv[0];
+                const _Float16 h2 = (_Float16)(wv[0] - (float)h1);
+                ax[(0 * 2 + hf) * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, h1);
+                ax[(1 * 2 + hf) * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, h2);
+            }
 #pragma unroll
-            for (int tr = 0; tr < 2; ++tr) {
+            for (int tr = FAST ? 1 : 0; tr < 2; ++tr) {
                 unsigned short* dst = tr ? axt : ax;
                 float rem = wv[tr];
 #pragma unroll

@@ -65,24 +65,6 @@ DI void mfma_x3(const float* Aimg, int lane, const Limbs3& L, f32x16& acc) {
     }
 }
 
-// the same contraction with all six weight-limb fragments requested up front (24 registers): math_mode fast's forward sweeps have the room, and
-// the requests then fly under the activation split instead of ahead of each group of matrix instructions
-struct LimbW { u32x4 w[3][2]; };
-DI void mfma_x3_request(const float* Aimg, int lane, LimbW& W) {
-#pragma unroll
-    for (int lb = 0; lb < 3; ++lb)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) W.w[lb][hf] = *reinterpret_cast<const u32x4*>(Aimg + ((lb * 2 + hf) * 64 + lane) * 4);
-}
-DI void mfma_x3_run(const LimbW& W, const Limbs3& L, f32x16& acc) {
-    constexpr int WA[6] = {2, 1, 1, 0, 0, 0}, VB[6] = {0, 1, 0, 2, 1, 0};
-#pragma unroll
-    for (int s6 = 0; s6 < 6; ++s6)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, W.w[WA[s6]][hf]), __builtin_bit_cast(bf16x8, L.l[VB[s6]][hf]), acc, 0, 0, 0);
-}
-
 // ---- MLPs of a step in the MFMA tile layout (32 particles per wave) ----
 // fwd_mlp_partials: the hidden tiles (A.h1d, A.h1n, A.h2) and the per-half partial chains of the seven output-layer dot products
 // (Po[0..5]: residual force / torque, Po[6]: density pre-activation); fwd_mlp_tiles adds the halves: (P0 + P1) + bias (SPEC.md §5.2).
@@ -152,15 +134,39 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc2, 0, 0, 0);
         }
     } else if constexpr (F16 == 2) {
-        Limbs3 L;
-        if constexpr (FAST) {       // (the forward sweeps of math_mode fast have 24 registers to spare: + 0.5 %, tools/ab_power.sh)
-            LimbW LW;
-            mfma_x3_request(sm.A2x, lane, LW);
+        if constexpr (FAST) {
+            // SPEC.md §10c: math_mode fast keeps activations in [0, 1], so the forward contraction splits them into TWO binary16 limbs by round to
+            // nearest (v_cvt_pk_f16_f32 packs two values per instruction, v_fma_mix_f32 forms the exact residual x - limb straight from the packed
+            // half): 2 instructions per value instead of 5.5, and eight v_mfma_f32_32x32x16_f16 on the limb products (w2,r2) (w2,r1) (w1,r2) (w1,r1)
+            // instead of twelve bf16 ones. The four weight fragments (load_weights: two binary16 limbs of the forward weights) are requested first
+            // and fly under the split.
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            u32x4 r1[2], r2[2], aw[2][2];
+#pragma unroll
+            for (int lb = 0; lb < 2; ++lb)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) aw[lb][hf] = *reinterpret_cast<const u32x4*>(sm.A2x + ((lb * 2 + hf) * 64 + lane) * 4);
             SCHED_PHASE();
-            split3_tile(accD, L);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const float x = accD[8 * hf + 2 * pr], y = accD[8 * hf + 2 * pr + 1];
+                    unsigned p1, p2; float xr, yr;
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(x), "v"(y));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(xr) : "v"(p1), "v"(x));                      // x - (float)p1.lo, exact
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(yr) : "v"(p1), "v"(y));     // y - (float)p1.hi
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p2) : "v"(xr), "v"(yr));
+                    r1[hf][pr] = p1; r2[hf][pr] = p2;
+                }
             SCHED_PHASE();
-            mfma_x3_run(LW, L, acc2);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, aw[s4 < 2 ? 1 : 0][hf]), __builtin_bit_cast(h8, (s4 & 1) ? r1[hf] : r2[hf]), acc2, 0, 0, 0);
         } else {
+            Limbs3 L;
             split3_tile(accD, L);
             mfma_x3(sm.A2x, lane, L, acc2);
         }

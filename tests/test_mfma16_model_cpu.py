@@ -17,16 +17,18 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _dot(bf16, a, b, c, soa=False):
-    """soa: through the structure-of-arrays group of eight the oracle's f32x3 path uses (bf16 only)"""
+    """soa: through the structure-of-arrays group of eight the oracle's f32x3 paths use (bf16: SPEC.md 9b; f16: 10c)"""
     L = orc.lib()
     L.orc_mfma16_dot.restype = C.c_float
     L.orc_mfma16_dot.argtypes = [C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_float]
     L.orc_mfma16_dot_bf16_soa.restype = C.c_float
     L.orc_mfma16_dot_bf16_soa.argtypes = [C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_float]
+    L.orc_mfma16_dot_f16_soa.restype = C.c_float
+    L.orc_mfma16_dot_f16_soa.argtypes = [C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.c_float]
     a = np.ascontiguousarray(a, np.uint16); b = np.ascontiguousarray(b, np.uint16)
     pa, pb = a.ctypes.data_as(C.POINTER(C.c_uint16)), b.ctypes.data_as(C.POINTER(C.c_uint16))
     if soa:
-        return np.float32(L.orc_mfma16_dot_bf16_soa(pa, pb, C.c_float(float(c))))
+        return np.float32((L.orc_mfma16_dot_bf16_soa if bf16 else L.orc_mfma16_dot_f16_soa)(pa, pb, C.c_float(float(c))))
     return np.float32(L.orc_mfma16_dot(bf16, pa, pb, C.c_float(float(c))))
 
 
@@ -38,7 +40,7 @@ def test_model_reproduces_the_recorded_hardware_answers(dtn):
     bad = {}
     for n in range(len(d)):
         cf = c[n:n + 1].view(np.float32)[0]
-        for soa in ((False, True) if dtn == "bf16" else (False,)):       # bf16: also through the vectorised group the f32x3 oracle path uses
+        for soa in (False, True):       # also through the structure-of-arrays groups the f32x3 oracle paths use
             got = _dot(int(dtn == "bf16"), a[n], b[n], cf, soa)
             if got.view(np.uint32) != d[n] and not (np.isnan(got) and np.isnan(d[n:n + 1].view(np.float32)[0])):
                 bad.setdefault(str(g["family_names"][fam[n]]) + ("/soa" if soa else ""), []).append(n)
@@ -191,6 +193,34 @@ def test_f32x3_contraction_is_as_close_to_float64_as_the_f32_chain():
     assert mx3 <= 2.0 ** -21 and rx3 <= 2.0 * r32, (r32, rx3, m32, mx3)
 
 
+def test_f16_two_limb_contraction_of_fast_mode_is_as_close_to_float64_as_the_f32_chain():
+    """SPEC.md §10c: math_mode fast's forward layer-2 contraction (activations in [0, 1], two f16 limbs by round-to-nearest of either operand, four
+    limb products, eight instructions) against float64, beside the f32 chain and the three-limb bf16 form on the same operands."""
+    rng = np.random.default_rng(11)
+    def run(gen, n):
+        e32, ex3, eh2 = [], [], []
+        for _ in range(n):
+            Wm, v, c = gen()
+            ref = c.astype(np.float64) + Wm.astype(np.float64) @ v.astype(np.float64)
+            mag = np.abs(c.astype(np.float64)) + np.abs(Wm.astype(np.float64)) @ np.abs(v.astype(np.float64))
+            e32.append((_contract(0, Wm, v, c).astype(np.float64) - ref) / mag)
+            ex3.append((_contract(2, Wm, v, c).astype(np.float64) - ref) / mag)
+            eh2.append((_contract(3, Wm, v, c).astype(np.float64) - ref) / mag)
+        e32, ex3, eh2 = (np.concatenate(t) for t in (e32, ex3, eh2))
+        rms = lambda e: np.sqrt((e ** 2).mean())
+        return rms(e32), rms(ex3), rms(eh2), np.abs(e32).max(), np.abs(eh2).max(), eh2.mean()
+    # the shapes of the mode: weights -2 (2 log2 e) N(0, 1/32), activations 1 / (1 + 2^a), start value of the size of the folded bias
+    r32, rx3, rh2, m32, mh2, bias = run(lambda: ((-5.77 * rng.standard_normal((32, 32)) / np.sqrt(32)).astype(np.float32),
+                                                 (1.0 / (1.0 + np.exp2(2.0 * rng.standard_normal(32)))).astype(np.float32), (2.0 * rng.standard_normal(32)).astype(np.float32)), 200)
+    assert rh2 <= 1.25 * r32 and mh2 <= 1.5 * m32 and mh2 <= 2.0 ** -22, (r32, rx3, rh2, m32, mh2)
+    assert abs(bias) <= 2.0 ** -26                                  # round to nearest: no direction
+    # saturated activations (exact 0 and 1, and values so small that their second limb is a binary16 sub-normal or vanishes)
+    r32, rx3, rh2, m32, mh2, _ = run(lambda: ((rng.standard_normal((32, 32))).astype(np.float32),
+                                              np.where(rng.random(32) < 0.3, rng.integers(0, 2, 32), np.exp2(-rng.uniform(0, 30, 32))).astype(np.float32),
+                                              rng.standard_normal(32).astype(np.float32)), 200)
+    assert rh2 <= 1.25 * r32 and mh2 <= 1.5 * m32, (r32, rx3, rh2, m32, mh2)
+
+
 def test_model_keeps_a_non_finite_running_value():
     """An earlier group (or instruction of a chain) that overflowed leaves inf in the accumulator: finite products cannot bring it back
     (the hardware keeps inf; the integer decode of exponent field 255 must not be taken for 2^128)."""
@@ -231,9 +261,10 @@ def test_sixteen_lane_group_addition_equals_the_scalar_statement():
                     Wm, v, c = (np.asarray(t, np.float64).astype(np.float32) for t in g())
                     if gi == 4 and rng.random() < 0.3:
                         Wm[:, ::2] = -Wm[:, 1::2]; v[::2] = v[1::2]
-                    L.orc_x3_force_scalar(1); a = _contract(2, Wm, v, c)
-                    L.orc_x3_force_scalar(0); b = _contract(2, Wm, v, c)
-                    assert np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(a)]) and np.array_equal(np.isnan(a), np.isnan(b)), gi
+                    for mode in (2, 3):      # the bf16 three-limb form and the f16 two-limb form of SPEC.md 10c (out-of-range operands of the latter: inf limbs, IEEE rules)
+                        L.orc_x3_force_scalar(1); a = _contract(mode, Wm, v, c)
+                        L.orc_x3_force_scalar(0); b = _contract(mode, Wm, v, c)
+                        assert np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(a)]) and np.array_equal(np.isnan(a), np.isnan(b)), (gi, mode)
         cfg, x0, xref, noise, u = _small("f32x3", H=12, P=48)
         O = orc.Oracle(cfg, synthetic_iris())
         L.orc_x3_force_scalar(1); s1 = O.solve(x0, xref, noise, u, 0.01)

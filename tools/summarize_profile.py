@@ -13,6 +13,7 @@ ap.add_argument("src"); ap.add_argument("tag")
 ap.add_argument("--batch", type=int, default=2048)
 ap.add_argument("--config", default="c2_iris_traj_h50_p128.yaml")
 ap.add_argument("--mfma-per-eval", type=float, default=0.0, help="f32 MFMAs of one forward sweep of one instance (C2: 2 pairs x 50 steps x 44 = 4400); enables the SQ sum check")
+ap.add_argument("--mfma-per-adjoint", type=float, default=0.0, help="matrix instructions of one ADJOINT sweep of one instance when they differ from a forward sweep's (f32x3 / fast: forward 2 x 50 x 28 = 2800, adjoint 2 x 50 x 36 = 3600)")
 ap.add_argument("--mlp-dtype", default="f32x3", help="arithmetic of the profiled launches (key of profiles/pmc_traffic.json)")
 ap.add_argument("--math-mode", default="fast", help="math mode of the profiled launches (key of profiles/pmc_traffic.json)")
 ap.add_argument("--sq-batch", type=int, default=0, help="batch of the SQ_* / GRBM passes (pmc_3, pmc_4) when it differs from --batch (tools/profile_round.sh)")
@@ -83,7 +84,8 @@ if "GRBM_GUI_ACTIVE" in solve and "SQ_INSTS_VALU" in solve:
 # not do the work the bench line describes (round 2: launches whose instance tickets were reset late solved 1,536 instances twice)
 if bench and "SQ_INSTS_MFMA" in solve and a.mfma_per_eval:
     cfgb = bench["config"]
-    exp = a.mfma_per_eval * (2 * cfgb["N_grad_evaluated_mean"] + cfgb["N_forward_rollouts_mean"]) * (a.sq_batch or a.batch)
+    adj = a.mfma_per_adjoint or a.mfma_per_eval
+    exp = ((a.mfma_per_eval + adj) * cfgb["N_grad_evaluated_mean"] + a.mfma_per_eval * cfgb["N_forward_rollouts_mean"]) * (a.sq_batch or a.batch)
     f = solve["SQ_INSTS_MFMA"] / exp
     res["sq_sum_check"] = {"expected_SQ_INSTS_MFMA": exp, "measured": solve["SQ_INSTS_MFMA"], "factor": f,
                            "SQ_INSTS_VALU_per_solve_corrected": solve.get("SQ_INSTS_VALU", 0) / f / (a.sq_batch or a.batch),

@@ -292,8 +292,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_build": traffic_build, "kernel": kernel_name, "kernel_ms": k_ms,
                          "binding_resource": ("the package power cap (field power: the firmware holds the shader clock below 2.4 GHz) and, inside it, vector (VALU) instruction issue with its LDS / matrix-chain waits — "
-                                              "math_mode fast: the vector stream alone is 55 % of the launch's cycles at the best rate a SIMD issues this mix (exact: 86 %), the matrix pipe is busy a quarter of them, "
-                                              "HBM moves 2.9 of 8 TB/s; valu_issue has the counters"),
+                                              "math_mode fast: the vector stream alone is 53 % of the launch's cycles at the best rate a SIMD issues this mix (exact: 86 %), the matrix pipe is busy a quarter of them, "
+                                              "HBM moves 3.1 of 8 TB/s; valu_issue has the counters"),
                          "valu_issue": valu_issue,
                          "note": "algorithmic flops = SURVEY 8d MLP formula x P*H*(2*N_grad+N_ls+2) (N_grad = gradient evaluations actually performed: sdempc_work_counters), "
                                  "against the 157.3 TFLOP/s f32 peak (f32 vector peak = f32-input MFMA peak): every operand and every accumulation of the path is f32; `bound` keeps the "

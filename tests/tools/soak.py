@@ -16,6 +16,8 @@ LAYOUTS = [("auto", {}), ("coop", {"spec": 0}), ("coop-rt", {"coop_launch": 1}),
            ("tile-nolane", {"coop": 0, "lane": 0, "pk": 0}), ("tile-noduo", {"coop": 0, "pk": 0, "duo": 0}), ("tile-noduo-gtab", {"coop": 0, "pk": 0, "duo": 0, "ustg": 1})]
 MLPS = (sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32", "f32", "f16", "f32x3", "f32x3"])     # contraction modes to draw from (SPEC.md 9, 9b): all bit-exact
 FAST_SHARE = float(sys.argv[4]) if len(sys.argv) > 4 else 0.4
+DEBUG = bool(os.environ.get("SOAK_DEBUG"))          # which outputs differ, per instance
+ONLY = set(int(x) for x in os.environ.get("SOAK_ONLY", "").split(",") if x)      # case numbers to run (the others are skipped; draws unchanged)
 used = {}
 for it in range(n):
     rng = np.random.default_rng(seed0 + it)
@@ -35,6 +37,7 @@ for it in range(n):
         kw.update(state_id=ids, state_penalty=[float(rng.uniform(0.1, 30)) for _ in ids], constr_pen=float(rng.choice([1.0, 0.1])),
                   state_bound=[[-float(rng.uniform(0.05, 1.0)), float(rng.uniform(0.05, 1.0))] for _ in ids])
     if FAST_SHARE and rng.random() < FAST_SHARE: kw.update(math_mode="fast")          # SPEC.md 10: the hardware-instruction arithmetic, checked against oracle/transc_model.c
+    if ONLY and (seed0 + it) not in ONLY: continue
     cfg = MPCConfig(**kw); model = synthetic_multirotor(m, seed=it)
     lname, lopts = LAYOUTS[int(rng.integers(0, len(LAYOUTS)))]
     if cfg.mlp_dtype != "f32":
@@ -54,8 +57,12 @@ for it in range(n):
     for b in range(B):
         c, t, mm = O.rollout(x0[b], u[b], xref[b], noise[b], True, True); c2, g2 = O.grad(x0[b], u[b], xref[b], noise[b])
         uo, xo, io, _ = O.solve(x0[b], xref[b], noise[b], u[b], float(cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize))
-        nb += bits_differ(cost[b], c) + bits_differ(traj[b], t) + bits_differ(xm[b], mm) + bits_differ(gc[b], c2) + bits_differ(g[b], g2.astype(np.float32)) \
-              + bits_differ(uopt[b], uo) + bits_differ(xe[b], xo) + bits_differ(info[b], io)
+        parts = dict(cost=bits_differ(cost[b], c), traj=bits_differ(traj[b], t), xmean=bits_differ(xm[b], mm), grad_cost=bits_differ(gc[b], c2), grad=bits_differ(g[b], g2.astype(np.float32)),
+                     uopt=bits_differ(uopt[b], uo), xevol=bits_differ(xe[b], xo), info=bits_differ(info[b], io))
+        nb += sum(parts.values())
+        if DEBUG and sum(parts.values()):
+            print(f"   case {seed0+it} instance {b}: differing words {parts}", flush=True)
+            if parts["info"]: print(f"      info GPU {info[b]}\n      info CPU {np.asarray(io)}\n      kernel {S.last_kernel_name()}", flush=True)
         nzo = orc.noise_from_key(keys[b], P, H)
         uo2, xo2, io2, _ = O.solve(x0[b], xref[b], nzo, u[b], float(cfg.ls_init_stepsize if cfg.ls_maxls else cfg.stepsize))
         nb += bits_differ(nk[b], nzo) + bits_differ(uk[b], uo2) + bits_differ(xk[b], xo2) + bits_differ(ik[b], io2)

@@ -73,8 +73,10 @@ DTYPE_NOTE = {
              "(tests/test_mfma16_model_cpu.py), bit-identical to the CPU oracle)",
     "f16": "f16 MLP operands / f32 accumulate and state",
 }
-MATH_NOTE = {"exact": "activations by the software forms of SPEC.md 3", "fast": "activations on v_exp_f32 / v_rcp_f32 (1 ulp), quaternion renormalisation on v_rsq_f32: SPEC.md 10, "
-             "bit-identical to the CPU oracle through its model of the three instructions (SPEC.md 10a)"}
+MATH_NOTE = {"exact": "activations by the software forms of SPEC.md 3", "fast": "activations on v_exp_f32 / v_rcp_f32 (1 ulp), kept as r = 1 / (1 + 2^a') with their affine maps folded into the weights (SPEC.md 10b), quaternion "
+             "renormalisation on v_rsq_f32; in f32x3 the forward layer-2 contraction takes two binary16 limbs (round to nearest, 2^-24) of the bounded activations and of the "
+             "weights on v_mfma_f32_32x32x16_f16 (SPEC.md 10c), the adjoint's keeps three bf16 limbs; bit-identical to the CPU oracle through its models of the three "
+             "transcendental instructions (SPEC.md 10a) and of the matrix instruction (9a)"}
 
 
 def dry_run(args, rank, world):

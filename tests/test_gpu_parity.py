@@ -529,9 +529,10 @@ def test_solve_with_keys_equals_solve_with_oracle_noise():
 
 
 # ---- math_mode: fast (SPEC.md §10): hardware transcendentals, checked bit for bit through the model of the three instructions (§10a) ------
-@pytest.mark.parametrize("mlp,P", [("f32", 70), ("f16", 70), ("f32x3", 70), ("f32", 1), ("f32", 33)])
+@pytest.mark.parametrize("mlp,P", [("f32", 70), ("f16", 70), ("f32x3", 70), ("f32", 1), ("f32", 33), ("f32x3", 32), ("f32x3", 7), ("f16", 31)])
 def test_fast_math_mode_matches_oracle_bit_for_bit(mlp, P, layout):
-    """(f32 contractions: the `layout` fixture also takes the mode through the lane layouts — single-particle lanes, speculative and plain cooperative kernels)"""
+    """(f32 contractions: the `layout` fixture also takes the mode through the lane layouts — single-particle lanes, speculative and plain cooperative kernels;
+    P <= 32 in the matrix-pipe modes: the one-wave-per-instance instantiation of the tile kernels, whose telemetry a register-pressure experiment once lost)"""
     cfg = MPCConfig(horizon=24 if P == 70 else 9, num_short_dt=9, long_step_dt=0.1, num_particles=P, u_slew_coeff=1.0, max_iter=8, max_no_improvement_iter=8, mlp_dtype=mlp, math_mode="fast")
     model = synthetic_iris()
     B = 4

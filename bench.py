@@ -301,7 +301,7 @@ def main():
                                  "against the 157.3 TFLOP/s f32 peak (f32 vector peak = f32-input MFMA peak): every operand and every accumulation of the path is f32; `bound` keeps the "
                                  "contract's vocabulary for that comparison. What binds the kernel is in binding_resource / valu_issue (vector instructions per SIMD, shader cycles, "
                                  "and the fraction of the cycles the stream takes at the best rate a SIMD issues it: PMC passes of the same build, profiles/). "
-                                 "In the f32x3 mode 74 % of the counted flops (the two 32x32 contractions) run as 6 bf16 limb products each on the matrix pipe (2.5 PFLOP/s dense): "
+                                 "In the f32x3 mode 74 % of the counted flops (the two 32x32 contractions) run as limb products on the matrix pipe (2.5 PFLOP/s dense): six bf16 products per contraction, in math_mode fast four binary16 ones in the forward sweeps (SPEC.md 9b, 10c): "
                                  "the kernel is bound by the f32 vector work beside them (tanh, rigid body, adjoint algebra), not by either matrix peak"},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
                              "traffic": traffic, "bytes_per_solve": bytes_solve, "B_grad": b_grad, "B_ls": b_ls,

@@ -25,6 +25,7 @@
 #include "sdempc_kernels.h"
 
 using namespace sdempc;
+static_assert(blob::FLOATS == SDEMPC_BLOB_FLOATS, "blob layout: sdempc_kernels.h and include/sdempc.h");
 
 namespace {
 std::string g_create_error;
@@ -407,8 +408,8 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     if (cfg->mlp_dtype < 0 || cfg->mlp_dtype > 2) return fail(nullptr, SDEMPC_EINVAL, "mlp_dtype must be 0 (f32), 1 (f16) or 2 (f32x3)%s");
     if (cfg->math_mode != 0 && cfg->math_mode != 1) return fail(nullptr, SDEMPC_EINVAL, "math_mode must be 0 (exact) or 1 (fast)%s");
     if (cfg->mlp_dtype == 1) {   // layer-1 state-input weights and layer-2 weights live in fp16 (forward and adjoint alike)
-        for (int i = 0; i < 64 * 6; ++i) h->blob_f[56 + i] = f16_rtz_host(h->blob_f[56 + i]);
-        for (int i = 0; i < 32 * 32; ++i) h->blob_f[760 + i] = f16_rtz_host(h->blob_f[760 + i]);
+        for (int i = 0; i < 64 * 6; ++i) h->blob_f[blob::W1Z + i] = f16_rtz_host(h->blob_f[blob::W1Z + i]);
+        for (int i = 0; i < 32 * 32; ++i) h->blob_f[blob::W2 + i] = f16_rtz_host(h->blob_f[blob::W2 + i]);
     }
     if (cfg->math_mode == 1) {
         // SPEC.md §10b: the hardware tanh is evaluated as r = rcp(1 + exp2(a')), a' = (2 log2 e) a, tanh(a) = 1 - 2 r. The pre-scale goes into the weights
@@ -418,37 +419,37 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
         const float c = 2.885390043258667f;
         const std::vector<float> o = h->blob_f;
         std::vector<float> F = o, V = o;
-        for (int i = 0; i < 64 * 6; ++i) { float w = c * o[56 + i]; F[56 + i] = cfg->mlp_dtype == 1 ? f16_rtz_host(w) : w; }
-        for (int i = 0; i < 64; ++i) F[440 + i] = c * o[440 + i];
-        for (int i = 0; i < 32 * 8; ++i) F[504 + i] = c * o[504 + i];
+        for (int i = 0; i < 64 * 6; ++i) { float w = c * o[blob::W1Z + i]; F[blob::W1Z + i] = cfg->mlp_dtype == 1 ? f16_rtz_host(w) : w; }
+        for (int i = 0; i < 64; ++i) F[blob::B1 + i] = c * o[blob::B1 + i];
+        for (int i = 0; i < 32 * 8; ++i) F[blob::W1U + i] = c * o[blob::W1U + i];
         for (int j = 0; j < 32; ++j) {
-            float sum = c * o[1784 + j];
+            float sum = c * o[blob::B2 + j];
             for (int k = 0; k < 32; ++k) {
-                float w = c * o[760 + j * 32 + k];
+                float w = c * o[blob::W2 + j * 32 + k];
                 if (cfg->mlp_dtype == 1) w = f16_rtz_host(w);
                 sum = sum + w;
-                F[760 + j * 32 + k] = -2.0f * w;
+                F[blob::W2 + j * 32 + k] = -2.0f * w;
             }
-            F[1784 + j] = sum;
+            F[blob::B2 + j] = sum;
         }
         for (int i = 0; i < 6; ++i) {
-            float sum = o[2072 + i];
-            for (int k = 0; k < 32; ++k) { sum = sum + o[1816 + i * 32 + k]; F[1816 + i * 32 + k] = -2.0f * o[1816 + i * 32 + k]; }
-            F[2072 + i] = sum;
+            float sum = o[blob::B3 + i];
+            for (int k = 0; k < 32; ++k) { sum = sum + o[blob::W3 + i * 32 + k]; F[blob::W3 + i * 32 + k] = -2.0f * o[blob::W3 + i * 32 + k]; }
+            F[blob::B3 + i] = sum;
         }
         {
-            float sum = o[2112];
-            for (int k = 0; k < 32; ++k) { sum = sum + o[2080 + k]; F[2080 + k] = -2.0f * o[2080 + k]; }
-            F[2112] = sum;
+            float sum = o[blob::B3N];
+            for (int k = 0; k < 32; ++k) { sum = sum + o[blob::W3N + k]; F[blob::W3N + k] = -2.0f * o[blob::W3N + k]; }
+            F[blob::B3N] = sum;
         }
-        for (int i = 0; i < 32 * 32; ++i) V[760 + i] = 4.0f * o[760 + i];
-        for (int i = 0; i < 6 * 32; ++i) V[1816 + i] = 4.0f * o[1816 + i];
-        for (int k = 0; k < 32; ++k) V[2080 + k] = 4.0f * o[2080 + k];
+        for (int i = 0; i < 32 * 32; ++i) V[blob::W2 + i] = 4.0f * o[blob::W2 + i];
+        for (int i = 0; i < 6 * 32; ++i) V[blob::W3 + i] = 4.0f * o[blob::W3 + i];
+        for (int k = 0; k < 32; ++k) V[blob::W3N + k] = 4.0f * o[blob::W3N + k];
         h->blob_f = F;
         h->blob_f.insert(h->blob_f.end(), V.begin(), V.end());
     }
     // tables (SPEC.md §5: float32 host arithmetic)
-    const float* sigma = f + 48;
+    const float* sigma = f + blob::SIGMA;
     h->h_sdt.resize((size_t)h->H * SDEMPC_NNOISE);
     for (int t = 0; t < h->H; ++t) {
         float sq = sqrtf(h->time_steps[t]);
@@ -475,9 +476,8 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     a.M.ct2 = f[8]; a.M.ct1 = f[9]; a.M.ct0 = f[10]; a.M.cm2 = f[11]; a.M.cm1 = f[12];
     for (int j = 0; j < 8; ++j) { a.M.rx[j] = f[16 + j]; a.M.ry[j] = f[24 + j]; a.M.dir[j] = f[32 + j]; }
     for (int i = 0; i < 3; ++i) { a.M.sF[i] = f[40 + i]; a.M.sT[i] = f[43 + i]; }
-    const int off_b3 = 56 + 384 + 64 + 256 + 1024 + 32 + 256;
-    for (int i = 0; i < 6; ++i) a.M.b3[i] = h->blob_f[off_b3 + i];      // (math_mode fast: the forward block's, SPEC.md §10b)
-    a.M.b3n = h->blob_f[off_b3 + 8 + 32];
+    for (int i = 0; i < 6; ++i) a.M.b3[i] = h->blob_f[blob::B3 + i];      // (math_mode fast: the forward block's, SPEC.md §10b)
+    a.M.b3n = h->blob_f[blob::B3N];
     for (int i = 0; i < 3; ++i) { a.C.perr[i] = cfg->perr[i]; a.C.verr[i] = cfg->verr[i]; a.C.qerr[i] = cfg->qerr[i]; a.C.werr[i] = cfg->werr[i]; }
     a.C.res_mult = cfg->res_mult; a.C.uerr = cfg->uerr; a.C.slew = cfg->u_slew_coeff; a.C.slew_cc = cfg->u_slew_constr_coeff;
     a.C.has_sc = cfg->has_slew_constr;

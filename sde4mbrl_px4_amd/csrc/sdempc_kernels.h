@@ -6,6 +6,15 @@
 
 namespace sdempc {
 
+// float payload of the model blob (SPEC.md §2; include/sdempc.h: SDEMPC_BLOB_FLOATS), offsets in floats — one statement for the kernels and for sdempc_create
+namespace blob {
+constexpr int SF = 40;                   // sF[3], sT[3]
+constexpr int SIGMA = 48;
+constexpr int W1Z = 56, B1 = W1Z + 64 * 6, W1U = B1 + 64, W2 = W1U + 32 * 8, B2 = W2 + 32 * 32, W3 = B2 + 32, B3 = W3 + 8 * 32, W3N = B3 + 8, B3N = W3N + 32;
+constexpr int FLOATS = B3N + 8;
+static_assert(FLOATS == 2120, "include/sdempc.h: SDEMPC_BLOB_FLOATS");
+}
+
 struct ModelK {  // physics prior + small output-layer constants (SPEC.md §2), passed in SGPRs
     float inv_mass, grav, J[3], iJ[3], ct2, ct1, ct0, cm2, cm1;
     float rx[8], ry[8], dir[8];

@@ -223,9 +223,9 @@ inline size_t smem_bytes(int H, int m, int ipb, bool coop = false, bool ust_lds 
 }
 
 // blob float payload offsets (SPEC.md §2)
-constexpr int OFF_SF = 40;     // sF[3], sT[3]
-constexpr int OFF_W1Z = 56, OFF_B1 = OFF_W1Z + 384, OFF_W1U = OFF_B1 + 64, OFF_W2 = OFF_W1U + 256, OFF_B2 = OFF_W2 + 1024,
-              OFF_W3 = OFF_B2 + 32, OFF_B3 = OFF_W3 + 256, OFF_W3N = OFF_B3 + 8, OFF_B3N = OFF_W3N + 32;
+constexpr int OFF_SF = blob::SF;     // sF[3], sT[3]
+constexpr int OFF_W1Z = blob::W1Z, OFF_B1 = blob::B1, OFF_W1U = blob::W1U, OFF_W2 = blob::W2, OFF_B2 = blob::B2,
+              OFF_W3 = blob::W3, OFF_B3 = blob::B3, OFF_W3N = blob::W3N, OFF_B3N = blob::B3N;
 
 // math_mode fast (SPEC.md §10b): the blob is two blocks of this layout — [0]: what the forward pass uses (pre-scale and affine map of the hardware
 // activation folded in), [VJP_BASE]: what the vector-Jacobian products use (W1z, W1u as given; 4 W2, 4 W3, 4 w3n). One block otherwise.

@@ -589,6 +589,41 @@ def test_transcendental_instructions_match_their_model():
         assert bad.size == 0, (func, [(hex(xb[i]), hex(hw[i]), hex(model[i])) for i in bad[:5]])
 
 
+def test_binary16_limb_split_instructions_match_their_statement():
+    """SPEC.md §10c rests on two instructions: v_cvt_pk_f16_f32 (round to nearest even to binary16, sub-normals kept, in the kernels' FP mode) and
+    v_fma_mix_f32 (x - (float)limb, exact). The split as the kernels write it (tools/transc_study/libtransc.so) against IEEE binary16 rounding (NumPy)
+    on 16 million values of the activation range [0, 1], the weights' range, every binary16 boundary case and anything else."""
+    import ctypes
+    import torch
+    so = os.path.join(os.path.dirname(CDIR), "tools", "transc_study", "libtransc.so")
+    if not os.path.exists(so):
+        pytest.skip("tools/transc_study/libtransc.so not built (python __graft_entry__.py builds it)")
+    L = ctypes.CDLL(so)
+    if not hasattr(L, "transc_split2h"):
+        pytest.skip("libtransc.so predates the limb-split probe")
+    L.transc_split2h.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+    rng = np.random.default_rng(9)
+    N = 1 << 22
+    x = np.concatenate([rng.random(N, dtype=np.float32), (1.0 / (1.0 + np.exp2(8 * rng.standard_normal(N)))).astype(np.float32),     # activations r
+                        (6 * rng.standard_normal(N) / np.sqrt(32)).astype(np.float32),                                                  # forward weights
+                        np.exp2(-rng.uniform(0, 40, N)).astype(np.float32),                                                           # down into the sub-normal limbs and below
+                        np.array([0.0, 1.0, 0.5, 2.0 ** -14, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * 1.000001, 2.0 ** -26, 65504.0, 65519.0, 1.0009765, 1.00048828125, 1.00146484375,
+                                  0.33325195, 6.1e-5, 6.0975e-5, -0.75, -2.0 ** -24], np.float32)])
+    if x.size & 1: x = x[:-1]
+    xin = torch.from_numpy(x.view(np.int32).copy()).cuda()
+    out = torch.empty_like(xin)
+    assert L.transc_split2h(xin.data_ptr(), x.size // 2, out.data_ptr()) == 0
+    o = out.cpu().numpy().view(np.uint32).reshape(-1, 2)
+    l1 = np.stack([o[:, 0] & 0xFFFF, o[:, 0] >> 16], axis=1).reshape(-1).astype(np.uint16)       # low half: the first value of the pair
+    l2 = np.stack([o[:, 1] & 0xFFFF, o[:, 1] >> 16], axis=1).reshape(-1).astype(np.uint16)
+    w1 = x.astype(np.float16)
+    w2 = (x - w1.astype(np.float32)).astype(np.float16)
+    assert np.array_equal(l1, w1.view(np.uint16)) and np.array_equal(l2, w2.view(np.uint16))
+    # and the pair represents the value to 2^-22 of it at worst (sub-normal second limbs: to 2^-25 absolute)
+    rec = w1.astype(np.float64) + w2.astype(np.float64)
+    assert np.all(np.abs(rec - x.astype(np.float64)) <= np.maximum(np.abs(x.astype(np.float64)) * 2.0 ** -22, 2.0 ** -25))
+
+
 # ---- the latency layouts on full-length solves (hundreds of phases: hits, misses, third / fourth trials) ---------------------------
 @pytest.mark.parametrize("cfg_name,iters", [("c2_iris_traj_h50_p128.yaml", 200), ("c1_iris_posctrl_h20_p32.yaml", 100), ("iris_traj_shipped_h20_p1.yaml", 200)])
 def test_single_instance_full_length_solve_bit_exact(cfg_name, iters, layout):

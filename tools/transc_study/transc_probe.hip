@@ -28,6 +28,20 @@ __global__ void array_kernel(const uint32_t* __restrict__ in, uint64_t n, uint32
     out[i] = __float_as_uint(hw<F>(__uint_as_float(in[i])));
 }
 
+// SPEC.md §10c: the two-limb binary16 split of a pair of values as the kernels write it — v_cvt_pk_f16_f32 (round and pack), two v_fma_mix_f32 (the residuals
+// x - (float)limb straight from the packed halves), v_cvt_pk_f16_f32 again; out[2 i] = the packed first limbs of (in[2 i], in[2 i + 1]), out[2 i + 1] the second limbs
+__global__ void split2h_kernel(const uint32_t* __restrict__ in, uint64_t npairs, uint32_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    const float x = __uint_as_float(in[2 * i]), y = __uint_as_float(in[2 * i + 1]);
+    unsigned p1, p2; float xr, yr;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(x), "v"(y));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(xr) : "v"(p1), "v"(x));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(yr) : "v"(p1), "v"(y));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p2) : "v"(xr), "v"(yr));
+    out[2 * i] = p1; out[2 * i + 1] = p2;
+}
+
 // the wave's MODE register (FP round / denorm fields), as the kernels see it
 __global__ void mode_kernel(uint32_t* out) {
     uint32_t m;
@@ -48,6 +62,12 @@ int transc_eval_range(int func, uint64_t start, uint64_t stride, uint64_t n, uin
         case 3: range_kernel<3><<<blocks, 256>>>(start, stride, n, out_dev); break;
         default: return -1;
     }
+    return (int)hipDeviceSynchronize();
+}
+
+int transc_split2h(const uint32_t* in_dev, uint64_t npairs, uint32_t* out_dev) {
+    if (npairs == 0) return 0;
+    split2h_kernel<<<(unsigned)((npairs + 255) / 256), 256>>>(in_dev, npairs, out_dev);
     return (int)hipDeviceSynchronize();
 }
 

@@ -1,6 +1,8 @@
 """Algorithmic work of one MPC solve and the two rooflines bench.py reports."""
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 F32_MFMA_PEAK_TF = 157.3     # dense f32-input MFMA peak (= f32 vector peak), same guide
+F32_SCALAR_VALU_PEAK_TF = 78.6   # what the vector ALUs reach WITHOUT packed-f32 instructions (one fma per lane per cycle: 256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz);
+                                 # the 157.3 figure needs v_pk_fma_f32 throughout, which this kernel measured as a loss (csrc/Makefile)
 F16_MFMA_PEAK_TF = 2500.0    # dense f16 / bf16 matrix peak, same guide
 
 

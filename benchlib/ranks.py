@@ -75,3 +75,40 @@ def spawn_ranks(n, script, argv, watchdog_s=None):
     for log in logs:
         log.close()
     return rc
+
+
+def fingerprint(data) -> int:
+    """64 bits of sha256 as a signed integer (what fits an int64 collective)"""
+    import hashlib
+    if isinstance(data, str):
+        data = data.encode()
+    return int.from_bytes(hashlib.sha256(bytes(data)).digest()[:8], "little", signed=True)
+
+
+def ranks_that_disagree(rows):
+    """rows: per-rank lists of fingerprints (gather_int64). Returns {column: [ranks whose value is not the one most ranks hold]} for the columns
+    that are not unanimous (ties: the value rank 0 holds counts as the common one)."""
+    bad = {}
+    for c in range(len(rows[0])):
+        col = [r[c] for r in rows]
+        if len(set(col)) > 1:
+            counts = {}
+            for v in col:
+                counts[v] = counts.get(v, 0) + 1
+            best = max(counts.values())
+            common = col[0] if counts[col[0]] == best else next(v for v in col if counts[v] == best)
+            bad[c] = [r for r, v in enumerate(col) if v != common]
+    return bad
+
+
+def require_same_on_every_rank(named, device=None, force=False):
+    """named: {what: bytes | str} held by THIS rank (the model blob it received, the build of the library it loaded). Every rank compares every
+    rank's fingerprints; a rank holding something else than the others is an error of the whole run, raised on every rank with the rank named."""
+    from sde4mbrl_px4_amd.dist import gather_int64
+    names = list(named)
+    rows = gather_int64([fingerprint(named[k]) for k in names], device=device, force=force)
+    bad = ranks_that_disagree(rows)
+    if bad:
+        what = "; ".join(f"{names[c]}: rank(s) {rs} hold another one than the other ranks" for c, rs in bad.items())
+        raise SystemExit(f"bench.py: the ranks do not run the same job — {what}")
+    return {k: rows[0][i] & 0xFFFFFFFFFFFFFFFF for i, k in enumerate(names)}

@@ -130,6 +130,12 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
 void sdempc_destroy(sdempc_handle* h);
 const char* sdempc_last_error(const sdempc_handle* h);   /* h may be NULL: last create error */
 int sdempc_abi_version(void);
+/* What the library was built with (no reference counterpart). Bit 0 (SDEMPC_BUILD_ALL_VARIANTS): the build carries every kernel instantiation
+ * (`make EXTRA=-DSDEMPC_ALL_VARIANTS=1`): the generic motor count (m other than 4 / 6) in the duo / six-team / cooperative / speculative layouts
+ * too, and the packed-tanh instantiations behind SDEMPC_OPT_PK = 1. The default build runs a generic motor count in the one-group-per-wave tile
+ * layouts (and P = 1 in the lane layout) and refuses SDEMPC_OPT_PK = 1; results never depend on the layout. */
+#define SDEMPC_BUILD_ALL_VARIANTS 1
+int sdempc_build_flags(void);
 
 /* Binds the handle to a HIP device ordinal (default 0). Must precede the first device call. */
 int sdempc_set_device(sdempc_handle* h, int32_t device);
@@ -158,6 +164,9 @@ int sdempc_device_ready(const sdempc_handle* h);
  *   SDEMPC_OPT_COOP_SPIN_US   -1 derived / >= 0 microseconds -1       SDEMPC_COOP_SPIN_US  how long one grid barrier of a cooperative layout may wait
  *                                                                                          before the launch gives up (derived: 5 x the handle's last completed
  *                                                                                          cooperative solve, clamped to 2..100 ms; 100 ms before the first)
+ *   SDEMPC_OPT_TEST_ABSENT_WG -1 none / >= 0 workgroup index -1       (none)               FAULT INJECTION for the tests of the bounded waits: that workgroup of a
+ *                                                                                          cooperative-layout grid leaves at once, as a workgroup that never became
+ *                                                                                          resident would; the launch then gives up within its spin budget
  *   SDEMPC_OPT_DEVICE_CUS     read-only                                                    compute units of the handle's device (after the first device call)
  */
 #define SDEMPC_OPT_LANE 1
@@ -171,6 +180,7 @@ int sdempc_device_ready(const sdempc_handle* h);
 #define SDEMPC_OPT_DEVICE_CUS 9
 #define SDEMPC_OPT_DUO 10
 #define SDEMPC_OPT_HEX 11
+#define SDEMPC_OPT_TEST_ABSENT_WG 12
 int sdempc_set_option(sdempc_handle* h, int32_t key, int32_t value);
 int sdempc_get_option(const sdempc_handle* h, int32_t key, int32_t* value);
 

@@ -458,6 +458,9 @@ class Restatement:
                 b3n = F(b3n + M.w3n[k])
             M.W1z, M.b1, M.W1u = W1z, (c * M.b1).astype(F), (c * M.W1u).astype(F)
             M.W2, M.b2 = (F(-2) * cW2).astype(F), b2
+            if self.mlp == "f16":                    # the re-quantised c w is what the forward pass evaluates: its derivative uses those weights (§10b)
+                self.V["W1z"] = (M.W1z / c).astype(F)
+                self.V["W2"] = ((F(-2) * M.W2).astype(F) / c).astype(F)
             M.W3, M.b3, M.w3n, M.b3n = (F(-2) * M.W3).astype(F), b3, (F(-2) * M.w3n).astype(F), b3n
         self.dt = np.asarray(cfg.time_steps, F)
         self.sdt = np.stack([self.M.sigma * F(np.sqrt(F(d))) for d in self.dt]).astype(F)       # sigma_i * sqrtf(dt_t), host float32

@@ -307,7 +307,7 @@ void NAME(contract32)(int mode, const float* W, const float* v, const float* c, 
 static inline void act_tanh4(const model_t* M, const preal* x, preal* y) {
 #ifdef ORC_MFMA16
     if (M->fast) {
-        for (int i = 0; i < 4; ++i) y[i] = orc_hw_rcp(1.0f + orc_hw_exp2(x[i]));       /* SPEC.md §10b: r, with tanh = 1 - 2 r folded into the weights */
+        orc_hw_sigm4(x, y);       /* SPEC.md §10b: r_i = v_rcp_f32(1 + v_exp_f32(x_i)), with tanh = 1 - 2 r folded into the weights */
         return;
     }
 #endif
@@ -400,6 +400,10 @@ static int parse_blob(const void* blob, model_t* M, int f16, int fast) {
         for (int j = 0; j < HID; ++j) for (int k = 0; k < HID; ++k) M->vW2[j][k] = 4.0f * M->vW2[j][k];
         for (int i = 0; i < 6; ++i) for (int k = 0; k < HID; ++k) M->vW3[i][k] = 4.0f * M->vW3[i][k];
         for (int k = 0; k < HID; ++k) M->vw3n[k] = 4.0f * M->vw3n[k];
+        if (f16 == 1) {         /* the forward pass evaluates the re-quantised c * w: the vector-Jacobian products differentiate those weights (SPEC.md §10b) */
+            for (int r = 0; r < 2 * HID; ++r) for (int k = 0; k < NN; ++k) M->vW1z[r][k] = M->W1z[r][k] / c;
+            for (int j = 0; j < HID; ++j) for (int k = 0; k < HID; ++k) M->vW2[j][k] = (-2.0f * M->W2[j][k]) / c;
+        }
     }
     if (f16 == 1) {
         for (int r = 0; r < 2 * HID; ++r) for (int k = 0; k < 16; ++k) orc_mfma16_decode(0, k < NN ? f16_bits(M->W1z[r][k]) : 0, &M->h1[r][k]);
@@ -900,6 +904,13 @@ static real ucost(const ctx_t* X, const real* u, real* gcu) {
     return dot256(ce, NULL, N);
 }
 
+/* Particles are independent between the reductions (each writes its own rows of traj / Jp / Q; the sums of SPEC.md §6 are formed afterwards in their
+ * fixed order), so the particle loops below may be spread over threads without changing a bit: NAME(set_threads)(n), default 1 (bench.py's verifier
+ * runs one solve per thread instead; the golden generators of the long configurations and a lone solve use n = cores). Needs -fopenmp (oracle/Makefile);
+ * without it the pragmas are ignored and the loops are serial. */
+static int g_threads = 1;
+void NAME(set_threads)(int n) { g_threads = n < 1 ? 1 : n; }
+
 /* rollout: expected cost; optional traj [P][H+1][13], xmean [H+1][13] (SPEC.md §5.3, §7) */
 static real rollout(const ctx_t* X, const real* x0, const real* u, const real* xref, const real* noise,
                     real* traj, real* xmean) {
@@ -908,10 +919,11 @@ static real rollout(const ctx_t* X, const real* x0, const real* u, const real* x
     for (int t = 0; t < H; ++t) ustep_eval(&X->M, u + t * m, &U[t]);
     real* Jp = X->wsJp;
     real* xs = xmean ? X->wsXs : NULL;
-    stepaux_t A;
     const size_t ps = (size_t)(H + 1) * NX;                 /* particle stride of traj / xs */
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int p = 0; p < P; p += VL) {                        /* one block of VL particles (VL = 1 in the checker builds) */
         const int n = P - p < VL ? P - p : VL;
+        stepaux_t A;
         preal x[NX], xn[NX], xi[NN];
         for (int i = 0; i < NX; ++i) x[i] = pbroadcast(x0[i]);
         real* tp = traj ? traj + (size_t)p * ps : NULL;
@@ -954,10 +966,11 @@ static real cost_grad(const ctx_t* X, const real* x0, const real* u, const real*
     /* per-particle, per-step adjoint outputs: [H][m+4][P] */
     int nq = m + 4;
     real* Q = X->wsQ;
-    stepaux_t A;
     const size_t ps = (size_t)(H + 1) * NX;                 /* particle stride of traj */
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int p = 0; p < P; p += VL) {                        /* one block of VL particles (VL = 1 in the checker builds) */
         const int n = P - p < VL ? P - p : VL;
+        stepaux_t A;
         real* tp = traj + (size_t)p * ps;
         preal x[NX], xn[NX], xi[NN];
         for (int i = 0; i < NX; ++i) { x[i] = pbroadcast(x0[i]); pstore(tp + i, ps, n, x[i]); }

@@ -59,7 +59,7 @@ class SdempcInfo(C.Structure):
 INFO_FIELDS = [f[0] for f in SdempcInfo._fields_]
 
 # execution options of a handle (include/sdempc.h, SDEMPC_OPT_*)
-OPTIONS = {"lane": 1, "coop": 2, "spec": 3, "pk": 4, "ustg": 5, "coop_launch": 6, "coop_fence": 7, "coop_spin_us": 8, "device_cus": 9, "duo": 10, "hex": 11}
+OPTIONS = {"lane": 1, "coop": 2, "spec": 3, "pk": 4, "ustg": 5, "coop_launch": 6, "coop_fence": 7, "coop_spin_us": 8, "device_cus": 9, "duo": 10, "hex": 11, "test_absent_wg": 12}
 
 ABI_VERSION = 2          # include/sdempc.h: SDEMPC_ABI_VERSION (the layout of SdempcCfg / SdempcInfo below)
 
@@ -97,6 +97,7 @@ def load_library():
     if got != ABI_VERSION:       # a stale build (or an SDEMPC_LIB override made against an older header) would read SdempcCfg past its end
         raise RuntimeError(f"{path} reports ABI version {got}, this package's struct layouts are version {ABI_VERSION} "
                            "(include/sdempc.h: SDEMPC_ABI_VERSION): rebuild the library (make -C sde4mbrl_px4_amd/csrc)")
+    lib.sdempc_build_flags.restype = C.c_int
     lib.sdempc_set_device.argtypes = [vp, i32]
     lib.sdempc_device_ready.argtypes = [vp]
     lib.sdempc_device_ready.restype = C.c_int
@@ -142,7 +143,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "sdempc_create", "sdempc_destroy", "sdempc_last_error", "sdempc_abi_version", "sdempc_set_device", "sdempc_device_ready", "sdempc_set_option", "sdempc_get_option", "sdempc_reset",
+    "sdempc_create", "sdempc_destroy", "sdempc_last_error", "sdempc_abi_version", "sdempc_build_flags", "sdempc_set_device", "sdempc_device_ready", "sdempc_set_option", "sdempc_get_option", "sdempc_reset",
     "sdempc_rollout_batch", "sdempc_grad_batch", "sdempc_solve_batch", "sdempc_noise_dev_floats",
     "sdempc_traj_dev_floats", "sdempc_noise_to_device_layout", "sdempc_solve_batch_dev", "sdempc_rollout_batch_dev",
     "sdempc_grad_batch_dev", "sdempc_last_kernel_ms", "sdempc_last_kernel_name", "sdempc_work_counters", "sdempc_solve_status", "sdempc_layout_fallbacks", "sdempc_noise_to_device_layout_dev", "sdempc_traj_to_canonical_dev",

@@ -145,6 +145,7 @@ void default_options(sdempc_handle* h) {
     o.coop_launch = env_int("SDEMPC_COOP_LAUNCH", 0, 0, 1);
     o.coop_fence = env_int("SDEMPC_COOP_FENCE", 0, 0, 1);
     o.hex = env_int("SDEMPC_HEX", 1, 0, 1);
+    o.absent_wg = -1;                                  // fault injection is a per-handle option only (SDEMPC_OPT_TEST_ABSENT_WG): never from the environment
     h->spin_us = env_int("SDEMPC_COOP_SPIN_US", -1, -1, 10 * 1000 * 1000);
 }
 // Budget of one grid barrier of the cooperative layouts, in 10 ns ticks (KArgs::coop_spin). A barrier is passed ~780 times per C2
@@ -370,6 +371,7 @@ int solve_staged(sdempc_handle* h, int32_t B, float* uopt, float* xevol, sdempc_
 extern "C" {
 
 int sdempc_abi_version(void) { return SDEMPC_ABI_VERSION; }
+int sdempc_build_flags(void) { return SDEMPC_ALL_VARIANTS ? SDEMPC_BUILD_ALL_VARIANTS : 0; }
 
 const char* sdempc_last_error(const sdempc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
@@ -445,6 +447,12 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
         for (int i = 0; i < 32 * 32; ++i) V[blob::W2 + i] = 4.0f * o[blob::W2 + i];
         for (int i = 0; i < 6 * 32; ++i) V[blob::W3 + i] = 4.0f * o[blob::W3 + i];
         for (int k = 0; k < 32; ++k) V[blob::W3N + k] = 4.0f * o[blob::W3N + k];
+        if (cfg->mlp_dtype == 1) {
+            // mlp_dtype f16 quantises c * w once more (toward zero), so the forward pass evaluates the weights F / c, not the Wq the blob held:
+            // the vector-Jacobian products differentiate what was evaluated (SPEC.md §10b, last item of "Adjoint")
+            for (int i = 0; i < 64 * 6; ++i) V[blob::W1Z + i] = F[blob::W1Z + i] / c;
+            for (int i = 0; i < 32 * 32; ++i) V[blob::W2 + i] = (-2.0f * F[blob::W2 + i]) / c;
+        }
         h->blob_f = F;
         h->blob_f.insert(h->blob_f.end(), V.begin(), V.end());
     }
@@ -544,12 +552,18 @@ int sdempc_set_option(sdempc_handle* h, int32_t key, int32_t value) {
         case SDEMPC_OPT_LANE: return flag(o.lane);
         case SDEMPC_OPT_COOP: { int rc = flag(o.coop); if (rc == SDEMPC_OK && value == 1) h->coop_off = false; return rc; }
         case SDEMPC_OPT_SPEC: return flag(o.spec);
-        case SDEMPC_OPT_PK: return tri(o.pk);
+        case SDEMPC_OPT_PK:
+            if (value == 1 && !SDEMPC_ALL_VARIANTS) return fail(h, SDEMPC_EINVAL, "this build carries no packed-tanh instantiations (make EXTRA=-DSDEMPC_ALL_VARIANTS=1)%s");
+            return tri(o.pk);
         case SDEMPC_OPT_USTG: return tri(o.ustg);
         case SDEMPC_OPT_DUO: return tri(o.duo);
         case SDEMPC_OPT_COOP_LAUNCH: return flag(o.coop_launch);
         case SDEMPC_OPT_COOP_FENCE: return flag(o.coop_fence);
         case SDEMPC_OPT_HEX: return flag(o.hex);
+        case SDEMPC_OPT_TEST_ABSENT_WG:
+            if (value < -1) return fail(h, SDEMPC_EINVAL, "absent workgroup must be -1 (none) or a workgroup index%s");
+            o.absent_wg = value;
+            return SDEMPC_OK;
         case SDEMPC_OPT_COOP_SPIN_US:
             if (value < -1) return fail(h, SDEMPC_EINVAL, "spin budget must be -1 (derived) or >= 0 microseconds%s");
             h->spin_us = value;
@@ -573,6 +587,7 @@ int sdempc_get_option(const sdempc_handle* h, int32_t key, int32_t* value) {
         case SDEMPC_OPT_COOP_LAUNCH: *value = o.coop_launch; break;
         case SDEMPC_OPT_COOP_FENCE: *value = o.coop_fence; break;
         case SDEMPC_OPT_HEX: *value = o.hex; break;
+        case SDEMPC_OPT_TEST_ABSENT_WG: *value = o.absent_wg; break;
         case SDEMPC_OPT_COOP_SPIN_US: *value = h->spin_us >= 0 ? h->spin_us : (int32_t)(coop_spin_ticks(h) / 100u); break;
         case SDEMPC_OPT_DEVICE_CUS: *value = o.cus; break;
         default: return SDEMPC_EINVAL;

@@ -44,8 +44,9 @@ DI void coop_barrier(CoopCtx& C, int tid) {
         const unsigned long long* both = reinterpret_cast<const unsigned long long*>(C.bar);
         for (;;) {
             const unsigned long long w = __hip_atomic_load(both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((unsigned)w >= target || (unsigned)(w >> 32) != 0u) break;      // everyone arrived / another workgroup gave up
-            if (__builtin_amdgcn_s_memrealtime() - t0 >= (uint64_t)C.spin_limit) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((unsigned)w >= target) break;                                   // everyone arrived
+            if ((unsigned)(w >> 32) != 0u) { C.spin_limit = 0; break; }          // another workgroup gave up: no further waiting in this kernel
+            if (__builtin_amdgcn_s_memrealtime() - t0 >= (uint64_t)C.spin_limit) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); C.spin_limit = 0; break; }
         }
         if (C.fence) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -53,6 +54,26 @@ DI void coop_barrier(CoopCtx& C, int tid) {
         }
     }
     __syncthreads();
+}
+
+// Wait of a tagged hand-off (a 64-bit word {value, tag}; the datum is its own flag: sdempc_spec.inc.h, coop_cost_grad): until the word carries
+// `tag`, bounded like a grid barrier — and, like coop_barrier, over as soon as ANY workgroup of the grid has given up: the error flag is looked at
+// on every eighth unsuccessful poll (a wait of a healthy launch ends within a handful of polls, so it never pays for that load), and a thread that
+// saw the flag or ran out of budget itself stops waiting for the rest of the kernel (C.spin_limit = 0: every later wait of this thread ends on its
+// first unsuccessful poll). Without it every reduction phase behind a missing producer waited a full budget: up to 200 x 100 ms per C2 solve
+// instead of one budget (the results are invalid from the first give-up on: the telemetry is poisoned with NaN, sdempc_solve_status reports it).
+DI float tagged_wait(CoopCtx& C, const unsigned long long* p, unsigned tag, uint64_t t0w) {
+    unsigned long long v;
+    unsigned polls = 0;
+    while ((unsigned)((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != tag) {
+        if (__builtin_amdgcn_s_memrealtime() - t0w >= (uint64_t)C.spin_limit) {
+            __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            C.spin_limit = 0;
+            break;
+        }
+        if ((++polls & 7u) == 0u && __hip_atomic_load(C.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { C.spin_limit = 0; break; }
+    }
+    return __uint_as_float((unsigned)v);
 }
 
 // total of quantity q over the particles: SPEC.md §6.1 (32-particle butterflies, slots g mod 4 in ascending g, ((S0+S1)+S2)+S3);
@@ -135,13 +156,7 @@ DI float coop_cost_grad(const KArgs& a, const Smem& sm, const LaneW& W, CoopCtx&
             if (lane == 0) __hip_atomic_store(gt + q, tag | (unsigned long long)__float_as_uint(sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
-        auto tagged = [&](const unsigned long long* pw) {
-            unsigned long long v;
-            while ((unsigned)((v = __hip_atomic_load(pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != C.epoch) {
-                if (__builtin_amdgcn_s_memrealtime() - t0w >= (uint64_t)C.spin_limit) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-            return __uint_as_float((unsigned)v);
-        };
+        auto tagged = [&](const unsigned long long* pw) { return tagged_wait(C, pw, C.epoch, t0w); };
         for (int q = tid; q < H * 12; q += Team::NT)
             if ((q % 12) < nq) sm.tot[q] = tagged(gt + q);
         if (tid == 0) sm.red[12] = tagged(gt + PS - 1);

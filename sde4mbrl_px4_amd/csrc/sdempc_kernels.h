@@ -4,6 +4,15 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// Which instantiations a build carries (DESIGN.md §2 "Instantiation set"). The default build holds what a handle with default options can be
+// dispatched to for the reference's vehicles (m = 4 Iris, m = 6 Hexa) in every layout, plus the GENERIC motor count (the 8-slot, zero-padded
+// instantiation: any m <= 8) in the one-group-per-wave tile layouts and the single-particle lane layout only. `make EXTRA=-DSDEMPC_ALL_VARIANTS=1`
+// adds the generic motor count in the duo / six-team / cooperative / speculative layouts and the packed-f32 tanh instantiations of the exact tile
+// layout (SDEMPC_OPT_PK; TeamBlock8): + 91 solve kernels, + 10 MB, + 7 CPU-minutes (tests/tools/soak.py draws them when they are there).
+#ifndef SDEMPC_ALL_VARIANTS
+#define SDEMPC_ALL_VARIANTS 0
+#endif
+
 namespace sdempc {
 
 // float payload of the model blob (SPEC.md §2; include/sdempc.h: SDEMPC_BLOB_FLOATS), offsets in floats — one statement for the kernels and for sdempc_create
@@ -46,6 +55,7 @@ struct LaunchOpts {
     int coop_launch;   // 1: hipLaunchCooperativeKernel for the cooperative layouts, 0: plain launch of a grid sized to be resident (default)
     int duo;           // throughput launches in the duo tile layout (64 particles per wave): -1 auto (= on for multi-group instances), 0 off, 1 on
     int coop_fence;    // 1: agent-scope release / acquire fences around the grid barrier, 0: sc1 write-through hand-off only (default)
+    int absent_wg;     // fault injection (tests): >= 0: that workgroup of a cooperative-layout grid leaves at once, as if it had never become resident; -1 (default): none
     int hex;           // 1: launches that fill every two-wave team slot of the device run one six-team workgroup per CU (default), 0: two-team workgroups always
 };
 struct KArgs {

@@ -805,6 +805,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     load_weights(a, sm, ww, threadIdx.x, Team::BNT);                                 \
     __syncthreads();                                                                 \
     if (b >= a.B) return; /* no workgroup-wide barrier below this line in TeamWave */ \
+    if constexpr (MODE == 2) { if ((int)blockIdx.x == a.opt.absent_wg) return; } /* fault injection: SDEMPC_OPT_TEST_ABSENT_WG */ \
     if constexpr (MODE == 1) load_lane_weights(a, LW, threadIdx.x & 63);              \
     load_common<Team>(a, sm, b, tid);                                                \
     if constexpr (MODE == 2) {                                                       \
@@ -1017,13 +1018,20 @@ __global__ void __launch_bounds__(Team::BNT, (MODE == 2 && PK ? 1 : (MODE == 1 |
 #define SDEMPC_DUO_M(X, TEAM, M)                                                                                   \
     X(TEAM, M, 0, 3, false) X(TEAM, M, 1, 3, false) X(TEAM, M, 2, 3, false) X(TEAM, M, 0, 3, true) X(TEAM, M, 1, 3, true) X(TEAM, M, 2, 3, true)  \
     X(TEAM, M, 0, 4, true) X(TEAM, M, 1, 4, true) X(TEAM, M, 2, 4, true)
-#define SDEMPC_DUO_TEAM(X, TEAM) SDEMPC_DUO_M(X, TEAM, 4) SDEMPC_DUO_M(X, TEAM, 6) SDEMPC_DUO_M(X, TEAM, 8)
+#if SDEMPC_ALL_VARIANTS
+#define SDEMPC_DUO_M8(X, TEAM) SDEMPC_DUO_M(X, TEAM, 8)
+#define SDEMPC_DUO_T8(X, TEAM) X(TEAM, 8, 0, 3, false) X(TEAM, 8, 1, 3, false) X(TEAM, 8, 2, 3, false)
+#else
+#define SDEMPC_DUO_M8(X, TEAM)
+#define SDEMPC_DUO_T8(X, TEAM)
+#endif
+#define SDEMPC_DUO_TEAM(X, TEAM) SDEMPC_DUO_M(X, TEAM, 4) SDEMPC_DUO_M(X, TEAM, 6) SDEMPC_DUO_M8(X, TEAM)
 #define SDEMPC_DUO_PAIR(X)                                                                                          \
     X(TeamPair, 4, 0, 3, false) X(TeamPair, 4, 1, 3, false) X(TeamPair, 4, 2, 3, false) X(TeamPair, 6, 0, 3, false) X(TeamPair, 6, 1, 3, false) X(TeamPair, 6, 2, 3, false) \
-    X(TeamPair, 8, 0, 3, false) X(TeamPair, 8, 1, 3, false) X(TeamPair, 8, 2, 3, false)
+    SDEMPC_DUO_T8(X, TeamPair)
 #define SDEMPC_DUO_HEX(X)                                                                                           \
     X(TeamHex, 4, 0, 3, false) X(TeamHex, 4, 1, 3, false) X(TeamHex, 4, 2, 3, false) X(TeamHex, 6, 0, 3, false) X(TeamHex, 6, 1, 3, false) X(TeamHex, 6, 2, 3, false) \
-    X(TeamHex, 8, 0, 3, false) X(TeamHex, 8, 1, 3, false) X(TeamHex, 8, 2, 3, false)
+    SDEMPC_DUO_T8(X, TeamHex)
 #define SDEMPC_DUO_DECL(TEAM, M, F16, MODE, USTG) extern template __global__ void sdempc_solve_kernel<TEAM, M, F16, false, MODE, USTG>(KArgs);
 #define SDEMPC_DUO_DEF(TEAM, M, F16, MODE, USTG) template __global__ void sdempc_solve_kernel<TEAM, M, F16, false, MODE, USTG>(KArgs);
 
@@ -1161,20 +1169,32 @@ static hipError_t launch_duo_small(const KArgs& a, hipStream_t st) {
         return launch_persistent(sdempc_solve_kernel<TeamPair, M, F16, false, 3, false>, a, st, 4, TeamPair::BNT, true, 2);
     return launch_duo_m<TeamBlock2, M, F16>(a, st);
 }
+// motor counts whose instantiations exist in every layout: the reference's two vehicles; the generic 8-slot instantiation of the duo / six-team /
+// cooperative / speculative layouts only in an all-variants build (other motor counts otherwise run one group per wave: same bits)
+static bool every_layout_built(int m) { return m == 4 || m == 6 || SDEMPC_ALL_VARIANTS != 0; }
 template <int F16>
 static hipError_t launch_duo(const KArgs& a, hipStream_t st) {
     if (a.G <= 4) {
         if (a.m == 4) return launch_duo_small<4, F16>(a, st);
         if (a.m == 6) return launch_duo_small<6, F16>(a, st);
+#if SDEMPC_ALL_VARIANTS
         return launch_duo_small<8, F16>(a, st);
+#else
+        return hipErrorInvalidValue;      // (not reached: launch_solve_team asks every_layout_built)
+#endif
     }
     if (a.m == 4) return launch_duo_m<TeamBlock, 4, F16>(a, st);
     if (a.m == 6) return launch_duo_m<TeamBlock, 6, F16>(a, st);
+#if SDEMPC_ALL_VARIANTS
     return launch_duo_m<TeamBlock, 8, F16>(a, st);
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 // duo = auto, up to four groups: does a batch of B fit resident with one group per wave (launch_solve_team, solve_workspace_rows)?
 static bool one_group_per_wave_batch(const KArgs& a, int B) {
     if (a.opt.duo >= 0 || a.G > 4) return false;
+    if (!every_layout_built(a.m)) return false;
     const bool gtab = use_global_ust(a.H, a.m, a.opt) && a.ustg;
     size_t per_cu = (156 * 1024) / smem_bytes(a.H, a.m, 1, false, !gtab);
     if (per_cu > 3) per_cu = 3;
@@ -1182,6 +1202,7 @@ static bool one_group_per_wave_batch(const KArgs& a, int B) {
 }
 template <class Team, int F16>
 static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
+#if SDEMPC_ALL_VARIANTS
     if constexpr (F16 == 0 && !FAST) {
         // small-batch (latency) launches: one workgroup per CU at most -> a lone wave per SIMD is issue-bound -> packed tanh
         const int wgs = (a.B + Team::IPB - 1) / Team::IPB;
@@ -1199,18 +1220,21 @@ static hipError_t launch_solve_team(const KArgs& a, hipStream_t st) {
             return launch_k(sdempc_solve_kernel<Team, 8, 0, true>, a, st, Team::IPB);
         }
     }
+#endif
     if constexpr (Team::IPB == 1) {
         // auto: every multi-group instance (measured, same box: C2 +1.3 %, C3 +4.4 %, C5 +7.5 % over one group per wave)
         // Batches that one 32-particle group per wave holds resident at once (three four-wave workgroups per CU: B <= 3 x CUs at C2) run
         // that way: four waves per instance instead of the duo layout's two, i.e. the shorter chain per instance and twice the waves per
         // CU (same box, C2 f32x3: B = 1..256 149 against 245 ms per launch, 512 189 / 260, 768 273 / 306; from 1,024 on the duo layout's
         // 1,536 resident instances win: 383 / 343)
-        if (a.G >= 2 && a.opt.duo != 0 && !one_group_per_wave_batch(a, a.B)) return launch_duo<F16>(a, st);
+        if (a.G >= 2 && a.opt.duo != 0 && every_layout_built(a.m) && !one_group_per_wave_batch(a, a.B)) return launch_duo<F16>(a, st);
         // long horizons: with the control table in LDS only two workgroups fit a CU; without it three do (the kernel is built for three)
         if (use_global_ust(a.H, a.m, a.opt) && a.ustg) {
             if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16, false, 0, true>, a, st, 1, Team::BNT, false);
             if (a.m == 6) return launch_k(sdempc_solve_kernel<Team, 6, F16, false, 0, true>, a, st, 1, Team::BNT, false);
+#if SDEMPC_ALL_VARIANTS
             return launch_k(sdempc_solve_kernel<Team, 8, F16, false, 0, true>, a, st, 1, Team::BNT, false);
+#endif
         }
     }
     if (a.m == 4) return launch_k(sdempc_solve_kernel<Team, 4, F16>, a, st, Team::IPB);
@@ -1236,7 +1260,7 @@ static hipError_t launch_lane_m(int what, const KArgs& k, hipStream_t st) {
 // ---- cooperative latency path (f32 contractions; both math modes) ----
 int coop_nwg(int P) { return (P + 3) / 4; }
 int coop_max_instances(int P, int H, int m, const LaunchOpts& o) {
-    if (!o.coop || P < 2 || o.cus < 16) return 0;               // SDEMPC_OPT_COOP = 0 disables the path (A/B, tests)
+    if (!o.coop || P < 2 || o.cus < 16 || !every_layout_built(m)) return 0;               // SDEMPC_OPT_COOP = 0 disables the path (A/B, tests)
     if (smem_bytes(H, m, 1, true) > 160 * 1024) return 0;
     // every workgroup of the grid must be resident at once: the kernel is built for two waves per SIMD, i.e. two workgroups per CU
     // (its LDS footprint allows more); a margin of 16 workgroups is left
@@ -1247,7 +1271,7 @@ int coop_max_instances(int P, int H, int m, const LaunchOpts& o) {
 size_t coop_pp_floats(int H, int G) { return coop_pp_stride(H, G * 32); }
 size_t coop_ck_floats(int H, int P) { return (size_t)SPEC_CKS * P * (H + 1) * COOP_ROW; }
 int spec_max_instances(int P, int H, int m, const LaunchOpts& o) {
-    if (!o.spec || !o.coop) return 0;      // SDEMPC_OPT_SPEC / SDEMPC_OPT_COOP = 0; P == 1 is welcome here (one wave per workgroup is active)
+    if (!o.spec || !o.coop || !every_layout_built(m)) return 0;      // SDEMPC_OPT_SPEC / SDEMPC_OPT_COOP = 0; P == 1 is welcome here (one wave per workgroup is active)
     const size_t nv = (size_t)((H * m + 3) & ~3);
     if (smem_bytes(H, m, 1, true) + (SPEC_XV * nv + SPEC_MRED) * sizeof(float) > 160 * 1024) return 0;
     return o.cus / (2 * coop_nwg(P));                    // built for one workgroup per CU; at least two groups per instance
@@ -1288,7 +1312,11 @@ hipError_t launch_solve_spec(const KArgs& a, int B, hipStream_t st) {
     if (k.coop_ngrp > SPEC_GROUPS) k.coop_ngrp = SPEC_GROUPS;
     if (k.m == 4) return launch_spec_m<4>(k, st);
     if (k.m == 6) return launch_spec_m<6>(k, st);
+#if SDEMPC_ALL_VARIANTS
     return launch_spec_m<8>(k, st);
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 template <int M>
 static hipError_t launch_coop_m(const KArgs& k, hipStream_t st) {
@@ -1309,7 +1337,11 @@ hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st) {
     if (B < 1 || B > (coop_max_instances)(k.P, k.H, k.m, k.opt) || !k.coop_bar || !k.coop_pp || !k.coop_ck) return hipErrorInvalidValue;
     if (k.m == 4) return launch_coop_m<4>(k, st);
     if (k.m == 6) return launch_coop_m<6>(k, st);
+#if SDEMPC_ALL_VARIANTS
     return launch_coop_m<8>(k, st);
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 
 // Rows of the per-instance / per-slot workspaces (KArgs::traj, act, part, ustg) a solve launch of B instances touches: B for the
@@ -1317,12 +1349,14 @@ hipError_t launch_solve_coop(const KArgs& a, int B, hipStream_t st) {
 // per CU: 128-thread workgroups six per CU, or three four-wave workgroups of two teams). Mirrors the dispatch of launch_solve_team.
 int solve_workspace_rows(const KArgs& k, int B) {
     if (use_lane(k) || use_wave_team(k.G, k.H, k.m)) return B;
+#if SDEMPC_ALL_VARIANTS
     if (k.f16 == 0 && !FAST) {
         const bool pk = k.opt.pk >= 0 ? k.opt.pk == 1 : B <= k.opt.cus;
         if (pk) return B;
     }
+#endif
     if (one_group_per_wave_batch(k, B)) return B;      // (launch_solve_team: batches that fit resident with one group per wave)
-    if (k.G >= 2 && k.opt.duo != 0) {       // (team slots come in workgroups of up to two teams: an odd batch leaves the last slot idle but counted; six-team workgroups only run full)
+    if (k.G >= 2 && k.opt.duo != 0 && every_layout_built(k.m)) {       // (team slots come in workgroups of up to two teams: an odd batch leaves the last slot idle but counted; six-team workgroups only run full)
         const int slots = 6 * (k.opt.cus > 0 ? k.opt.cus : 256), even = (B + 1) & ~1;
         return even < slots ? even : slots;
     }

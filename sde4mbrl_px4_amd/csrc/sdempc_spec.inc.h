@@ -80,6 +80,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     load_weights(a, sm, ww, tid, Team::BNT);
     __syncthreads();
     if (b >= a.B) return;
+    if ((int)blockIdx.x == a.opt.absent_wg) return;      // fault injection (SDEMPC_OPT_TEST_ABSENT_WG): a workgroup that never became resident
     load_common<Team>(a, sm, b, tid);
     __syncthreads();
     lane2_stage<Team>(a, sm, b, C.wgi, tid);
@@ -201,11 +202,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             red_cnt += 1u;
             const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
             auto tagged = [&](const unsigned long long* p) {        // wait (bounded like a grid barrier) until the word carries this phase's tag
-                unsigned long long v;
-                while ((unsigned)((v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != red_cnt) {
-                    if (__builtin_amdgcn_s_memrealtime() - t0w >= (uint64_t)C.spin_limit) { __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                }
-                return __uint_as_float((unsigned)v);
+                return tagged_wait(C, p, red_cnt, t0w);
             };
             for (int q = tid; q < H * 12; q += Team::NT)
                 if ((q % 12) < nq) sm.tot[q] = tagged(gt + q);

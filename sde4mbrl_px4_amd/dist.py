@@ -76,3 +76,25 @@ def gather_rows(local: np.ndarray, device=None) -> np.ndarray:
     outs = [torch.zeros(pad.shape, dtype=torch.from_numpy(pad).dtype, device=device) for _ in range(d.get_world_size())]
     d.all_gather(outs, torch.from_numpy(pad).to(device) if device is not None else torch.from_numpy(pad))
     return np.concatenate([o.cpu().numpy()[:int(c.item())] for o, c in zip(outs, counts)], axis=0)
+
+
+def sum_over_ranks(values, device=None, force: bool = False):
+    """Element-wise integer sum over ranks (e.g. words of the timed launches that differ from the checker: must be 0 everywhere)."""
+    import torch
+    if not is_distributed(force):
+        return [int(v) for v in values]
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
+    return [int(v) for v in t.cpu().numpy()]
+
+
+def gather_int64(values, device=None, force: bool = False):
+    """Every rank's equally long list of 64-bit integers, in rank order, on every rank (fingerprints of what a rank holds, per-rank counts)."""
+    import torch
+    if not is_distributed(force):
+        return [[int(v) for v in values]]
+    d = _dist()
+    mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    outs = [torch.zeros_like(mine) for _ in range(d.get_world_size())]
+    d.all_gather(outs, mine)
+    return [[int(v) for v in o.cpu().numpy()] for o in outs]

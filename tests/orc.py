@@ -78,6 +78,13 @@ def lib():
     return _LIB
 
 
+def set_threads(n):
+    """Threads ONE solve / gradient / rollout of the checker spreads its particle loops over (oracle/sde_mpc_oracle.c: set_threads; same bits at any
+    count). Process-wide, default 1: callers that run one solve per Python thread (bench.py's verifier) keep 1; golden generators and lone solves take the cores."""
+    L = lib()
+    L.orc_set_threads(int(n)); L.orcd_set_threads(int(n))
+
+
 def _key(key):
     k = np.asarray(key, dtype=np.uint32).reshape(2)
     return (C.c_uint32 * 2)(int(k[0]), int(k[1]))

@@ -12,7 +12,7 @@ from sde4mbrl_px4_amd import synthetic_iris
 from sde4mbrl_px4_amd import workload as W
 from sde4mbrl_px4_amd.sde_mpc_design import MpcProblem, load_mpc_problem
 from sde4mbrl_px4_amd.utils import enu2ned
-from sde4mbrl_px4_amd.worker import CONTROL_STATE, MpcWorker, select_command
+from worker import CONTROL_STATE, MpcWorker, select_command
 
 FIXTURE = os.path.join(GOLDEN_DIR, "worker_replay.npz")
 SMALL = dict(max_iter=6, max_no_improvement_iter=6)

@@ -9,7 +9,7 @@ from sde4mbrl_px4_amd import jax_shim
 from sde4mbrl_px4_amd import synthetic_iris
 from sde4mbrl_px4_amd.sde_mpc_design import OptState, load_mpc_from_cfgfile
 from sde4mbrl_px4_amd.utils import TrajectoryCSV, enu2ned
-from sde4mbrl_px4_amd.worker import CONTROL_STATE, SharedBlocks, select_command
+from worker import CONTROL_STATE, SharedBlocks, select_command
 from sde4mbrl_px4_amd.workload import HOVER, lemniscate_state, random_initial_states
 
 

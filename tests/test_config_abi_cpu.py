@@ -291,8 +291,10 @@ def test_product_and_tools_never_touch_the_oracle():
     src = open(os.path.join(root, "benchlib", "verify.py")).read()
     assert src.count("import orc") == 1 and src.split("import orc")[0].rsplit("\ndef ", 1)[-1].startswith("cpu_oracle()")
     callers = {blk.split("(", 1)[0].strip() for blk in re.split(r"\n(?:    )?def ", src)[1:] if "cpu_oracle()" in blk.split("\n", 1)[1]}
-    assert callers == {"cpu_solve_instances", "cpu_c1_single_solve_ms", "start"}, callers          # (start: Verifier.start)
-    for other in ("bench.py", "benchlib/counts.py", "benchlib/power.py", "benchlib/ranks.py", "benchlib/legs.py"):
+    # (start: Verifier.start — checks, float64 referee, cpu_baseline; calibrate: one three-iteration solve that sizes the sample; instruction_model_check: the
+    # recorded instruction answers against the GPU's at start-up; stand_in_outputs: the GPU-less dry run of the rank plumbing)
+    assert callers == {"cpu_solve_instances", "cpu_c1_single_solve_ms", "start", "calibrate_checker_seconds", "instruction_model_check", "stand_in_outputs"}, callers
+    for other in ("bench.py", "benchlib/counts.py", "benchlib/power.py", "benchlib/ranks.py", "benchlib/legs.py", "benchlib/referee.py"):
         assert not re.search(r"import orc\b|liborc|cpu_oracle\(", open(os.path.join(root, other)).read()), other
     main_src = open(os.path.join(root, "bench.py")).read()
     timed = main_src.split("t0 = time.perf_counter()")[1].split("t1 = time.perf_counter()")[0]

@@ -111,7 +111,29 @@ def test_bench_four_ranks_dry_run_over_gloo():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out == {"dry_run": True, "n_gpus": 4, "blob_bytes": 4 * (16 + 2120), "max_over_ranks": 4.0, "ticks": [3.0, None]}
+    assert out == {"dry_run": True, "n_gpus": 4, "blob_bytes": 4 * (16 + 2120), "max_over_ranks": 4.0, "ticks": [3.0, None],
+                   "same_on_every_rank": ["library build", "model blob"], "verified_by_rank": [[2, 2]] * 4, "bad_words_all_ranks": 0}
+
+
+def test_bench_four_ranks_a_rank_with_a_corrupted_blob_stops_the_run_and_is_named():
+    """Rank 2's copy of the broadcast model blob has one bit flipped (SDEMPC_BENCH_CORRUPT_RANK): the fingerprints every rank exchanges at start-up
+    disagree, every rank exits non-zero before a single launch, nothing is printed on stdout and the message names rank 2."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=_bench_env(SDEMPC_BENCH_DRY="1", SDEMPC_BENCH_CORRUPT_RANK="2"),
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "model blob: rank(s) [2] hold another one than the other ranks" in r.stderr, r.stderr[-1500:]
+
+
+def test_bench_four_ranks_a_rank_whose_outputs_differ_from_the_oracle_fails_the_run():
+    """Every rank checks instances of ITS OWN launches; one flipped bit in rank 3's outputs (SDEMPC_BENCH_CORRUPT_OUTPUT_RANK) — what a wrong device
+    binding or a faulty GPU would look like, invisible to rank 0's sample — makes the whole job exit non-zero, with rank 3 short in verified_by_rank."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=_bench_env(SDEMPC_BENCH_DRY="1", SDEMPC_BENCH_CORRUPT_OUTPUT_RANK="3"),
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert out["verified_by_rank"] == [[2, 2], [2, 2], [2, 2], [0, 2]] and out["bad_words_all_ranks"] == 1
+    assert "the outputs of rank(s) [3] differ from the oracle" in r.stderr
 
 
 def test_bench_four_ranks_one_fails_before_the_rendezvous():

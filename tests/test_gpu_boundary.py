@@ -10,7 +10,7 @@ from sde4mbrl_px4_amd import jax_shim
 from sde4mbrl_px4_amd import workload as W
 from sde4mbrl_px4_amd.sde_mpc_design import _next_key, load_mpc_problem
 from sde4mbrl_px4_amd.utils import enu2ned
-from sde4mbrl_px4_amd.worker import CONTROL_STATE, KEY2INDEX_INFO, MpcWorker, select_command
+from worker import CONTROL_STATE, KEY2INDEX_INFO, MpcWorker, select_command
 
 pytestmark = pytest.mark.gpu
 SMALL = dict(max_iter=6, max_no_improvement_iter=6)
@@ -151,6 +151,10 @@ def test_bench_two_ranks_self_started_on_one_gpu():
     c4 = rec["c4_one_instance_per_gpu"]                                   # BASELINE config 4: one instance per rank, barrier-aligned ticks
     # (the two ranks share ONE GPU here: their cooperative grids cannot be co-resident, a tick whose barrier gave up is dropped, not timed)
     assert c4["instances"] == 2 and c4["ticks"] + c4["ticks_dropped"] == 6 and c4["ticks"] >= 1 and c4["p50_tick_ms"] > 0 and c4["value"] > 0
+    # EVERY rank proved its own results: two instances of its own timed launch and the instance of its last good config-4 tick, against the oracle
+    vr = rec["verified_by_rank"]
+    assert [v["rank"] for v in vr] == [0, 1] and all(v["asked"] in (2, 3) and v["checked_bit_exact"] == v["asked"] for v in vr), vr
+    assert c4.get("verified_bit_exact") in (True, None)                   # (None: no tick of rank 0 completed without a give-up on the shared GPU)
 
 
 def test_bench_rccl_branch_on_one_gpu():
@@ -171,6 +175,8 @@ def test_bench_rccl_branch_on_one_gpu():
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["verified_bit_exact"] is True
+    assert rec["verified_by_rank"] == [{"rank": 0, "checked_bit_exact": 3, "asked": 3}]      # two instances of the timed launch + the config-4 tick (counts gathered through RCCL)
+    assert rec["c4_one_instance_per_gpu"]["verified_bit_exact"] is True
     assert rec["c4_one_instance_per_gpu"]["instances"] == 1 and rec["c4_one_instance_per_gpu"]["barrier_give_ups_rank0"] == 0      # (max over ranks through RCCL)
     # the process really loaded RCCL and ran collectives on it
     chk = subprocess.run([sys.executable, "-c", "import torch, torch.distributed as d, os; d.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0)); "

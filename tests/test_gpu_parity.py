@@ -688,6 +688,50 @@ def test_barrier_timeout_falls_back_to_tile_layout(spec):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("spec", ["1", "0"])
+def test_absent_workgroup_gives_up_within_a_few_budgets(spec):
+    """A workgroup of a cooperative-layout grid that never becomes resident (fault injection: SDEMPC_OPT_TEST_ABSENT_WG makes one leave at once) with a
+    NON-ZERO spin budget: the first grid barrier runs out of budget and raises the error flag; from then on no wait of the kernel may cost another budget
+    — neither the later barriers (they see the flag) nor the tagged hand-offs of the reduction phases (they look at the flag too and latch: before
+    round 5 each of them waited a full budget, 30 iterations x 20 ms here). The launch must return within a few budgets, report the give-up, and the
+    host-pointer entry point must still deliver the oracle's bits through the tile layout."""
+    import time
+    import torch
+    from sde4mbrl_px4_amd.solver import SdempcError
+    budget_us, n_it = 20000, 30
+    cfg = load_mpc_config(os.path.join(CDIR, "c2_iris_traj_h50_p128.yaml")).replace(horizon=12, num_short_dt=12, num_particles=72, max_iter=n_it, max_no_improvement_iter=n_it)
+    B = 1
+    x0, xref, noise, u = _problem(cfg, B, 5)
+    s0 = np.full(B, cfg.ls_init_stepsize, np.float32)
+    uo, xo, io = orc.Oracle(cfg, synthetic_iris()).solve_batch(x0, xref, noise, u, s0)
+    assert io[0, 2] == n_it                                   # the healthy solve runs all iterations: thirty reduction phases to wait in
+    S = _solver(cfg, synthetic_iris(), B, spec=int(spec), coop_spin_us=budget_us)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d = dict(x0=t(x0), xref=t(xref), nd=t(S.noise_to_device_layout(noise)), u=t(u), s=t(s0))
+    uopt, xev, info = torch.zeros((B, 12, 4), device="cuda"), torch.zeros((B, 13, 13), device="cuda"), torch.zeros((B, 8), device="cuda")
+    run = lambda: S.solve_dev(B, d["x0"].data_ptr(), d["xref"].data_ptr(), d["nd"].data_ptr(), d["u"].data_ptr(), d["s"].data_ptr(),
+                              uopt.data_ptr(), xev.data_ptr(), info.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    run(); torch.cuda.synchronize(); S.solve_status()              # healthy launch first (module load, workspaces): the oracle's bits, a cooperative kernel
+    assert bits_differ(uopt.cpu().numpy(), uo) == 0 and ("spec_kernel" in S.last_kernel_name() or ", 2, false>" in S.last_kernel_name()), S.last_kernel_name()
+    S.set_option("test_absent_wg", 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    with pytest.raises(SdempcError, match="barrier"):
+        S.solve_status()
+    assert np.isnan(info.cpu().numpy()).any() and S.layout_fallbacks() == 1
+    assert dt < 4 * budget_us * 1e-6, f"the launch took {dt * 1e3:.0f} ms with a {budget_us / 1e3:.0f} ms budget: a wait behind the give-up cost a budget again"
+    assert dt > 0.5 * budget_us * 1e-6                          # (and it did wait for its budget once)
+    # host-pointer entry point on a re-armed handle: gives up once more, re-runs in the tile layout, identical results
+    S.set_option("coop", 1)
+    ug, xg, ig = S.solve(x0, xref, noise, u, s0)
+    assert S.layout_fallbacks() == 2 and bits_differ(ug, uo) == 0 and bits_differ(xg, xo) == 0 and bits_differ(ig, io) == 0
+    S.set_option("test_absent_wg", -1)
+    S.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec", ["1", "0"])
 @pytest.mark.parametrize("opt", ["coop_launch", "coop_fence"])
 def test_runtime_cooperative_launch_and_fenced_barrier_bit_exact(spec, opt):
     """SDEMPC_OPT_COOP_LAUNCH: the cooperative layouts launched through hipLaunchCooperativeKernel; SDEMPC_OPT_COOP_FENCE: agent-scope
@@ -819,20 +863,21 @@ def test_c2_full_size_fast_math_mode_in_the_duo_layout_bit_exact():
             assert np.abs(uopt[b] - 0.71).max() > 1e-4                              # the iterations moved the controls
 
 
-@pytest.mark.parametrize("mlp", ["f16", "f32x3"])
-def test_c5_full_length_solve_matches_the_committed_oracle_result(mlp):
-    """BASELINE config 5 end to end in its own mode (`mlp_dtype: f16`; and in f32x3): ONE full-length solve — H = 200, P = 1024, 200 iterations, ~400
-    line-search rollouts — against what the CPU oracle computed for the same instance (tests/golden/make_c5_fullsize.py: 10 - 30 minutes on one core,
-    hence committed rather than recomputed), bit for bit: uopt, xevol, the eight telemetry words."""
+@pytest.mark.parametrize("config,mlp,math", [("c5", "f16", "exact"), ("c5", "f32x3", "exact"), ("c5", "f16", "fast"), ("c5", "f32x3", "fast"), ("c3", "f32x3", "fast")])
+def test_full_length_solves_match_the_committed_oracle_results(config, mlp, math):
+    """BASELINE config 5 end to end in its own mode (`mlp_dtype: f16`; and in f32x3), in BOTH math modes — `fast` is the arithmetic bench.py's C5 legs time —
+    and config 3 in the arithmetic bench.py times it in: ONE full-length solve each (C5: H = 200, P = 1024, 200 iterations, ~400 line-search rollouts) against
+    what the CPU oracle computed for the same instance (tests/golden/make_c5_fullsize.py: 10 - 60 minutes on one core, hence committed rather than
+    recomputed), bit for bit: uopt, xevol, the eight telemetry words."""
     import importlib.util
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"c5_fullsize_{mlp}.npz")
-    if not os.path.exists(f):
-        pytest.skip(f"{os.path.basename(f)} not generated yet (python tests/golden/make_c5_fullsize.py {mlp})")
-    spec = importlib.util.spec_from_file_location("make_c5_fullsize", os.path.join(os.path.dirname(f), "make_c5_fullsize.py"))
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_c5_fullsize", os.path.join(gdir, "make_c5_fullsize.py"))
     mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
-    g = np.load(f)
-    cfg, x0, xref, key = mk.problem(mlp)
-    S = _solver(cfg, synthetic_iris(), 1)
+    assert (config, mlp, math) in mk.COMMITTED
+    g = np.load(mk.golden_path(mlp, math, config))
+    cfg, x0, xref, key = mk.problem(mlp, math, config)
+    assert cfg.math_mode == math and cfg.mlp_dtype == mlp
+    S = _solver(cfg, mk.model_of(config), 1)
     yk, i0 = S.reset()
     assert bits_differ(yk, g["u0"]) == 0 and np.float32(i0["stepsize"]) == g["stepsize"]
     uopt, xevol, info = S.solve_keys(x0, xref, key, yk[None], np.array([i0["stepsize"]], np.float32))
@@ -899,10 +944,16 @@ def test_six_team_workgroups_every_motor_count_and_contraction_mode(m, mlp):
     u0 = np.tile(yk[None], (B, 1, 1))
     s0 = np.full(B, i0["stepsize"], np.float32)
     uopt, xevol, info = S.solve_keys(x0, xref, keys, u0, s0)
-    assert f"TeamPairT<6>, {m}, {dict(f32=0, f16=1, f32x3=2)[mlp]}, false, 3, false" in S.last_kernel_name(), S.last_kernel_name()
-    S.set_option("hex", 0)
-    u2, x2, i2 = S.solve_keys(x0, xref, keys, u0, s0)
-    assert "TeamPairT<2>" in S.last_kernel_name() and bits_differ(uopt, u2) == 0 and bits_differ(xevol, x2) == 0 and bits_differ(info, i2) == 0
+    from sde4mbrl_px4_amd import _abi
+    if m == 8 and not (_abi.load_library().sdempc_build_flags() & 1):
+        # the default build carries the generic motor count in the one-group-per-wave tile layouts only (make EXTRA=-DSDEMPC_ALL_VARIANTS=1 adds the rest;
+        # include/sdempc.h: sdempc_build_flags): same bits from another layout
+        assert f"TeamBlock, 8, {dict(f32=0, f16=1, f32x3=2)[mlp]}, false, 0, " in S.last_kernel_name(), S.last_kernel_name()
+    else:
+        assert f"TeamPairT<6>, {m}, {dict(f32=0, f16=1, f32x3=2)[mlp]}, false, 3, false" in S.last_kernel_name(), S.last_kernel_name()
+        S.set_option("hex", 0)
+        u2, x2, i2 = S.solve_keys(x0, xref, keys, u0, s0)
+        assert "TeamPairT<2>" in S.last_kernel_name() and bits_differ(uopt, u2) == 0 and bits_differ(xevol, x2) == 0 and bits_differ(info, i2) == 0
     O = orc.Oracle(cfg, model)
     for b in (0, 5, 1535, 1536, B - 1):
         uo, xe, io = O.solve(x0[b], xref[b], orc.noise_from_key(keys[b], P, H), u0[b], float(s0[b]))[:3]

@@ -98,3 +98,30 @@ def test_fast_mode_oracle_is_close_to_the_exact_one_and_deterministic():
     import pytest
     with pytest.raises(AssertionError):
         orc.Oracle(cfg.replace(math_mode="fast"), model, double=True).rollout(x0, u, xref, noise)
+
+
+def test_four_at_once_activation_equals_its_scalar_statement():
+    """oracle/transc_model.c: orc_hw_sigm4 (what the checker's hidden layers call in math_mode fast: four reference polynomials as one 4-lane chain, table
+    bytes requested ahead) returns, lane by lane, orc_hw_rcp(1 + orc_hw_exp2(x)) — on pre-activation-like values, every binade of either sign, the
+    reduction range |x| >= 2, and the special values (zero, sub-normals, infinities, NaNs; mixed into groups of four so that general and special lanes meet)."""
+    import ctypes as C
+    L = orc.lib()
+    orc.transc_tables(L)
+    L.orc_hw_sigm_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.orc_hw_sigm_eval.restype = None
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    x = np.concatenate([
+        (rng.standard_normal(n) * 4).astype(np.float32),                                              # pre-activations as the MLPs see them
+        (rng.uniform(1, 2, n) * np.exp2(rng.integers(-40, 9, n)) * rng.choice([-1, 1], n)).astype(np.float32),   # every binade from below 2^-30 to beyond 128
+        rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32),                # any bit pattern (NaNs, infinities, sub-normals)
+    ])
+    sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 127.99999, 128.0, -126.0, -149.5, 2.0, -2.0, 1.9999999, 2.0 ** -30, 2.0 ** -31], np.float32)
+    x[rng.integers(0, x.size, 4096)] = sp[rng.integers(0, sp.size, 4096)]
+    x = np.ascontiguousarray(x[: x.size // 4 * 4])
+    y4, y1 = np.empty_like(x), np.empty_like(x)
+    L.orc_hw_sigm_eval(1, x.ctypes.data, y4.ctypes.data, x.size)
+    L.orc_hw_sigm_eval(0, x.ctypes.data, y1.ctypes.data, x.size)
+    same = (_bits(y4) == _bits(y1)) | (np.isnan(y4) & np.isnan(y1))
+    assert same.all(), (x[~same][:8], y4[~same][:8], y1[~same][:8])
+    assert np.isfinite(y1).mean() > 0.9 and (y1 > 0).mean() > 0.5

@@ -1,5 +1,8 @@
+"""Re-runs ONE edge case of tests/test_gpu_parity.py (EDGE) in one execution layout on the GPU and prints where the outputs differ from the oracle.
+usage: python tests/tools/repro_edge.py <edge case name> auto|coop|tile"""
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import orc
 from cases import bits_differ

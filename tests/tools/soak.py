@@ -14,6 +14,9 @@ bad = 0; nonfinite = 0; t0 = time.time()
 LAYOUTS = [("auto", {}), ("coop", {"spec": 0}), ("coop-rt", {"coop_launch": 1}), ("auto-fence", {"coop_fence": 1}), ("coop-fence", {"spec": 0, "coop_fence": 1}),
            ("tile-pk", {"coop": 0, "pk": 1}), ("tile", {"coop": 0, "pk": 0}), ("tile-duo", {"coop": 0, "pk": 0, "duo": 1}), ("tile-gtab", {"coop": 0, "pk": 0, "ustg": 1, "duo": 1}),
            ("tile-nolane", {"coop": 0, "lane": 0, "pk": 0}), ("tile-noduo", {"coop": 0, "pk": 0, "duo": 0}), ("tile-noduo-gtab", {"coop": 0, "pk": 0, "duo": 0, "ustg": 1})]
+from sde4mbrl_px4_amd import _abi
+if not (_abi.load_library().sdempc_build_flags() & 1):       # default build: no packed-tanh instantiations (a layout is drawn by index: keep the list's length, so the draws of a case number do not move)
+    LAYOUTS = [(n_, ({"coop": 0, "pk": 0} if n_ == "tile-pk" else o_)) for n_, o_ in LAYOUTS]
 MLPS = (sys.argv[3].split(",") if len(sys.argv) > 3 else ["f32", "f32", "f16", "f32x3", "f32x3"])     # contraction modes to draw from (SPEC.md 9, 9b): all bit-exact
 FAST_SHARE = float(sys.argv[4]) if len(sys.argv) > 4 else 0.4
 DEBUG = bool(os.environ.get("SOAK_DEBUG"))          # which outputs differ, per instance

@@ -6,6 +6,9 @@ position/trajectory solve per mode (:398-416, idle alternation :406-408), the A8
 (:428-432) and the shared-block writes (:437-450). `SharedBlocks` has the layouts of
 `multi_process_shared_variables` (:616-656) as plain numpy arrays; `select_command` is the index rule
 of `mpc_state_callback` (:283-306). ROS, MAVLink and the process/lock plumbing are out of scope.
+
+TEST HARNESS (SURVEY.md §8f N1, §8c last row): a statement-by-statement counterpart of the reference's caller, kept next to tests/replay.py —
+not a component of the product package (it drives the product through the reference's own entry points: load_mpc_from_cfgfile, m_reset, m_mpc).
 """
 from __future__ import annotations
 
@@ -14,10 +17,10 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from . import jax_shim
-from .sde_mpc_design import MpcProblem
-from .utils import enu2ned
-from .workload import HOVER
+from sde4mbrl_px4_amd import jax_shim
+from sde4mbrl_px4_amd.sde_mpc_design import MpcProblem
+from sde4mbrl_px4_amd.utils import enu2ned
+from sde4mbrl_px4_amd.workload import HOVER
 
 CONTROL_STATE = {"none": 0, "reset": 1, "test": 2, "pos": 3, "idle": 4, "traj": 5}          # sde_control.py:46
 KEY2INDEX_PRE = {"sample_time_prempc": 0, "duration": 1, "ctrl_state": 2}                     # sde_control.py:639

@@ -170,6 +170,10 @@ typedef struct {
     orc_op16 h2[HID][2][16];             /* f16 mode, layer 2: row i, K-half hf */
     int32_t x2m[2][3][HID][2][16], x2x[2][3][HID][2][16];       /* f32x3 mode: significands / exponents of the bf16 limbs, [0 = W2 rows, 1 = W2^T rows][limb][row][K-half][slot] */
     int32_t x2mT[2][3][2][16][HID], x2xT[2][3][2][16][HID];     /* the same, row index last: sixteen rows per vector in the 16-lane group addition (mfma16_model.c) */
+    /* SPEC.md §10e (f32x3 + fast): the three contractions of the MLP's vector-Jacobian products from two binary16 limbs each, behind a per-particle
+     * power-of-two scale. Images [0 = (4 W2)^T, 1 = density tile: rows 0..5 = W1z[32 + k][row], 2 = drift tile: rows 0..5 = W1z[k][row], rows 6..6+m-1 = W1u[k][row - 6]][limb][row][K-half][slot] */
+    int adjmp, adj_eoff;
+    int32_t y2m[3][3][HID][2][16], y2x[3][3][HID][2][16], y2mT[3][3][2][16][HID], y2xT[3][3][2][16][HID];
 #endif
     real inv_mass, grav, J[3], iJ[3], ct2, ct1, ct0, cm2, cm1;
     real rx[MAXM], ry[MAXM], dir[MAXM];
@@ -420,6 +424,21 @@ static int parse_blob(const void* blob, model_t* M, int f16, int fast) {
             for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(!h2, lb[l], &o); M->x2m[tr][l][i][hf][k] = M->x2mT[tr][l][hf][k][i] = o.m; M->x2x[tr][l][i][hf][k] = M->x2xT[tr][l][hf][k][i] = o.ex; }
         }
     }
+    M->adjmp = 0; M->adj_eoff = 10;
+    if (f16 == 2 && M->fast && getenv("ORC_ADJMP") && atoi(getenv("ORC_ADJMP"))) {
+        M->adjmp = 1;
+        if (getenv("ORC_ADJ_EOFF")) M->adj_eoff = atoi(getenv("ORC_ADJ_EOFF"));
+        for (int img = 0; img < 3; ++img) for (int i = 0; i < HID; ++i) for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k) {
+            const int un = slot_unit(hf, k);
+            float w = 0.0f;
+            if (img == 0) w = M->vW2[un][i];                                   /* (4 W2)^T: row i = input unit, contraction over the layer-2 unit un */
+            else if (img == 1) w = i < NN ? M->vW1z[HID + un][i] : 0.0f;
+            else w = i < NN ? M->vW1z[un][i] : (i < NN + M->m ? M->vW1u[un][i - NN] : 0.0f);
+            uint16_t lb[3] = {f16_rne_bits(w), 0, 0};
+            lb[1] = f16_rne_bits(w - f16_value(lb[0]));
+            for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(0, lb[l], &o); M->y2m[img][l][i][hf][k] = M->y2mT[img][l][hf][k][i] = o.m; M->y2x[img][l][i][hf][k] = M->y2xT[img][l][hf][k][i] = o.ex; }
+        }
+    }
 #endif
     return 0;
 }
@@ -646,6 +665,34 @@ static preal stage_cost(const sdempc_cfg* C, const preal* x, const real* xr, pre
 
 /* VJP of step_fwd. L = adjoint wrt x_{t+1}; etabar_cost = direct d(cost)/d(eta).
  * Outputs: lam = adjoint wrt x_t; gu[m] = W1u^T abar1 (drift tile); gT = adjoint of Tz; gtau[3]. */
+/* second half of step_vjp: from the adjoint of z (zb) and of the velocity (vbar) to the state adjoint (shared by the arithmetics of the MLP part) */
+static inline void step_vjp_tail(const model_t* M, const stepaux_t* A, const preal* v, const preal* om, preal qw, preal qx, preal qy, preal qz, const preal* Rm,
+                                 const preal* Fwb, const preal* zb, const preal* vbar, const preal* qtb, const preal* dqb, preal* omb, const preal* Lp, preal* lam) {
+    (void)M;
+    /* Rbar_ij = Fwb_i Fb_j + v_i zb_j */
+    preal Rb[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rb[3 * i + j] = PFMA(v[i], zb[j], Fwb[i] * A->Fb[j]);
+    /* dq = 0.5 q (x) (0, om) */
+    preal qb[4];
+    qb[0] = PFMA(R(0.5), PFMA(dqb[3], om[2], PFMA(dqb[2], om[1], dqb[1] * om[0])), qtb[0]);
+    qb[1] = PFMA(R(0.5), PFMA(dqb[3], om[1], PFMA(-dqb[2], om[2], -(dqb[0] * om[0]))), qtb[1]);
+    qb[2] = PFMA(R(0.5), PFMA(-dqb[3], om[0], PFMA(dqb[1], om[2], -(dqb[0] * om[1]))), qtb[2]);
+    qb[3] = PFMA(R(0.5), PFMA(dqb[2], om[0], PFMA(-dqb[1], om[1], -(dqb[0] * om[2]))), qtb[3]);
+    omb[0] = PFMA(R(0.5), PFMA(-dqb[3], qy, PFMA(dqb[2], qz, PFMA(dqb[1], qw, -(dqb[0] * qx)))), omb[0]);
+    omb[1] = PFMA(R(0.5), PFMA(dqb[3], qx, PFMA(dqb[2], qw, PFMA(-dqb[1], qz, -(dqb[0] * qy)))), omb[1]);
+    omb[2] = PFMA(R(0.5), PFMA(dqb[3], qw, PFMA(-dqb[2], qx, PFMA(dqb[1], qy, -(dqb[0] * qz)))), omb[2]);
+    /* R(q) */
+    preal s01 = Rb[1] + Rb[3], d10 = Rb[3] - Rb[1];
+    preal s02 = Rb[2] + Rb[6], d02 = Rb[2] - Rb[6];
+    preal s12 = Rb[5] + Rb[7], d21 = Rb[7] - Rb[5];
+    qb[0] = PFMA(R(2), PFMA(qx, d21, PFMA(qy, d02, qz * d10)), qb[0]);
+    qb[1] = PFMA(R(2), PFMA(qw, d21, PFMA(qz, s02, qy * s01)), PFMA(R(-4) * qx, Rb[4] + Rb[8], qb[1]));
+    qb[2] = PFMA(R(2), PFMA(qz, s12, PFMA(qw, d02, qx * s01)), PFMA(R(-4) * qy, Rb[0] + Rb[8], qb[2]));
+    qb[3] = PFMA(R(2), PFMA(qy, s12, PFMA(qx, s02, qw * d10)), PFMA(R(-4) * qz, Rb[0] + Rb[4], qb[3]));
+    for (int i = 0; i < 3; ++i) { lam[i] = Lp[i]; lam[3 + i] = vbar[i]; lam[10 + i] = omb[i]; }
+    for (int i = 0; i < 4; ++i) lam[6 + i] = qb[i];
+}
+
 static void step_vjp(const model_t* M, const preal* x, const preal* xi, real dt, const real* sdt,
                      const stepaux_t* A, const preal* L, preal etabar_cost,
                      preal* lam, preal* gu, preal* gT, preal* gtau) {
@@ -685,6 +732,43 @@ static void step_vjp(const model_t* M, const preal* x, const preal* xi, real dt,
     for (int i = 0; i < 3; ++i) gtau[i] = taub_b[i];
     /* MLP VJP (SPEC.md §5.4) */
     preal a2b[HID], a1d[HID], a1n[HID];
+#ifdef ORC_MFMA16
+    float adj_inv = 1.0f;
+    if (M->adjmp) {
+        /* SPEC.md §10e: one power of two per particle brings the output adjoints to 2^eoff (the largest of the seven in [2^(eoff-1), 2^eoff)): every product
+         * below is exact in the scale, and the three contractions can take binary16 limbs. The forward weights (-2 W3, -2 w3n) meet the adjoints times -2 s. */
+        float mx = fabsf(ebraw);
+        for (int i = 0; i < 6; ++i) mx = fmaxf(mx, fabsf(ob[i]));
+        int e = 0;
+        if (mx > 0.0f && isfinite(mx)) (void)frexpf(mx, &e);
+        if (e < -100) e = -100;
+        const float s2 = -2.0f * ldexpf(1.0f, M->adj_eoff - e);
+        adj_inv = ldexpf(1.0f, e - M->adj_eoff);
+        for (int i = 0; i < 6; ++i) ob[i] = ob[i] * s2;
+        ebraw = ebraw * s2;
+        for (int k = 0; k < HID; ++k) {
+            float hb = 0.0f;
+            for (int i = 0; i < 6; ++i) hb = fmaf(M->W3[i][k], ob[i], hb);
+            a2b[k] = hb * DACT(M, A->h2[k]);
+        }
+        float hb2[HID], zacc[HID], zacc2[HID];
+        x3_contract(1, M->y2m[0], M->y2x[0], M->y2mT[0], M->y2xT[0], a2b, NULL, hb2);
+        for (int k = 0; k < HID; ++k) { a1d[k] = hb2[k] * DACT(M, A->h1d[k]); a1n[k] = (M->w3n[k] * ebraw) * DACT(M, A->h1n[k]); }
+        x3_contract(1, M->y2m[1], M->y2x[1], M->y2mT[1], M->y2xT[1], a1n, NULL, zacc);
+        x3_contract(1, M->y2m[2], M->y2x[2], M->y2mT[2], M->y2xT[2], a1d, zacc, zacc2);
+        preal zb2[NN];
+        for (int k = 0; k < NN; ++k) zb2[k] = zacc2[k] * adj_inv;
+        for (int j = 0; j < M->m; ++j) gu[j] = zacc2[NN + j] * adj_inv;
+        for (int i = 0; i < 3; ++i) omb[i] = omb[i] + zb2[3 + i];
+        preal vbar2[3];
+        for (int i = 0; i < 3; ++i) {
+            preal Rvb = PFMA(Rm[3 * i + 2], zb2[2], PFMA(Rm[3 * i + 1], zb2[1], Rm[3 * i] * zb2[0]));
+            vbar2[i] = PFMA(Lp[i], dt, Lv[i]) + Rvb;
+        }
+        step_vjp_tail(M, A, v, om, qw, qx, qy, qz, Rm, Fwb, zb2, vbar2, qtb, dqb, omb, Lp, lam);
+        return;
+    }
+#endif
     for (int k = 0; k < HID; ++k) {
         preal hb = pbroadcast(R(0));
         for (int i = 0; i < 6; ++i) hb = PFMA(M->vW3[i][k], ob[i], hb);
@@ -722,28 +806,7 @@ static void step_vjp(const model_t* M, const preal* x, const preal* xi, real dt,
         preal Rvb = PFMA(Rm[3 * i + 2], zb[2], PFMA(Rm[3 * i + 1], zb[1], Rm[3 * i] * zb[0]));
         vbar[i] = PFMA(Lp[i], dt, Lv[i]) + Rvb;
     }
-    /* Rbar_ij = Fwb_i Fb_j + v_i zb_j */
-    preal Rb[9];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rb[3 * i + j] = PFMA(v[i], zb[j], Fwb[i] * A->Fb[j]);
-    /* dq = 0.5 q (x) (0, om) */
-    preal qb[4];
-    qb[0] = PFMA(R(0.5), PFMA(dqb[3], om[2], PFMA(dqb[2], om[1], dqb[1] * om[0])), qtb[0]);
-    qb[1] = PFMA(R(0.5), PFMA(dqb[3], om[1], PFMA(-dqb[2], om[2], -(dqb[0] * om[0]))), qtb[1]);
-    qb[2] = PFMA(R(0.5), PFMA(-dqb[3], om[0], PFMA(dqb[1], om[2], -(dqb[0] * om[1]))), qtb[2]);
-    qb[3] = PFMA(R(0.5), PFMA(dqb[2], om[0], PFMA(-dqb[1], om[1], -(dqb[0] * om[2]))), qtb[3]);
-    omb[0] = PFMA(R(0.5), PFMA(-dqb[3], qy, PFMA(dqb[2], qz, PFMA(dqb[1], qw, -(dqb[0] * qx)))), omb[0]);
-    omb[1] = PFMA(R(0.5), PFMA(dqb[3], qx, PFMA(dqb[2], qw, PFMA(-dqb[1], qz, -(dqb[0] * qy)))), omb[1]);
-    omb[2] = PFMA(R(0.5), PFMA(dqb[3], qw, PFMA(-dqb[2], qx, PFMA(dqb[1], qy, -(dqb[0] * qz)))), omb[2]);
-    /* R(q) */
-    preal s01 = Rb[1] + Rb[3], d10 = Rb[3] - Rb[1];
-    preal s02 = Rb[2] + Rb[6], d02 = Rb[2] - Rb[6];
-    preal s12 = Rb[5] + Rb[7], d21 = Rb[7] - Rb[5];
-    qb[0] = PFMA(R(2), PFMA(qx, d21, PFMA(qy, d02, qz * d10)), qb[0]);
-    qb[1] = PFMA(R(2), PFMA(qw, d21, PFMA(qz, s02, qy * s01)), PFMA(R(-4) * qx, Rb[4] + Rb[8], qb[1]));
-    qb[2] = PFMA(R(2), PFMA(qz, s12, PFMA(qw, d02, qx * s01)), PFMA(R(-4) * qy, Rb[0] + Rb[8], qb[2]));
-    qb[3] = PFMA(R(2), PFMA(qy, s12, PFMA(qx, s02, qw * d10)), PFMA(R(-4) * qz, Rb[0] + Rb[4], qb[3]));
-    for (int i = 0; i < 3; ++i) { lam[i] = Lp[i]; lam[3 + i] = vbar[i]; lam[10 + i] = omb[i]; }
-    for (int i = 0; i < 4; ++i) lam[6 + i] = qb[i];
+    step_vjp_tail(M, A, v, om, qw, qx, qy, qz, Rm, Fwb, zb, vbar, qtb, dqb, omb, Lp, lam);
 }
 
 /* ------------------------------------------------------------------------------------------- */

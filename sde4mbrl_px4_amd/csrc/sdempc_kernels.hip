@@ -36,7 +36,8 @@
 // This file is compiled twice (Makefile): SDEMPC_FAST=0 -> namespace sdempc::exact, the bit-reproducible arithmetic of SPEC.md
 // §3 (the default and the path every parity claim is about); SDEMPC_FAST=1 -> namespace sdempc::fastm, the same kernels with the
 // hardware transcendentals v_exp_f32 / v_rcp_f32 / v_rsq_f32 in tanh, sigmoid and the quaternion normalisation (SPEC.md §10,
-// `math_mode: fast`): not reproducible on a CPU, checked against the oracle within tolerances.
+// `math_mode: fast`): the three instructions are described exhaustively by structure + record (SPEC.md §10a, oracle/transc_model.c), so this namespace too
+// is compared with the CPU oracle bit for bit (since round 4).
 #ifndef SDEMPC_FAST
 #define SDEMPC_FAST 0
 #endif

@@ -65,6 +65,40 @@ DI void mfma_x3(const float* Aimg, int lane, const Limbs3& L, f32x16& acc) {
     }
 }
 
+#ifndef SDEMPC_VAR_ADJMP
+#define SDEMPC_VAR_ADJMP 0
+#endif
+#if SDEMPC_VAR_ADJMP
+// TIMING-ONLY (profiles/r5_ab.txt §1): a tile split into two binary16 limbs (the forward split of SPEC.md §10c) and contracted by eight
+// v_mfma_f32_32x32x16_f16 against whatever the LDS image `img` holds — the instruction mix of an adjoint whose three contractions (W2^T abar2, W1z^T abar1n,
+// [W1z; W1u]^T abar1d) run on the matrix pipe behind a per-particle power-of-two scale. Values are wrong.
+DI void var_split2h_mfma(const float* img, int lane, const f32x16& v, f32x16& acc) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    u32x4 r1[2], r2[2], aw[2][2];
+#pragma unroll
+    for (int lb = 0; lb < 2; ++lb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) aw[lb][hf] = *reinterpret_cast<const u32x4*>(img + ((lb * 2 + hf) * 64 + lane) * 4);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const float x = v[8 * hf + 2 * pr], y = v[8 * hf + 2 * pr + 1];
+            unsigned p1, p2; float xr, yr;
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(x), "v"(y));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(xr) : "v"(p1), "v"(x));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(yr) : "v"(p1), "v"(y));
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p2) : "v"(xr), "v"(yr));
+            r1[hf][pr] = p1; r2[hf][pr] = p2;
+        }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, aw[s4 < 2 ? 1 : 0][hf]), __builtin_bit_cast(h8, (s4 & 1) ? r1[hf] : r2[hf]), acc, 0, 0, 0);
+}
+#endif
+
 // ---- MLPs of a step in the MFMA tile layout (32 particles per wave) ----
 // fwd_mlp_partials: the hidden tiles (A.h1d, A.h1n, A.h2) and the per-half partial chains of the seven output-layer dot products
 // (Po[0..5]: residual force / torque, Po[6]: density pre-activation); fwd_mlp_tiles adds the halves: (P0 + P1) + bias (SPEC.md §5.2).
@@ -562,10 +596,36 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
     for (int k = 0; k < NN; ++k) Pz[k] = 0.0f;
 #pragma unroll
     for (int jj = 0; jj < M; ++jj) Pu[jj] = 0.0f;
+#if SDEMPC_VAR_ADJMP
+    f32x16 var_accZ; float var_unscale = 1.0f;
+#endif
     {   // density net: abar1n = (w3n * etaraw_bar) * (1 - h1n^2); zbar += W1z[32:64]^T abar1n
         f32x16 hn;
         layer1_tile<F16, false>(sm, ww, ust, h, z, hn);
         // (weight quads of a quarter are requested from LDS together, then consumed: one exposed LDS round trip per quarter, see fwd_mlp_partials)
+#if SDEMPC_VAR_ADJMP
+        if constexpr (FAST && F16 == 2) {
+            // TIMING-ONLY: scale from the largest output adjoint (free in the -2 multiplier), abar1n as a tile, W1z^T abar1n on the matrix pipe
+            float sc = fabsf(ob_in[0]);
+#pragma unroll
+            for (int i = 1; i < 6; ++i) sc = fmaxf(sc, fabsf(ob_in[i]));
+            sc = fmaxf(sc, fabsf(ebraw_in));
+            sc = __builtin_amdgcn_ldexpf(1.0f, -__builtin_amdgcn_frexp_expf(sc));
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ob[i] = ob[i] * sc;
+            f32x16 an;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
+                an[4 * q] = (wn4.x * (ebraw * sc)) * dact(hn[4 * q]); an[4 * q + 1] = (wn4.y * (ebraw * sc)) * dact(hn[4 * q + 1]);
+                an[4 * q + 2] = (wn4.z * (ebraw * sc)) * dact(hn[4 * q + 2]); an[4 * q + 3] = (wn4.w * (ebraw * sc)) * dact(hn[4 * q + 3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) var_accZ[r] = 0.0f;
+            var_split2h_mfma(sm.A2xT, lane, an, var_accZ);
+            var_unscale = __builtin_amdgcn_rcpf(sc);
+        } else
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
@@ -617,9 +677,15 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
         if constexpr (F16 == 2) {       // SPEC.md §9b: W2^T abar2 as the three-limb bf16 split on the matrix pipe
+#if SDEMPC_VAR_ADJMP
+            if constexpr (FAST) var_split2h_mfma(sm.A2xT, lane, a2b, accB);
+            else
+#endif
+            {
             Limbs3 L;
             split3_tile(a2b, L);
             mfma_x3(sm.A2xT, lane, L, accB);
+            }
         } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -635,6 +701,19 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
     {   // drift net, first layer: recomputed only now
         f32x16 hd;
         layer1_tile<F16, true>(sm, ww, ust, h, z, hd);
+#if SDEMPC_VAR_ADJMP
+        if constexpr (FAST && F16 == 2) {
+            f32x16 ad;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ad[r] = accB[r] * dact(hd[r]);
+            var_split2h_mfma(sm.A2xT, lane, ad, var_accZ);
+            // outputs: rows 0..5 = zbar, 6..6+M-1 = W1u^T abar1d, in the accumulator layout (registers 0..3 of either lane half, 4 / 5 of the lower): unscaled
+#pragma unroll
+            for (int k = 0; k < NN; ++k) Pz[k] = var_accZ[k & 3] * var_unscale + (k >= 4 ? var_accZ[4 + (k & 1)] : 0.0f);
+#pragma unroll
+            for (int jj = 0; jj < M; ++jj) Pu[jj] = var_accZ[(jj + 2) & 7] * var_unscale;
+        } else
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float ad0 = accB[4 * q] * dact(hd[4 * q]);

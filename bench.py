@@ -505,6 +505,8 @@ def main():
                                                   f"(N_it {c1['vec'][1]:.0f}) on ONE thread, median of 3: particle-vectorised build / bit-exact scalar -O2 build"}
         if short or V.errors:
             out["verification_errors"] = V.errors[:8]
+        out["bench_wall_s"] = time.perf_counter() - _T0
+        progress(f"done: {out['bench_wall_s']:.0f} s in all; CPU threads busy for {wall:.0f} s")
         emit(out)
     if use_dist:
         dist.barrier()

@@ -462,6 +462,31 @@ class Restatement:
                 self.V["W1z"] = (M.W1z / c).astype(F)
                 self.V["W2"] = ((F(-2) * M.W2).astype(F) / c).astype(F)
             M.W3, M.b3, M.w3n, M.b3n = (F(-2) * M.W3).astype(F), b3, (F(-2) * M.w3n).astype(F), b3n
+        # SPEC.md §10e (math_mode fast + f32x3): the adjoint's contractions from binary16 limbs behind a per-particle power-of-two scale; its offset from
+        # bounds on the scaled quantities (float32, absolute column sums in ascending index order)
+        self.adjmp = self.fast and self.mlp == "f32x3"
+        if self.adjmp:
+            B3, Bn, C2 = F(0), F(0), F(0)
+            for k in range(32):
+                s3, s2 = F(0), F(0)
+                for i in range(6):
+                    s3 = F(s3 + abs(M.W3[i, k]))
+                for j in range(32):
+                    s2 = F(s2 + abs(self.V["W2"][j, k]))
+                B3, C2, Bn = max(B3, s3), max(C2, s2), max(Bn, F(abs(M.w3n[k])))
+            bound = max(F(B3 * F(0.25)), F(Bn * F(0.25)), F(F(C2 * F(B3 * F(0.25))) * F(0.25)))
+            self.adj_eoff = 10
+            if bound > 0 and np.isfinite(bound):
+                self.adj_eoff = min(10, 14 - int(np.frexp(bound)[1]))
+            self.adj_eoff = max(self.adj_eoff, -40)
+            # A-operand matrices of the two narrow contractions: rows 0..5 W1z^T (density / drift tile), drift rows 6..6+m-1 W1u^T, the rest zero
+            self.Zn = np.zeros((32, 32), F); self.Zd = np.zeros((32, 32), F)
+            self.Zn[:6, :] = self.V["W1z"][32:, :].T
+            self.Zd[:6, :] = self.V["W1z"][:32, :].T
+            self.Zd[6:6 + self.m, :] = self.V["W1u"][:, :self.m].T
+            self.W3t = np.zeros((32, 32), F)             # (-2 W3)^T, the six output adjoints in k slots 0..5 of K-half 0
+            for i in range(6):
+                self.W3t[:, slot_unit(0, i)] = M.W3[i, :]
         self.dt = np.asarray(cfg.time_steps, F)
         self.sdt = np.stack([self.M.sigma * F(np.sqrt(F(d))) for d in self.dt]).astype(F)       # sigma_i * sqrtf(dt_t), host float32
         disc = []
@@ -607,6 +632,9 @@ class Restatement:
         gT, gtau = Fbb[2], np.stack(taub_b, axis=1)
         # MLP part: abar2 = (W3^T obar) (1 - h2^2); hbar1d = W2^T abar2 in the k order of §4; abar1 = hbar1 (1 - h1^2)
         h1d, h1n, h2 = A["h1d"], A["h1n"], A["h2"]
+        if self.adjmp:
+            zb, gu = self.mlp_vjp_scaled(ob, ebraw, h1d, h1n, h2)
+            return self._vjp_tail(x, dt, v, om, q, R, Fb, Fwb, zb, gu, qtb, dqb, omb, Lp, Lv, gT, gtau)
         hb2 = np.zeros_like(h2)
         for i in range(6):
             hb2 = fma(V["W3"][i][None, :], ob[i][:, None], hb2)
@@ -630,6 +658,46 @@ class Restatement:
                     P1 = fma(V["W1z"][tile + k1, k], a1[:, k1], P1)
             zb.append(P0 + P1)
         gu = np.stack([half_sums(V["W1u"][:, j], a1d) for j in range(m)], axis=1)
+        return self._vjp_tail(x, dt, v, om, q, R, Fb, Fwb, zb, gu, qtb, dqb, omb, Lp, Lv, gT, gtau)
+
+    def mlp_vjp_scaled(self, ob, ebraw, h1d, h1n, h2):
+        """SPEC.md §10e: per particle, the seven output adjoints scaled by sigma = -2 * 2^(eoff - e) (e: the binary exponent of the largest of them, as
+        frexp returns it, at least -100; 0 for zero / non-finite), the forward output weights (-2 W3, -2 w3n), and the three contractions — (4 W2)^T abar2,
+        Zn abar1n, Zd abar1d — each from two binary16 limbs of either operand (eight instructions, C = 0); rows 0..7 of the two narrow results are added;
+        everything is unscaled by 2^(e - eoff) at the end."""
+        M, m, V = self.M, self.m, self.V
+        P = ebraw.shape[0]
+        zb, gu = np.zeros((P, 6), F), np.zeros((P, m), F)
+        for p_ in range(P):
+            vals = [abs(F(ebraw[p_]))] + [abs(F(ob[i][p_])) for i in range(6)]
+            mx = F(0)
+            for v_ in vals:                        # a maximum that ignores NaNs (fmaxf / v_max_f32)
+                if not np.isnan(v_) and (np.isnan(mx) or v_ > mx):
+                    mx = v_
+            e = int(np.frexp(mx)[1]) if (mx > 0 and np.isfinite(mx)) else 0
+            e = max(e, -100)
+            sig = F(np.ldexp(F(-2), self.adj_eoff - e))
+            inv = F(np.ldexp(F(1), e - self.adj_eoff))
+            with np.errstate(all="ignore"):
+                obs = [F(F(ob[i][p_]) * sig) for i in range(6)]
+                ebs = F(F(ebraw[p_]) * sig)
+                ov = np.zeros(32, F)
+                for i in range(6):
+                    ov[slot_unit(0, i)] = obs[i]             # k slot i of K-half 0
+                hb = h2_contract(self.W3t, ov, None)
+                a2 = (hb * self.dact(h2[p_])).astype(F)
+                hb1 = h2_contract(V["W2"].T, a2, None)
+                a1d = (hb1 * self.dact(h1d[p_])).astype(F)
+                a1n = ((M.w3n * ebs).astype(F) * self.dact(h1n[p_])).astype(F)
+                zn = h2_contract(self.Zn, a1n, None)
+                zd = h2_contract(self.Zd, a1d, None)
+                zd[:8] = (zd[:8] + zn[:8]).astype(F)
+                zb[p_] = (zd[:6] * inv).astype(F)
+                gu[p_] = (zd[6:6 + m] * inv).astype(F)
+        return [zb[:, k] for k in range(6)], gu
+
+    def _vjp_tail(self, x, dt, v, om, q, R, Fb, Fwb, zb, gu, qtb, dqb, omb, Lp, Lv, gT, gtau):
+        qw, qx, qy, qz = q
         omb = [omb[i] + zb[3 + i] for i in range(3)]
         vbar = [fma(Lp[i], dt, Lv[i]) + fma(R[3 * i + 2], zb[2], fma(R[3 * i + 1], zb[1], R[3 * i] * zb[0])) for i in range(3)]
         Rb = [fma(v[i], zb[j], Fwb[i] * Fb[j]) for i in range(3) for j in range(3)]

@@ -173,7 +173,7 @@ typedef struct {
     /* SPEC.md §10e (f32x3 + fast): the three contractions of the MLP's vector-Jacobian products from two binary16 limbs each, behind a per-particle
      * power-of-two scale. Images [0 = (4 W2)^T, 1 = density tile: rows 0..5 = W1z[32 + k][row], 2 = drift tile: rows 0..5 = W1z[k][row], rows 6..6+m-1 = W1u[k][row - 6]][limb][row][K-half][slot] */
     int adjmp, adj_eoff;
-    int32_t y2m[3][3][HID][2][16], y2x[3][3][HID][2][16], y2mT[3][3][2][16][HID], y2xT[3][3][2][16][HID];
+    int32_t y2m[4][3][HID][2][16], y2x[4][3][HID][2][16], y2mT[4][3][2][16][HID], y2xT[4][3][2][16][HID];     /* image 3: (-2 W3)^T in k slots 0..5 of K-half 0 (row = layer-2 unit) */
 #endif
     real inv_mass, grav, J[3], iJ[3], ct2, ct1, ct0, cm2, cm1;
     real rx[MAXM], ry[MAXM], dir[MAXM];
@@ -425,15 +425,27 @@ static int parse_blob(const void* blob, model_t* M, int f16, int fast) {
         }
     }
     M->adjmp = 0; M->adj_eoff = 10;
-    if (f16 == 2 && M->fast && getenv("ORC_ADJMP") && atoi(getenv("ORC_ADJMP"))) {
+    if (f16 == 2 && M->fast) {
+        /* SPEC.md §10e: the scale offset (the same float32 statements as sdempc_create's: absolute column sums in ascending index order) */
         M->adjmp = 1;
-        if (getenv("ORC_ADJ_EOFF")) M->adj_eoff = atoi(getenv("ORC_ADJ_EOFF"));
-        for (int img = 0; img < 3; ++img) for (int i = 0; i < HID; ++i) for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k) {
+        float B3 = 0.0f, Bn = 0.0f, C2 = 0.0f;
+        for (int k = 0; k < HID; ++k) {
+            float s3 = 0.0f, s2 = 0.0f;
+            for (int i = 0; i < 6; ++i) s3 = s3 + fabsf(M->W3[i][k]);
+            for (int j = 0; j < HID; ++j) s2 = s2 + fabsf(M->vW2[j][k]);
+            B3 = fmaxf(B3, s3); C2 = fmaxf(C2, s2); Bn = fmaxf(Bn, fabsf(M->w3n[k]));
+        }
+        const float bound = fmaxf(fmaxf(B3 * 0.25f, Bn * 0.25f), (C2 * (B3 * 0.25f)) * 0.25f);
+        int eb = 0;
+        if (bound > 0.0f && bound < INFINITY) { (void)frexpf(bound, &eb); if (14 - eb < M->adj_eoff) M->adj_eoff = 14 - eb; }
+        if (M->adj_eoff < -40) M->adj_eoff = -40;
+        for (int img = 0; img < 4; ++img) for (int i = 0; i < HID; ++i) for (int hf = 0; hf < 2; ++hf) for (int k = 0; k < 16; ++k) {
             const int un = slot_unit(hf, k);
             float w = 0.0f;
             if (img == 0) w = M->vW2[un][i];                                   /* (4 W2)^T: row i = input unit, contraction over the layer-2 unit un */
             else if (img == 1) w = i < NN ? M->vW1z[HID + un][i] : 0.0f;
-            else w = i < NN ? M->vW1z[un][i] : (i < NN + M->m ? M->vW1u[un][i - NN] : 0.0f);
+            else if (img == 2) w = i < NN ? M->vW1z[un][i] : (i < NN + M->m ? M->vW1u[un][i - NN] : 0.0f);
+            else w = (hf == 0 && k < 6) ? M->W3[k][i] : 0.0f;                  /* the six output adjoints sit in k slots 0..5 of K-half 0 */
             uint16_t lb[3] = {f16_rne_bits(w), 0, 0};
             lb[1] = f16_rne_bits(w - f16_value(lb[0]));
             for (int l = 0; l < 3; ++l) { orc_op16 o; orc_mfma16_decode(0, lb[l], &o); M->y2m[img][l][i][hf][k] = M->y2mT[img][l][hf][k][i] = o.m; M->y2x[img][l][i][hf][k] = M->y2xT[img][l][hf][k][i] = o.ex; }
@@ -746,16 +758,17 @@ static void step_vjp(const model_t* M, const preal* x, const preal* xi, real dt,
         adj_inv = ldexpf(1.0f, e - M->adj_eoff);
         for (int i = 0; i < 6; ++i) ob[i] = ob[i] * s2;
         ebraw = ebraw * s2;
-        for (int k = 0; k < HID; ++k) {
-            float hb = 0.0f;
-            for (int i = 0; i < 6; ++i) hb = fmaf(M->W3[i][k], ob[i], hb);
-            a2b[k] = hb * DACT(M, A->h2[k]);
-        }
+        float ov[HID], hb3[HID];
+        for (int k = 0; k < HID; ++k) ov[k] = 0.0f;
+        for (int i = 0; i < 6; ++i) ov[slot_unit(0, i)] = ob[i];               /* k slot i of K-half 0 */
+        x3_contract(1, M->y2m[3], M->y2x[3], M->y2mT[3], M->y2xT[3], ov, NULL, hb3);          /* (only K-half 0 holds products: four instructions on the GPU) */
+        for (int k = 0; k < HID; ++k) a2b[k] = hb3[k] * DACT(M, A->h2[k]);
         float hb2[HID], zacc[HID], zacc2[HID];
         x3_contract(1, M->y2m[0], M->y2x[0], M->y2mT[0], M->y2xT[0], a2b, NULL, hb2);
         for (int k = 0; k < HID; ++k) { a1d[k] = hb2[k] * DACT(M, A->h1d[k]); a1n[k] = (M->w3n[k] * ebraw) * DACT(M, A->h1n[k]); }
         x3_contract(1, M->y2m[1], M->y2x[1], M->y2mT[1], M->y2xT[1], a1n, NULL, zacc);
-        x3_contract(1, M->y2m[2], M->y2x[2], M->y2mT[2], M->y2xT[2], a1d, zacc, zacc2);
+        x3_contract(1, M->y2m[2], M->y2x[2], M->y2mT[2], M->y2xT[2], a1d, NULL, zacc2);
+        for (int r = 0; r < 8; ++r) zacc2[r] = zacc2[r] + zacc[r];         /* rows 0..7 (accumulator registers 0..3 of either lane half): the density tile's rows, one float32 addition each */
         preal zb2[NN];
         for (int k = 0; k < NN; ++k) zb2[k] = zacc2[k] * adj_inv;
         for (int j = 0; j < M->m; ++j) gu[j] = zacc2[NN + j] * adj_inv;

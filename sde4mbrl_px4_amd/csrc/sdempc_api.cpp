@@ -486,6 +486,27 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     for (int i = 0; i < 3; ++i) { a.M.sF[i] = f[40 + i]; a.M.sT[i] = f[43 + i]; }
     for (int i = 0; i < 6; ++i) a.M.b3[i] = h->blob_f[blob::B3 + i];      // (math_mode fast: the forward block's, SPEC.md §10b)
     a.M.b3n = h->blob_f[blob::B3N];
+    a.M.adj_s0 = -2.0f; a.M.adj_i0 = 1.0f;
+    if (cfg->math_mode == 1 && cfg->mlp_dtype == 2) {
+        // SPEC.md §10e: the scale offset of the adjoint's binary16 contractions. With the largest output adjoint of a particle scaled into [2^eoff, 2^(eoff+1)),
+        // |abar2| < 2^(eoff+1) B3/4, |abar1n| < 2^(eoff+1) Bn/4, |abar1d| < 2^(eoff+1) C2 B3/16 (|r - r^2| <= 1/4; B3, Bn: absolute column sums of the forward
+        // output weights, C2: of 4 W2): eoff = min(10, 14 - e) with 2^e > the largest of the three bounds keeps all of them below 2^15 (binary16 ends at 65504).
+        // float32 host arithmetic, sums in ascending index order; the oracle derives the same number by the same statements.
+        const float* F = h->blob_f.data();
+        const float* V = F + SDEMPC_BLOB_FLOATS;
+        float B3 = 0.0f, Bn = 0.0f, C2 = 0.0f;
+        for (int k = 0; k < 32; ++k) {
+            float s3 = 0.0f, s2 = 0.0f;
+            for (int i = 0; i < 6; ++i) s3 = s3 + fabsf(F[blob::W3 + i * 32 + k]);
+            for (int j = 0; j < 32; ++j) s2 = s2 + fabsf(V[blob::W2 + j * 32 + k]);
+            B3 = fmaxf(B3, s3); C2 = fmaxf(C2, s2); Bn = fmaxf(Bn, fabsf(F[blob::W3N + k]));
+        }
+        const float bound = fmaxf(fmaxf(B3 * 0.25f, Bn * 0.25f), (C2 * (B3 * 0.25f)) * 0.25f);
+        int e = 0, eoff = 10;
+        if (bound > 0.0f && bound < INFINITY) { (void)frexpf(bound, &e); if (14 - e < eoff) eoff = 14 - e; }
+        if (eoff < -40) eoff = -40;
+        a.M.adj_s0 = ldexpf(-2.0f, eoff); a.M.adj_i0 = ldexpf(1.0f, -eoff);
+    }
     for (int i = 0; i < 3; ++i) { a.C.perr[i] = cfg->perr[i]; a.C.verr[i] = cfg->verr[i]; a.C.qerr[i] = cfg->qerr[i]; a.C.werr[i] = cfg->werr[i]; }
     a.C.res_mult = cfg->res_mult; a.C.uerr = cfg->uerr; a.C.slew = cfg->u_slew_coeff; a.C.slew_cc = cfg->u_slew_constr_coeff;
     a.C.has_sc = cfg->has_slew_constr;

@@ -411,10 +411,73 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             float gq[12], lamn[NX];
             vjp_head<M>(a, sm, t, xt, xi, A, lam, ebc, T, gq);
             float eA, eB, obA[6], obB[6];
+            float adj_inv = 1.0f;
+            ObLimbs OA, OB;
+            if constexpr (FAST && F16 == 2) {       // SPEC.md §10e: one power of two per particle, applied before the broadcast (once for both passes)
+                const AdjScale S = adj_scale(a, T.ebraw, T.ob);
+                adj_inv = S.inv;
+                half_split(T.ebraw * S.s2, eA, eB);
+                float obs[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) obs[i] = T.ob[i] * S.s2;
+                const ObLimbs O = ob_limbs(obs);          // per particle, once for both passes: the limbs are what is broadcast
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    float la, lb;
+                    half_split(__builtin_bit_cast(float, O.r1[i]), la, lb); OA.r1[i] = __builtin_bit_cast(unsigned, la); OB.r1[i] = __builtin_bit_cast(unsigned, lb);
+                    half_split(__builtin_bit_cast(float, O.r2[i]), la, lb); OA.r2[i] = __builtin_bit_cast(unsigned, la); OB.r2[i] = __builtin_bit_cast(unsigned, lb);
+                }
+            } else {
             half_split(T.ebraw, eA, eB);
 #pragma unroll
             for (int i = 0; i < 6; ++i) half_split(T.ob[i], obA[i], obB[i]);
+            }
             SCHED_PHASE();
+            float zb[NN];
+            if constexpr (FAST && F16 == 2) {
+                // (only AdjRegs<M>::N registers of a pass's result tile hold existing rows)
+                constexpr int NR = AdjRegs<M>::N;
+                float rA[NR], rB[NR];
+                // pass B's second-layer checkpoint is requested when pass A's drift net is done and arrives under pass A's and pass B's density phases; requested before
+                // pass A, as the f32 / three-limb forms do, this loop spilled it (three synchronous HBM round trips per step: profiles/r5_ab.txt §2)
+                // (pass B's six broadcast inputs wait in this wave's noise staging rows — idle during the adjoint sweep — while pass A runs: six registers that the
+                // loop otherwise takes from the checkpoint prefetch by spilling it)
+                if constexpr (NZS) {
+#pragma unroll
+                    for (int k = 0; k < NN; ++k) sm.nzs[k * 64 + lane] = zB[k];
+                }
+                adj_mlp_pass_mp<NR, false>(sm, ww, ust, h, lane, zA, hA, eA, OA, rA, [&]() {
+                    if (pr.hasB) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hB[q] = *reinterpret_cast<const float4*>(apB + (q * 64 + lane) * 4);
+                    }
+                });
+                SCHED_PHASE();
+                if constexpr (NZS) {
+#pragma unroll
+                    for (int k = 0; k < NN; ++k) zB[k] = sm.nzs[k * 64 + lane];
+                }
+                // (parking pass A's result rows there in turn while pass B runs was tried: the allocator answered with MORE spills in three of four kernels)
+                if (pr.hasB) adj_mlp_pass_mp<NR, true>(sm, ww, ust, h, lane, zB, hB, eB, OB, rB, []() {});
+                else {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(rB[r]) : "v"(rA[r]));      // (a register of its own: the swap below aliases otherwise)
+                }
+                SCHED_PHASE();
+                // rows of pass A belong to lanes < 32, rows of pass B to lanes >= 32: ONE swap per register pair puts row rowmap(r, 0) of either pass into the
+                // first result and row rowmap(r, 1) into the second, each in the lane half that owns the particle
+                float lo[8], hi[8];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, rA[r]), __builtin_bit_cast(unsigned, rB[r]), false, false);
+                    const unsigned s0 = sw[0], s1 = sw[1];
+                    lo[r] = __builtin_bit_cast(float, s0); hi[r] = __builtin_bit_cast(float, s1);
+                }
+#pragma unroll
+                for (int k = 0; k < NN; ++k) zb[k] = (adj_row_upper(k) ? hi[adj_row_reg(k)] : lo[adj_row_reg(k)]) * adj_inv;
+#pragma unroll
+                for (int jj = 0; jj < M; ++jj) gq[jj] = (adj_row_upper(NN + jj) ? hi[adj_row_reg(NN + jj)] : lo[adj_row_reg(NN + jj)]) * adj_inv;
+            } else {
             float PzA[NN], PuA[M], PzB[NN], PuB[M];
             // pass B's second-layer checkpoint is requested before pass A computes (requesting it later — once pass A has consumed its own
             // checkpoint, to reuse the registers — measured 35 % slower: vmcnt is in-order, the wait for it then also covers younger loads)
@@ -434,11 +497,11 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
                 for (int jj = 0; jj < M; ++jj) PuB[jj] = PuA[jj];
             }
             SCHED_PHASE();
-            float zb[NN];
 #pragma unroll
             for (int k = 0; k < NN; ++k) zb[k] = half_join_sum(PzA[k], PzB[k]);
 #pragma unroll
             for (int jj = 0; jj < M; ++jj) gq[jj] = half_join_sum(PuA[jj], PuB[jj]);
+            }
             duo_reform_rotation(xt, A.Rm);       // nine registers less across both MLP passes
             vjp_tail(sm, t, xt, A, lam, T, zb, lamn);
 #pragma unroll

@@ -29,6 +29,7 @@ struct ModelK {  // physics prior + small output-layer constants (SPEC.md §2), 
     float rx[8], ry[8], dir[8];
     float sF[3], sT[3];
     float b3[6], b3n;
+    float adj_s0, adj_i0;   // SPEC.md §10e (math_mode fast + f32x3): -2 * 2^eoff and 2^-eoff, the handle's scale offset of the adjoint's binary16 contractions
 };
 struct CostK {
     float perr[3], verr[3], qerr[3], werr[3];

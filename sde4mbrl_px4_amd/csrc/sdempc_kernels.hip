@@ -172,6 +172,12 @@ struct Smem {
     float *nzs;                                        // duo layout only: this WAVE's noise staging rows [6][64] (LDS-DMA target), behind every team's state
 };
 constexpr int NZ_STAGE = 6 * 64;                       // floats per wave
+// SPEC.md §10e (math_mode fast + f32x3): compact A-operand images of the adjoint's two narrow contractions, in the slack of the 3072-float limb region
+// (in this mode the forward and the transposed W2 image take two binary16 limbs each: floats 0..1023 and 1536..2559 of the region)
+constexpr int ZROWS_D = 15, ZROWS_N = 7;               // drift image: rows 0..5 zbar, 6..13 W1u^T (m <= 8), 14 zero; density image: rows 0..5, 6 zero
+constexpr int AZD_OFF = 1024, AZN_OFF = 2560;          // floats from sm.A2; 2 limbs x 2 K-halves x 2 lane halves x ROWS x 16 bytes = 480 / 224 floats
+constexpr int A3T_OFF = 2784, A3T_ROWS = 33;           // (-2 W3)^T for the K = 6 contraction with the output adjoints: [limb][row][8 x binary16], k slots 0..5 of the LOWER lane half; row 32 zero (upper half)
+static_assert(AZD_OFF + 2 * 2 * 2 * ZROWS_D * 4 <= 1536 && AZN_OFF + 2 * 2 * 2 * ZROWS_N * 4 <= A3T_OFF && A3T_OFF + 2 * A3T_ROWS * 4 <= 3072, "adjoint images must fit the slack of the limb region");
 constexpr int UST = 36;
 constexpr int REC = 64, NZL = 8;                       // cooperative layouts: floats per step record / per noise row in LDS (sdempc_lane2.inc.h)
 constexpr int COOP_ROW = 172;                          // floats per (particle, step) checkpoint row of the cooperative layouts (sdempc_lane2.inc.h)
@@ -274,14 +280,18 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid, int BNT
         for (int i = tid; i < 2 * 64 * 8; i += BNT) {
             const int e = i & 7, l = (i >> 3) & 63, hf = i >> 9, jj = l & 31, hh = l >> 5, un = rowmap(8 * hf + e, hh);
             float wv[2] = {w[OFF_W2 + jj * HID + un], w[VJP_BASE + OFF_W2 + un * HID + jj]};
-            if constexpr (FAST) {       // SPEC.md §10c: the forward operand as two binary16 limbs, round to nearest even (the casts), w - limb exact
-                const _Float16 h1 = (_Float16)wv[0];
-                const _Float16 h2 = (_Float16)(wv[0] - (float)h1);
-                ax[(0 * 2 + hf) * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, h1);
-                ax[(1 * 2 + hf) * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, h2);
+            if constexpr (FAST) {       // SPEC.md §10c / §10e: either operand image as two binary16 limbs, round to nearest even (the casts), w - limb exact
+#pragma unroll
+                for (int tr = 0; tr < 2; ++tr) {
+                    unsigned short* dst = tr ? axt : ax;
+                    const _Float16 h1 = (_Float16)wv[tr];
+                    const _Float16 h2 = (_Float16)(wv[tr] - (float)h1);
+                    dst[(0 * 2 + hf) * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, h1);
+                    dst[(1 * 2 + hf) * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, h2);
+                }
             }
 #pragma unroll
-            for (int tr = FAST ? 1 : 0; tr < 2; ++tr) {
+            for (int tr = FAST ? 2 : 0; tr < 2; ++tr) {
                 unsigned short* dst = tr ? axt : ax;
                 float rem = wv[tr];
 #pragma unroll
@@ -290,6 +300,36 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid, int BNT
                     dst[(lb * 2 + hf) * 512 + l * 8 + e] = (unsigned short)(hi >> 16);
                     rem = rem - __uint_as_float(hi);
                 }
+            }
+        }
+        if constexpr (FAST) {
+            // SPEC.md §10e: compact A-operand images of the adjoint's two narrow contractions, [limb][K-half][lane half][row][8 x binary16], last row zero:
+            // drift tile rows 0..5 = W1z[un][row], rows 6..6+m-1 = W1u[un][row-6]; density tile rows 0..5 = W1z[32+un][row] (the VJP block's: as given)
+            unsigned short* zd = reinterpret_cast<unsigned short*>(sm.A2 + AZD_OFF);
+            unsigned short* zn = reinterpret_cast<unsigned short*>(sm.A2 + AZN_OFF);
+            for (int i = tid; i < 2 * 2 * (ZROWS_D + ZROWS_N) * 8; i += BNT) {
+                const int e = i & 7, rw = (i >> 3) % (ZROWS_D + ZROWS_N), hh = ((i >> 3) / (ZROWS_D + ZROWS_N)) & 1, hf = ((i >> 3) / (ZROWS_D + ZROWS_N)) >> 1;
+                const int un = rowmap(8 * hf + e, hh);
+                const bool dr = rw < ZROWS_D;
+                const int row = dr ? rw : rw - ZROWS_D;
+                float wz = 0.0f;
+                if (dr) wz = row < NN ? w[VJP_BASE + OFF_W1Z + un * NN + row] : (row < NN + a.m ? w[VJP_BASE + OFF_W1U + un * 8 + (row - NN)] : 0.0f);
+                else if (row < NN) wz = w[VJP_BASE + OFF_W1Z + (HID + un) * NN + row];
+                const _Float16 h1 = (_Float16)wz;
+                const _Float16 h2 = (_Float16)(wz - (float)h1);
+                unsigned short* dst = dr ? zd : zn;
+                const int R = dr ? ZROWS_D : ZROWS_N;
+                dst[(((0 * 2 + hf) * 2 + hh) * R + row) * 8 + e] = __builtin_bit_cast(unsigned short, h1);
+                dst[(((1 * 2 + hf) * 2 + hh) * R + row) * 8 + e] = __builtin_bit_cast(unsigned short, h2);
+            }
+            unsigned short* a3 = reinterpret_cast<unsigned short*>(sm.A2 + A3T_OFF);
+            for (int i = tid; i < A3T_ROWS * 8; i += BNT) {
+                const int e = i & 7, row = i >> 3;
+                const float w3v = (row < HID && e < 6) ? w[OFF_W3 + e * HID + row] : 0.0f;       // the forward block's -2 W3 (SPEC.md §10b)
+                const _Float16 h1 = (_Float16)w3v;
+                const _Float16 h2 = (_Float16)(w3v - (float)h1);
+                a3[(0 * A3T_ROWS + row) * 8 + e] = __builtin_bit_cast(unsigned short, h1);
+                a3[(1 * A3T_ROWS + row) * 8 + e] = __builtin_bit_cast(unsigned short, h2);
             }
         }
     } else

@@ -65,20 +65,12 @@ DI void mfma_x3(const float* Aimg, int lane, const Limbs3& L, f32x16& acc) {
     }
 }
 
-#ifndef SDEMPC_VAR_ADJMP
-#define SDEMPC_VAR_ADJMP 0
-#endif
-#if SDEMPC_VAR_ADJMP
-// TIMING-ONLY (profiles/r5_ab.txt §1): a tile split into two binary16 limbs (the forward split of SPEC.md §10c) and contracted by eight
-// v_mfma_f32_32x32x16_f16 against whatever the LDS image `img` holds — the instruction mix of an adjoint whose three contractions (W2^T abar2, W1z^T abar1n,
-// [W1z; W1u]^T abar1d) run on the matrix pipe behind a per-particle power-of-two scale. Values are wrong.
-DI void var_split2h_mfma(const float* img, int lane, const f32x16& v, f32x16& acc) {
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    u32x4 r1[2], r2[2], aw[2][2];
-#pragma unroll
-    for (int lb = 0; lb < 2; ++lb)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) aw[lb][hf] = *reinterpret_cast<const u32x4*>(img + ((lb * 2 + hf) * 64 + lane) * 4);
+// ---- SPEC.md §10c / §10e: contractions from TWO binary16 limbs of either operand (math_mode fast + mlp_dtype f32x3) ----
+// A tile's sixteen values per lane split by round to nearest (v_cvt_pk_f16_f32 packs two values per instruction, v_fma_mix_f32 forms the exact residual
+// x - limb straight from the packed half): 2 instructions per value, against 5.5 for the three-limb bf16 split.
+typedef _Float16 h8x __attribute__((ext_vector_type(8)));
+struct Limbs2 { u32x4 r1[2], r2[2]; };      // [K-half]: 8 binary16 per lane = this lane half's k slots; r1 the leading limb
+DI void split2h_tile(const f32x16& v, Limbs2& L) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
@@ -86,18 +78,163 @@ DI void var_split2h_mfma(const float* img, int lane, const f32x16& v, f32x16& ac
             const float x = v[8 * hf + 2 * pr], y = v[8 * hf + 2 * pr + 1];
             unsigned p1, p2; float xr, yr;
             asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(x), "v"(y));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(xr) : "v"(p1), "v"(x));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(yr) : "v"(p1), "v"(y));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(xr) : "v"(p1), "v"(x));                      // x - (float)p1.lo, exact
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(yr) : "v"(p1), "v"(y));     // y - (float)p1.hi
             asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p2) : "v"(xr), "v"(yr));
-            r1[hf][pr] = p1; r2[hf][pr] = p2;
+            L.r1[hf][pr] = p1; L.r2[hf][pr] = p2;
         }
+}
+// acc += the four limb products (w2,v2) (w2,v1) (w1,v2) (w1,v1), each over the two K halves: eight v_mfma_f32_32x32x16_f16. aw[limb][K-half]: the weight fragments
+DI void mfma_2h(const u32x4 (&aw)[2][2], const Limbs2& L, f32x16& acc) {
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, aw[s4 < 2 ? 1 : 0][hf]), __builtin_bit_cast(h8, (s4 & 1) ? r1[hf] : r2[hf]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8x, aw[s4 < 2 ? 1 : 0][hf]), __builtin_bit_cast(h8x, (s4 & 1) ? L.r1[hf] : L.r2[hf]), acc, 0, 0, 0);
 }
-#endif
+// weight fragments of a full 32-row image [limb][K-half][lane][8 x binary16] (load_weights: sm.A2x forward, sm.A2xT transposed)
+DI void load_aw_full(const float* img, int lane, u32x4 (&aw)[2][2]) {
+#pragma unroll
+    for (int lb = 0; lb < 2; ++lb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) aw[lb][hf] = *reinterpret_cast<const u32x4*>(img + ((lb * 2 + hf) * 64 + lane) * 4);
+}
+// SPEC.md §10e: the adjoint's two narrow contractions (6 rows: W1z^T abar1n; 6 + m rows: [W1z; W1u]^T abar1d) take their A operand from COMPACT images
+// [limb][K-half][lane half][ROWS][8 x binary16] whose last row is zero: lanes whose output row does not exist read that row
+// (ZROWS_D / ZROWS_N rows, at sm.A2 + AZD_OFF / AZN_OFF: sdempc_kernels.hip, beside Smem)
+template <int ROWS>
+DI void load_aw_rows(const float* img, int lane, u32x4 (&aw)[2][2]) {
+    const int row = lane & 31, hh = lane >> 5, rr = row < ROWS - 1 ? row : ROWS - 1;
+#pragma unroll
+    for (int lb = 0; lb < 2; ++lb)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) aw[lb][hf] = *reinterpret_cast<const u32x4*>(img + ((((lb * 2 + hf) * 2 + hh) * ROWS) + rr) * 4);
+}
+// One power of two per particle brings the seven output adjoints of the MLPs to 2^eoff (the largest of them into [2^eoff, 2^(eoff+1)) once the -2 of the
+// forward output weights is in): everything between here and the unscaling is linear in them, every scaling is exact, and the bounded quantities can
+// take binary16 limbs. s2 = -2 * 2^(eoff - e) multiplies the adjoints, inv = 2^(e - eoff) the results; KArgs::M carries -2 * 2^eoff and 2^-eoff (sdempc_create).
+struct AdjScale { float s2, inv; };
+DI AdjScale adj_scale(const KArgs& a, float ebraw, const float* ob) {
+    float mx = fmaxf(fabsf(ebraw), fabsf(ob[0]));
+#pragma unroll
+    for (int i = 1; i < 6; ++i) mx = fmaxf(mx, fabsf(ob[i]));
+    int e = __builtin_amdgcn_frexp_expf(mx);          // 0 for zero, infinity and NaN
+    e = e < -100 ? -100 : e;
+    AdjScale S;
+    S.s2 = __builtin_amdgcn_ldexpf(a.M.adj_s0, -e);
+    S.inv = __builtin_amdgcn_ldexpf(a.M.adj_i0, e);
+    return S;
+}
+// The six scaled output adjoints of a particle as two binary16 limbs each, packed in pairs: the B operand (k slots 0..5) of the K = 6 contraction with (-2 W3)^T
+struct ObLimbs { unsigned r1[3], r2[3]; };
+DI ObLimbs ob_limbs(const float* ob) {
+    ObLimbs O;
+#pragma unroll
+    for (int pr = 0; pr < 3; ++pr) {
+        const float x = ob[2 * pr], y = ob[2 * pr + 1];
+        unsigned p1, p2; float xr, yr;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(x), "v"(y));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(xr) : "v"(p1), "v"(x));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(yr) : "v"(p1), "v"(y));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p2) : "v"(xr), "v"(yr));
+        O.r1[pr] = p1; O.r2[pr] = p2;
+    }
+    return O;
+}
+// Results of the narrow contractions in the accumulator layout: register r of lane half hh holds output row rowmap(r, hh) — rows 0..3 in registers 0..3 of the
+// lower half, 4..7 in registers 0..3 of the upper half, 8..11 in registers 4..7 of the lower half. Row k < 6 is zbar_k, row 6 + j is (W1u^T abar1d)_j.
+// One group per wave (both lane halves hold the same particle): a swap of a register with its copy leaves {lower, lower} and {upper, upper}.
+// (row -> register / lane half; ADJ_REGS<M>: accumulator registers that hold an existing row)
+DI constexpr int adj_row_reg(int row) { return (row >> 3) * 4 + (row & 3); }
+DI constexpr bool adj_row_upper(int row) { return ((row >> 2) & 1) != 0; }
+template <int M> struct AdjRegs { static constexpr int N = M <= 2 ? 4 : (M <= 6 ? M + 2 : 8); };
+template <int M>
+DI void adj_rows_tile(const float* accZ, float inv, float* zb, float* gq) {
+    float lo[8], hi[8];
+#pragma unroll
+    for (int r = 0; r < AdjRegs<M>::N; ++r) {
+        unsigned a0 = __builtin_bit_cast(unsigned, accZ[r]), b0;
+        asm("v_mov_b32 %0, %1" : "=v"(b0) : "v"(a0));
+        auto sw = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const unsigned s0 = sw[0], s1 = sw[1];
+        lo[r] = __builtin_bit_cast(float, s0); hi[r] = __builtin_bit_cast(float, s1);
+    }
+#pragma unroll
+    for (int k = 0; k < NN; ++k) zb[k] = (adj_row_upper(k) ? hi[adj_row_reg(k)] : lo[adj_row_reg(k)]) * inv;
+#pragma unroll
+    for (int jj = 0; jj < M; ++jj) gq[jj] = (adj_row_upper(NN + jj) ? hi[adj_row_reg(NN + jj)] : lo[adj_row_reg(NN + jj)]) * inv;
+}
+// the three contractions of one 32-particle pass (SPEC.md §10e); ebraw / ob already carry the scale; hn / hd / h2: the r-tiles of the density net's and the drift net's
+// first layer and of the drift net's second layer (from registers, a recompute or the checkpoint: callers differ). The density tile is consumed first.
+// The density tile's contraction has six rows: registers 0..3 of its result — rows 0..7 — are added to the drift tile's rows (SPEC.md §10e states the sum that
+// way; one float32 addition each). It runs LAST in a pass: by then the pass's second-layer checkpoint and the drift tiles are dead, and pass B's checkpoint, which
+// is in flight since before pass A, keeps its registers (requested a phase earlier this loop spilled it: three synchronous HBM round trips per step).
+DI void adj_mp_density(const Smem& sm, int h, int lane, f32x16& hn, float ebraw, float* rows) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
+        hn[4 * q] = (wn4.x * ebraw) * dact(hn[4 * q]); hn[4 * q + 1] = (wn4.y * ebraw) * dact(hn[4 * q + 1]);
+        hn[4 * q + 2] = (wn4.z * ebraw) * dact(hn[4 * q + 2]); hn[4 * q + 3] = (wn4.w * ebraw) * dact(hn[4 * q + 3]);
+    }
+    SCHED_PHASE();
+    Limbs2 L;
+    split2h_tile(hn, L);
+    u32x4 aw[2][2];
+    load_aw_rows<ZROWS_N>(sm.A2 + AZN_OFF, lane, aw);
+    f32x16 accZ;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accZ[r] = 0.0f;
+    mfma_2h(aw, L, accZ);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rows[r] = rows[r] + accZ[r];
+}
+template <class H2>
+DI void adj_mp_layer2(const Smem& sm, int lane, const H2& h2_of, const ObLimbs& O, f32x16& accB) {
+    // abar2 = ((-2 W3)^T obar') (r2 - r2^2): the K = 6 contraction as four v_mfma_f32_32x32x16_f16 — limb products (w2,o2) (w2,o1) (w1,o2) (w1,o1), k slots 0..5 of the
+    // lower lane half; the upper half's A operand is the zero row (its k slots 8..15 do not exist) — straight into the accumulator layout the rest of the pass works in
+    const int rr = (lane >> 5) ? A3T_ROWS - 1 : (lane & 31);
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(sm.A2 + A3T_OFF + (0 * A3T_ROWS + rr) * 4);
+    const u32x4 a2 = *reinterpret_cast<const u32x4*>(sm.A2 + A3T_OFF + (1 * A3T_ROWS + rr) * 4);
+    u32x4 b1, b2;
+    b1[0] = O.r1[0]; b1[1] = O.r1[1]; b1[2] = O.r1[2]; b1[3] = 0u;
+    b2[0] = O.r2[0]; b2[1] = O.r2[1]; b2[2] = O.r2[2]; b2[3] = 0u;
+    f32x16 a2b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a2b[r] = 0.0f;
+    a2b = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8x, a2), __builtin_bit_cast(h8x, b2), a2b, 0, 0, 0);
+    a2b = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8x, a2), __builtin_bit_cast(h8x, b1), a2b, 0, 0, 0);
+    a2b = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8x, a1), __builtin_bit_cast(h8x, b2), a2b, 0, 0, 0);
+    a2b = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8x, a1), __builtin_bit_cast(h8x, b1), a2b, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 hq = h2_of(q);
+        a2b[4 * q] = a2b[4 * q] * dact(hq.x); a2b[4 * q + 1] = a2b[4 * q + 1] * dact(hq.y); a2b[4 * q + 2] = a2b[4 * q + 2] * dact(hq.z); a2b[4 * q + 3] = a2b[4 * q + 3] * dact(hq.w);
+    }
+    SCHED_PHASE();
+    Limbs2 L;
+    split2h_tile(a2b, L);
+    u32x4 aw[2][2];
+    load_aw_full(sm.A2xT, lane, aw);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
+    mfma_2h(aw, L, accB);
+}
+template <int NR>
+DI void adj_mp_drift(const Smem& sm, int lane, const f32x16& hd, const f32x16& accB, float* rows) {
+    u32x4 aw[2][2];
+    f32x16 ad;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ad[r] = accB[r] * dact(hd[r]);
+    load_aw_rows<ZROWS_D>(sm.A2 + AZD_OFF, lane, aw);
+    Limbs2 L;
+    split2h_tile(ad, L);
+    f32x16 accZ;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accZ[r] = 0.0f;
+    mfma_2h(aw, L, accZ);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) rows[r] = accZ[r];
+}
 
 // ---- MLPs of a step in the MFMA tile layout (32 particles per wave) ----
 // fwd_mlp_partials: the hidden tiles (A.h1d, A.h1n, A.h2) and the per-half partial chains of the seven output-layer dot products
@@ -174,31 +311,13 @@ DI void fwd_mlp_partials(const KArgs& a, const Smem& sm, const WaveW& ww, const 
             // half): 2 instructions per value instead of 5.5, and eight v_mfma_f32_32x32x16_f16 on the limb products (w2,r2) (w2,r1) (w1,r2) (w1,r1)
             // instead of twelve bf16 ones. The four weight fragments (load_weights: two binary16 limbs of the forward weights) are requested first
             // and fly under the split.
-            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-            u32x4 r1[2], r2[2], aw[2][2];
-#pragma unroll
-            for (int lb = 0; lb < 2; ++lb)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) aw[lb][hf] = *reinterpret_cast<const u32x4*>(sm.A2x + ((lb * 2 + hf) * 64 + lane) * 4);
+            u32x4 aw[2][2];
+            load_aw_full(sm.A2x, lane, aw);
             SCHED_PHASE();
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-                for (int pr = 0; pr < 4; ++pr) {
-                    const float x = accD[8 * hf + 2 * pr], y = accD[8 * hf + 2 * pr + 1];
-                    unsigned p1, p2; float xr, yr;
-                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p1) : "v"(x), "v"(y));
-                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(xr) : "v"(p1), "v"(x));                      // x - (float)p1.lo, exact
-                    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(yr) : "v"(p1), "v"(y));     // y - (float)p1.hi
-                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(p2) : "v"(xr), "v"(yr));
-                    r1[hf][pr] = p1; r2[hf][pr] = p2;
-                }
+            Limbs2 L;
+            split2h_tile(accD, L);
             SCHED_PHASE();
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, aw[s4 < 2 ? 1 : 0][hf]), __builtin_bit_cast(h8, (s4 & 1) ? r1[hf] : r2[hf]), acc2, 0, 0, 0);
+            mfma_2h(aw, L, acc2);
         } else {
             Limbs3 L;
             split3_tile(accD, L);
@@ -581,6 +700,42 @@ DI void layer1_tile(const Smem& sm, const WaveW& ww, const float* ust, int h, co
     tanh_tile<false>(acc);
 }
 
+// SPEC.md §10e (math_mode fast + f32x3): the same pass with the scaled adjoints and its three contractions on the matrix pipe; leaves the result tile (rows 0..5 zbar,
+// 6.. W1u^T abar1d, still scaled) as the NR accumulator registers that hold existing rows. One hidden tile at a time, like adj_mlp_pass.
+// DENS_FIRST: the density tile before the drift net (pass B of the duo layout: its second-layer checkpoint is requested only once pass A's is consumed — the hook
+// after_l2 of pass A — and arrives under the density phase); otherwise the drift net first (pass A: its checkpoint is already there). The two tiles' rows are added
+// (commutative: the same bits either way).
+template <int NR, bool DENS_FIRST, class Hook>
+DI void adj_mlp_pass_mp(const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, const float4* h2c, float ebraw, const ObLimbs& O, float* rows, const Hook& after_l2) {
+    float rn[4];
+    if constexpr (DENS_FIRST) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rn[r] = 0.0f;
+        f32x16 hn;
+        layer1_tile<2, false>(sm, ww, ust, h, z, hn);
+        adj_mp_density(sm, h, lane, hn, ebraw, rn);
+        SCHED_PHASE();
+    }
+    f32x16 accB;
+    adj_mp_layer2(sm, lane, [&](int q) { return h2c[q]; }, O, accB);
+    SCHED_PHASE();
+    {
+        f32x16 hd;
+        layer1_tile<2, true>(sm, ww, ust, h, z, hd);
+        adj_mp_drift<NR>(sm, lane, hd, accB, rows);
+    }
+    after_l2();
+    if constexpr (DENS_FIRST) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rows[r] = rows[r] + rn[r];
+    } else {
+        SCHED_PHASE();
+        f32x16 hn;
+        layer1_tile<2, false>(sm, ww, ust, h, z, hn);
+        adj_mp_density(sm, h, lane, hn, ebraw, rows);
+    }
+}
+
 // The adjoint's MLP work of one 32-particle pass with short live ranges (one hidden tile at a time): density tile recomputed and
 // consumed, then abar2 from the checkpointed second layer (h2c: this lane's four float4 of the tile), W2^T abar2 by MFMA, and only
 // then the drift layer-1 tile recomputed and consumed. Same operations and the same chain order per value as step_fwd's layer 1 +
@@ -596,36 +751,10 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
     for (int k = 0; k < NN; ++k) Pz[k] = 0.0f;
 #pragma unroll
     for (int jj = 0; jj < M; ++jj) Pu[jj] = 0.0f;
-#if SDEMPC_VAR_ADJMP
-    f32x16 var_accZ; float var_unscale = 1.0f;
-#endif
     {   // density net: abar1n = (w3n * etaraw_bar) * (1 - h1n^2); zbar += W1z[32:64]^T abar1n
         f32x16 hn;
         layer1_tile<F16, false>(sm, ww, ust, h, z, hn);
         // (weight quads of a quarter are requested from LDS together, then consumed: one exposed LDS round trip per quarter, see fwd_mlp_partials)
-#if SDEMPC_VAR_ADJMP
-        if constexpr (FAST && F16 == 2) {
-            // TIMING-ONLY: scale from the largest output adjoint (free in the -2 multiplier), abar1n as a tile, W1z^T abar1n on the matrix pipe
-            float sc = fabsf(ob_in[0]);
-#pragma unroll
-            for (int i = 1; i < 6; ++i) sc = fmaxf(sc, fabsf(ob_in[i]));
-            sc = fmaxf(sc, fabsf(ebraw_in));
-            sc = __builtin_amdgcn_ldexpf(1.0f, -__builtin_amdgcn_frexp_expf(sc));
-#pragma unroll
-            for (int i = 0; i < 6; ++i) ob[i] = ob[i] * sc;
-            f32x16 an;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
-                an[4 * q] = (wn4.x * (ebraw * sc)) * dact(hn[4 * q]); an[4 * q + 1] = (wn4.y * (ebraw * sc)) * dact(hn[4 * q + 1]);
-                an[4 * q + 2] = (wn4.z * (ebraw * sc)) * dact(hn[4 * q + 2]); an[4 * q + 3] = (wn4.w * (ebraw * sc)) * dact(hn[4 * q + 3]);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) var_accZ[r] = 0.0f;
-            var_split2h_mfma(sm.A2xT, lane, an, var_accZ);
-            var_unscale = __builtin_amdgcn_rcpf(sc);
-        } else
-#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 wn4 = *reinterpret_cast<const float4*>(sm.w3n + 8 * q + 4 * h);
@@ -677,15 +806,9 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
         if constexpr (F16 == 2) {       // SPEC.md §9b: W2^T abar2 as the three-limb bf16 split on the matrix pipe
-#if SDEMPC_VAR_ADJMP
-            if constexpr (FAST) var_split2h_mfma(sm.A2xT, lane, a2b, accB);
-            else
-#endif
-            {
             Limbs3 L;
             split3_tile(a2b, L);
             mfma_x3(sm.A2xT, lane, L, accB);
-            }
         } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -701,19 +824,6 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
     {   // drift net, first layer: recomputed only now
         f32x16 hd;
         layer1_tile<F16, true>(sm, ww, ust, h, z, hd);
-#if SDEMPC_VAR_ADJMP
-        if constexpr (FAST && F16 == 2) {
-            f32x16 ad;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ad[r] = accB[r] * dact(hd[r]);
-            var_split2h_mfma(sm.A2xT, lane, ad, var_accZ);
-            // outputs: rows 0..5 = zbar, 6..6+M-1 = W1u^T abar1d, in the accumulator layout (registers 0..3 of either lane half, 4 / 5 of the lower): unscaled
-#pragma unroll
-            for (int k = 0; k < NN; ++k) Pz[k] = var_accZ[k & 3] * var_unscale + (k >= 4 ? var_accZ[4 + (k & 1)] : 0.0f);
-#pragma unroll
-            for (int jj = 0; jj < M; ++jj) Pu[jj] = var_accZ[(jj + 2) & 7] * var_unscale;
-        } else
-#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float ad0 = accB[4 * q] * dact(hd[4 * q]);
@@ -748,7 +858,22 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
 }
 
 template <int M, int F16 = 0>
-DI void vjp_mlp_tiles(const Smem& sm, int h, int lane, const StepAux& A, const VjpTmp& T, float* zb, float* gq) {
+DI void vjp_mlp_tiles(const KArgs& a, const Smem& sm, int h, int lane, const StepAux& A, const VjpTmp& T, float* zb, float* gq) {
+    if constexpr (FAST && F16 == 2) {       // SPEC.md §10e: scaled adjoints, the three contractions on the matrix pipe from binary16 limbs
+        const AdjScale S = adj_scale(a, T.ebraw, T.ob);
+        float ob[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ob[i] = T.ob[i] * S.s2;
+        const ObLimbs O = ob_limbs(ob);
+        f32x16 accB, hn = A.h1n;
+        float rows[AdjRegs<M>::N];
+        adj_mp_layer2(sm, lane, [&](int q) { return make_float4(A.h2[4 * q], A.h2[4 * q + 1], A.h2[4 * q + 2], A.h2[4 * q + 3]); }, O, accB);
+        adj_mp_drift<AdjRegs<M>::N>(sm, lane, A.h1d, accB, rows);
+        adj_mp_density(sm, h, lane, hn, T.ebraw * S.s2, rows);
+        adj_rows_tile<M>(rows, S.inv, zb, gq);
+        SCHED_PHASE();
+        return;
+    }
     float Pz[NN], Pu[M];
     vjp_mlp_partials<M, F16>(sm, h, lane, A, T.ebraw, T.ob, Pz, Pu);
 #pragma unroll
@@ -813,7 +938,7 @@ DI void step_vjp(const KArgs& a, const Smem& sm, const WaveW& ww, int t, int h, 
     vjp_head<M>(a, sm, t, x, xi, A, L, etabar_cost, T, gq);
     SCHED_PHASE();
     float zb[NN];
-    vjp_mlp_tiles<M, F16>(sm, h, lane, A, T, zb, gq);
+    vjp_mlp_tiles<M, F16>(a, sm, h, lane, A, T, zb, gq);
     vjp_tail(sm, t, x, A, L, T, zb, lam);
 }
 

@@ -76,7 +76,8 @@ DTYPE_NOTE = {
 }
 MATH_NOTE = {"exact": "activations by the software forms of SPEC.md 3", "fast": "activations on v_exp_f32 / v_rcp_f32 (1 ulp), kept as r = 1 / (1 + 2^a') with their affine maps folded into the weights (SPEC.md 10b), quaternion "
              "renormalisation on v_rsq_f32; in f32x3 the forward layer-2 contraction takes two binary16 limbs (round to nearest, 2^-24) of the bounded activations and of the "
-             "weights on v_mfma_f32_32x32x16_f16 (SPEC.md 10c), the adjoint's keeps three bf16 limbs; bit-identical to the CPU oracle through its models of the three "
+             "weights on v_mfma_f32_32x32x16_f16 (SPEC.md 10c), and so do all four contractions of the adjoint sweep behind a per-particle power-of-two scale (SPEC.md 10e; "
+             "mlp_dtype f16 too); bit-identical to the CPU oracle through its models of the three "
              "transcendental instructions (SPEC.md 10a) and of the matrix instruction (9a)"}
 
 

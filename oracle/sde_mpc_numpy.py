@@ -464,7 +464,7 @@ class Restatement:
             M.W3, M.b3, M.w3n, M.b3n = (F(-2) * M.W3).astype(F), b3, (F(-2) * M.w3n).astype(F), b3n
         # SPEC.md §10e (math_mode fast + f32x3): the adjoint's contractions from binary16 limbs behind a per-particle power-of-two scale; its offset from
         # bounds on the scaled quantities (float32, absolute column sums in ascending index order)
-        self.adjmp = self.fast and self.mlp == "f32x3"
+        self.adjmp = self.fast and self.mlp in ("f32x3", "f16")
         if self.adjmp:
             B3, Bn, C2 = F(0), F(0), F(0)
             for k in range(32):

@@ -425,8 +425,8 @@ static int parse_blob(const void* blob, model_t* M, int f16, int fast) {
         }
     }
     M->adjmp = 0; M->adj_eoff = 10;
-    if (f16 == 2 && M->fast) {
-        /* SPEC.md §10e: the scale offset (the same float32 statements as sdempc_create's: absolute column sums in ascending index order) */
+    if ((f16 == 2 || f16 == 1) && M->fast) {
+        /* SPEC.md §10e (both matrix-pipe contraction modes in math_mode fast): the scale offset (the same float32 statements as sdempc_create's: absolute column sums in ascending index order) */
         M->adjmp = 1;
         float B3 = 0.0f, Bn = 0.0f, C2 = 0.0f;
         for (int k = 0; k < HID; ++k) {

@@ -487,7 +487,7 @@ int sdempc_create(const sdempc_cfg* cfg, const void* model_blob, size_t blob_byt
     for (int i = 0; i < 6; ++i) a.M.b3[i] = h->blob_f[blob::B3 + i];      // (math_mode fast: the forward block's, SPEC.md §10b)
     a.M.b3n = h->blob_f[blob::B3N];
     a.M.adj_s0 = -2.0f; a.M.adj_i0 = 1.0f;
-    if (cfg->math_mode == 1 && cfg->mlp_dtype == 2) {
+    if (cfg->math_mode == 1 && cfg->mlp_dtype != 0) {
         // SPEC.md §10e: the scale offset of the adjoint's binary16 contractions. With the largest output adjoint of a particle scaled into [2^eoff, 2^(eoff+1)),
         // |abar2| < 2^(eoff+1) B3/4, |abar1n| < 2^(eoff+1) Bn/4, |abar1d| < 2^(eoff+1) C2 B3/16 (|r - r^2| <= 1/4; B3, Bn: absolute column sums of the forward
         // output weights, C2: of 4 W2): eoff = min(10, 14 - e) with 2^e > the largest of the three bounds keeps all of them below 2^15 (binary16 ends at 65504).

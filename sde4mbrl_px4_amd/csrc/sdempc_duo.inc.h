@@ -378,6 +378,18 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             float4 hA[4], hB[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) hA[q] = *reinterpret_cast<const float4*>(apA + (q * 64 + lane) * 4);
+            float touched = 0.0f;
+            {
+                // Pass B's checkpoint tile (4 KB = 32 lines of 128 bytes) is only TOUCHED here — one dword per line, into a register nobody reads — and loaded right before
+                // pass B needs it (an L2 hit by then). The compiler does not know the touch: an unknown OLDER load only makes its vmcnt waits longer, never shorter.
+                // The destination register must stay reserved until the load has certainly returned — the compiler believes the asm is over at once and would hand the
+                // register to someone else, whose value the returning dword then overwrites (a memory fault within the first launch, round 5): `touched` is kept alive
+                // by an empty asm BEHIND pass B, which has waited for its own, younger checkpoint loads by then (loads return in order).
+                if (pr.hasB) {
+                    const float* tp = apB + (lane & 31) * 32;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(touched) : "v"(tp) : "memory");
+                }
+            }
             const unsigned so = aso + (unsigned)(t * ACT_STRIDE);
             const float4 ns4 = *reinterpret_cast<const float4*>(acA + so);
             const float nrn = acA[so + 4];
@@ -413,7 +425,7 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             float eA, eB, obA[6], obB[6];
             float adj_inv = 1.0f;
             ObLimbs OA, OB;
-            if constexpr (FAST && F16 == 2) {       // SPEC.md §10e: one power of two per particle, applied before the broadcast (once for both passes)
+            if constexpr (FAST && F16 != 0) {       // SPEC.md §10e: one power of two per particle, applied before the broadcast (once for both passes)
                 const AdjScale S = adj_scale(a, T.ebraw, T.ob);
                 adj_inv = S.inv;
                 half_split(T.ebraw * S.s2, eA, eB);
@@ -434,31 +446,26 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
             }
             SCHED_PHASE();
             float zb[NN];
-            if constexpr (FAST && F16 == 2) {
+            if constexpr (FAST && F16 != 0) {
                 // (only AdjRegs<M>::N registers of a pass's result tile hold existing rows)
                 constexpr int NR = AdjRegs<M>::N;
                 float rA[NR], rB[NR];
-                // pass B's second-layer checkpoint is requested when pass A's drift net is done and arrives under pass A's and pass B's density phases; requested before
-                // pass A, as the f32 / three-limb forms do, this loop spilled it (three synchronous HBM round trips per step: profiles/r5_ab.txt §2)
-                // (pass B's six broadcast inputs wait in this wave's noise staging rows — idle during the adjoint sweep — while pass A runs: six registers that the
-                // loop otherwise takes from the checkpoint prefetch by spilling it)
+                // (pass B's six broadcast inputs wait in this wave's noise staging rows — idle during the adjoint sweep — while pass A runs)
                 if constexpr (NZS) {
 #pragma unroll
                     for (int k = 0; k < NN; ++k) sm.nzs[k * 64 + lane] = zB[k];
                 }
-                adj_mlp_pass_mp<NR, false>(sm, ww, ust, h, lane, zA, hA, eA, OA, rA, [&]() {
-                    if (pr.hasB) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) hB[q] = *reinterpret_cast<const float4*>(apB + (q * 64 + lane) * 4);
-                    }
-                });
+                adj_mlp_pass_mp<NR, false, F16>(sm, ww, ust, h, lane, zA, hA, eA, OA, rA, []() {});
                 SCHED_PHASE();
                 if constexpr (NZS) {
 #pragma unroll
                     for (int k = 0; k < NN; ++k) zB[k] = sm.nzs[k * 64 + lane];
                 }
                 // (parking pass A's result rows there in turn while pass B runs was tried: the allocator answered with MORE spills in three of four kernels)
-                if (pr.hasB) adj_mlp_pass_mp<NR, true>(sm, ww, ust, h, lane, zB, hB, eB, OB, rB, []() {});
+                if (pr.hasB) adj_mlp_pass_mp<NR, true, F16>(sm, ww, ust, h, lane, zB, hB, eB, OB, rB, [&]() {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hB[q] = *reinterpret_cast<const float4*>(apB + (q * 64 + lane) * 4);       // (touched at the top of the step: an L2 hit)
+                });
                 else {
 #pragma unroll
                     for (int r = 0; r < NR; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(rB[r]) : "v"(rA[r]));      // (a register of its own: the swap below aliases otherwise)
@@ -479,16 +486,15 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
                 for (int jj = 0; jj < M; ++jj) gq[jj] = (adj_row_upper(NN + jj) ? hi[adj_row_reg(NN + jj)] : lo[adj_row_reg(NN + jj)]) * adj_inv;
             } else {
             float PzA[NN], PuA[M], PzB[NN], PuB[M];
-            // pass B's second-layer checkpoint is requested before pass A computes (requesting it later — once pass A has consumed its own
-            // checkpoint, to reuse the registers — measured 35 % slower: vmcnt is in-order, the wait for it then also covers younger loads)
-            if (pr.hasB) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) hB[q] = *reinterpret_cast<const float4*>(apB + (q * 64 + lane) * 4);
-            }
             // per pass: layer 1 recomputed tile by tile (6 MFMAs, 32 tanh), layer 2 from the checkpoint (adj_mlp_pass)
             adj_mlp_pass<M, F16>(sm, ww, ust, h, lane, zA, hA, eA, obA, PzA, PuA);
             SCHED_PHASE();
             if (pr.hasB) {
+                // pass B's second-layer checkpoint: touched at the top of the step, loaded here (until round 5 it was requested before pass A and held in registers
+                // across it — where the allocator, short of registers, spilled one or two of its quads right behind the load: a synchronous HBM round trip each)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hB[q] = *reinterpret_cast<const float4*>(apB + (q * 64 + lane) * 4);
+                SCHED_PHASE();
                 adj_mlp_pass<M, F16>(sm, ww, ust, h, lane, zB, hB, eB, obB, PzB, PuB);
             } else {
 #pragma unroll
@@ -502,6 +508,7 @@ DI float duo_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const fl
 #pragma unroll
             for (int jj = 0; jj < M; ++jj) gq[jj] = half_join_sum(PuA[jj], PuB[jj]);
             }
+            asm volatile("" :: "v"(touched));     // (see the touch at the top of the step)
             duo_reform_rotation(xt, A.Rm);       // nine registers less across both MLP passes
             vjp_tail(sm, t, xt, A, lam, T, zb, lamn);
 #pragma unroll

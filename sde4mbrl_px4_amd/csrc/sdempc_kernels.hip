@@ -175,9 +175,13 @@ constexpr int NZ_STAGE = 6 * 64;                       // floats per wave
 // SPEC.md §10e (math_mode fast + f32x3): compact A-operand images of the adjoint's two narrow contractions, in the slack of the 3072-float limb region
 // (in this mode the forward and the transposed W2 image take two binary16 limbs each: floats 0..1023 and 1536..2559 of the region)
 constexpr int ZROWS_D = 15, ZROWS_N = 7;               // drift image: rows 0..5 zbar, 6..13 W1u^T (m <= 8), 14 zero; density image: rows 0..5, 6 zero
-constexpr int AZD_OFF = 1024, AZN_OFF = 2560;          // floats from sm.A2; 2 limbs x 2 K-halves x 2 lane halves x ROWS x 16 bytes = 480 / 224 floats
-constexpr int A3T_OFF = 2784, A3T_ROWS = 33;           // (-2 W3)^T for the K = 6 contraction with the output adjoints: [limb][row][8 x binary16], k slots 0..5 of the LOWER lane half; row 32 zero (upper half)
-static_assert(AZD_OFF + 2 * 2 * 2 * ZROWS_D * 4 <= 1536 && AZN_OFF + 2 * 2 * 2 * ZROWS_N * 4 <= A3T_OFF && A3T_OFF + 2 * A3T_ROWS * 4 <= 3072, "adjoint images must fit the slack of the limb region");
+constexpr int A3T_ROWS = 33;                           // (-2 W3)^T for the K = 6 contraction with the output adjoints: [limb][row][8 x binary16], k slots 0..5 of the LOWER lane half; row 32 zero (upper half)
+// where the four images sit (floats from sm.A2; xt: the transposed (4 W2) image, two limbs = 1024 floats; azd 480, azn 224, a3t 264 floats):
+//   f32x3: forward image 0..1023, xt 1536..2559 (= sm.A2xT), azd 1024.., azn 2560.., a3t 2784..   f16: forward image sm.A2h 2048..2559, xt 0..1023, azd 1024.., azn 1536.., a3t 1760..
+struct AdjOff { int xt, azd, azn, a3t; };
+__host__ __device__ constexpr AdjOff adj_off(int f16) { return f16 == 2 ? AdjOff{1536, 1024, 2560, 2784} : AdjOff{0, 1024, 1536, 1760}; }
+static_assert(adj_off(2).azd + 2 * 2 * 2 * ZROWS_D * 4 <= 1536 && adj_off(2).azn + 2 * 2 * 2 * ZROWS_N * 4 <= adj_off(2).a3t && adj_off(2).a3t + 2 * A3T_ROWS * 4 <= 3072, "f32x3: adjoint images must fit the slack of the limb region");
+static_assert(adj_off(1).azd + 2 * 2 * 2 * ZROWS_D * 4 <= adj_off(1).azn && adj_off(1).azn + 2 * 2 * 2 * ZROWS_N * 4 <= adj_off(1).a3t && adj_off(1).a3t + 2 * A3T_ROWS * 4 <= 2048, "f16: adjoint images must stay below the fp16 forward image");
 constexpr int UST = 36;
 constexpr int REC = 64, NZL = 8;                       // cooperative layouts: floats per step record / per noise row in LDS (sdempc_lane2.inc.h)
 constexpr int COOP_ROW = 172;                          // floats per (particle, step) checkpoint row of the cooperative layouts (sdempc_lane2.inc.h)
@@ -254,6 +258,50 @@ DI int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
 DI int opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
 DI int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// SPEC.md §10e (math_mode fast, mlp_dtype f32x3 / f16): A-operand images of the adjoint's contractions, two binary16 limbs each (round to nearest even: the casts; w - limb exact).
+// Compact images [limb][K-half][lane half][row][8 x binary16], last row zero: drift tile rows 0..5 = W1z[un][row], rows 6..6+m-1 = W1u[un][row-6]; density tile rows 0..5 =
+// W1z[32+un][row] (the VJP block's: as given); (-2 W3)^T [limb][row][8]: k slots 0..5 of the lower lane half. with_xt: also the full transposed (4 W2) image (f16 mode: the
+// f32x3 branch of load_weights writes its own beside the forward image).
+DI void load_adj_images(const KArgs& a, const Smem& sm, const float* w, int tid, int BNT, const AdjOff O, bool with_xt) {
+    if (with_xt) {
+        unsigned short* axt = reinterpret_cast<unsigned short*>(sm.A2 + O.xt);
+        for (int i = tid; i < 2 * 64 * 8; i += BNT) {
+            const int e = i & 7, l = (i >> 3) & 63, hf = i >> 9, jj = l & 31, hh = l >> 5, un = rowmap(8 * hf + e, hh);
+            const float wv = w[VJP_BASE + OFF_W2 + un * HID + jj];
+            const _Float16 h1 = (_Float16)wv;
+            const _Float16 h2 = (_Float16)(wv - (float)h1);
+            axt[(0 * 2 + hf) * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, h1);
+            axt[(1 * 2 + hf) * 512 + l * 8 + e] = __builtin_bit_cast(unsigned short, h2);
+        }
+    }
+    unsigned short* zd = reinterpret_cast<unsigned short*>(sm.A2 + O.azd);
+    unsigned short* zn = reinterpret_cast<unsigned short*>(sm.A2 + O.azn);
+    for (int i = tid; i < 2 * 2 * (ZROWS_D + ZROWS_N) * 8; i += BNT) {
+        const int e = i & 7, rw = (i >> 3) % (ZROWS_D + ZROWS_N), hh = ((i >> 3) / (ZROWS_D + ZROWS_N)) & 1, hf = ((i >> 3) / (ZROWS_D + ZROWS_N)) >> 1;
+        const int un = rowmap(8 * hf + e, hh);
+        const bool dr = rw < ZROWS_D;
+        const int row = dr ? rw : rw - ZROWS_D;
+        float wz = 0.0f;
+        if (dr) wz = row < NN ? w[VJP_BASE + OFF_W1Z + un * NN + row] : (row < NN + a.m ? w[VJP_BASE + OFF_W1U + un * 8 + (row - NN)] : 0.0f);
+        else if (row < NN) wz = w[VJP_BASE + OFF_W1Z + (HID + un) * NN + row];
+        const _Float16 h1 = (_Float16)wz;
+        const _Float16 h2 = (_Float16)(wz - (float)h1);
+        unsigned short* dst = dr ? zd : zn;
+        const int R = dr ? ZROWS_D : ZROWS_N;
+        dst[(((0 * 2 + hf) * 2 + hh) * R + row) * 8 + e] = __builtin_bit_cast(unsigned short, h1);
+        dst[(((1 * 2 + hf) * 2 + hh) * R + row) * 8 + e] = __builtin_bit_cast(unsigned short, h2);
+    }
+    unsigned short* a3 = reinterpret_cast<unsigned short*>(sm.A2 + O.a3t);
+    for (int i = tid; i < A3T_ROWS * 8; i += BNT) {
+        const int e = i & 7, row = i >> 3;
+        const float w3v = (row < HID && e < 6) ? w[OFF_W3 + e * HID + row] : 0.0f;       // the forward block's -2 W3 (SPEC.md §10b)
+        const _Float16 h1 = (_Float16)w3v;
+        const _Float16 h2 = (_Float16)(w3v - (float)h1);
+        a3[(0 * A3T_ROWS + row) * 8 + e] = __builtin_bit_cast(unsigned short, h1);
+        a3[(1 * A3T_ROWS + row) * 8 + e] = __builtin_bit_cast(unsigned short, h2);
+    }
+}
+
 // cooperative (all BNT threads of the workgroup); caller issues __syncthreads() afterwards
 DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid, int BNT) {
     const float* w = a.wts;
@@ -302,36 +350,9 @@ DI void load_weights(const KArgs& a, const Smem& sm, WaveW& ww, int tid, int BNT
                 }
             }
         }
-        if constexpr (FAST) {
-            // SPEC.md §10e: compact A-operand images of the adjoint's two narrow contractions, [limb][K-half][lane half][row][8 x binary16], last row zero:
-            // drift tile rows 0..5 = W1z[un][row], rows 6..6+m-1 = W1u[un][row-6]; density tile rows 0..5 = W1z[32+un][row] (the VJP block's: as given)
-            unsigned short* zd = reinterpret_cast<unsigned short*>(sm.A2 + AZD_OFF);
-            unsigned short* zn = reinterpret_cast<unsigned short*>(sm.A2 + AZN_OFF);
-            for (int i = tid; i < 2 * 2 * (ZROWS_D + ZROWS_N) * 8; i += BNT) {
-                const int e = i & 7, rw = (i >> 3) % (ZROWS_D + ZROWS_N), hh = ((i >> 3) / (ZROWS_D + ZROWS_N)) & 1, hf = ((i >> 3) / (ZROWS_D + ZROWS_N)) >> 1;
-                const int un = rowmap(8 * hf + e, hh);
-                const bool dr = rw < ZROWS_D;
-                const int row = dr ? rw : rw - ZROWS_D;
-                float wz = 0.0f;
-                if (dr) wz = row < NN ? w[VJP_BASE + OFF_W1Z + un * NN + row] : (row < NN + a.m ? w[VJP_BASE + OFF_W1U + un * 8 + (row - NN)] : 0.0f);
-                else if (row < NN) wz = w[VJP_BASE + OFF_W1Z + (HID + un) * NN + row];
-                const _Float16 h1 = (_Float16)wz;
-                const _Float16 h2 = (_Float16)(wz - (float)h1);
-                unsigned short* dst = dr ? zd : zn;
-                const int R = dr ? ZROWS_D : ZROWS_N;
-                dst[(((0 * 2 + hf) * 2 + hh) * R + row) * 8 + e] = __builtin_bit_cast(unsigned short, h1);
-                dst[(((1 * 2 + hf) * 2 + hh) * R + row) * 8 + e] = __builtin_bit_cast(unsigned short, h2);
-            }
-            unsigned short* a3 = reinterpret_cast<unsigned short*>(sm.A2 + A3T_OFF);
-            for (int i = tid; i < A3T_ROWS * 8; i += BNT) {
-                const int e = i & 7, row = i >> 3;
-                const float w3v = (row < HID && e < 6) ? w[OFF_W3 + e * HID + row] : 0.0f;       // the forward block's -2 W3 (SPEC.md §10b)
-                const _Float16 h1 = (_Float16)w3v;
-                const _Float16 h2 = (_Float16)(w3v - (float)h1);
-                a3[(0 * A3T_ROWS + row) * 8 + e] = __builtin_bit_cast(unsigned short, h1);
-                a3[(1 * A3T_ROWS + row) * 8 + e] = __builtin_bit_cast(unsigned short, h2);
-            }
-        }
+        if constexpr (FAST) load_adj_images(a, sm, w, tid, BNT, adj_off(2), false);
+    } else if (FAST && a.f16 == 1) {
+        load_adj_images(a, sm, w, tid, BNT, adj_off(1), true);       // (the f32 images below have no reader in this mode: forward from sm.A2h, adjoint from these)
     } else
     // A operand of k-step r for lane l: W2[j][rowmap(r,h)] (forward) / W2[rowmap(r,h)][j] (transpose)
     for (int i = tid; i < HID * HID; i += BNT) {
@@ -747,7 +768,7 @@ DI float block_cost_grad(const KArgs& a, const Smem& sm, const WaveW& ww, const 
 #pragma unroll
             for (int i = 0; i < 4; ++i) A.qn[i] = x[6 + i];   // q_{t+1}
             float ebc = dsc * ((2.0f * a.C.res_mult) * A.eta);
-            step_vjp<M, F16 == 2 ? 2 : 0>(a, sm, ww, t, h, lane, xt, xi, A, lam, ebc, lamn, gq);
+            step_vjp<M, (F16 == 2 || (FAST && F16 == 1)) ? F16 : 0>(a, sm, ww, t, h, lane, xt, xi, A, lam, ebc, lamn, gq);      // (exact f16 mode: the adjoint is the f32 one; fast: SPEC.md §10e in both matrix-pipe modes)
 #pragma unroll
             for (int i = 0; i < NX; ++i) { lam[i] = lamn[i]; x[i] = xt[i]; }
             // particle sums of the nq per-step adjoint outputs: both lane halves hold the same values, so the lower

@@ -101,7 +101,7 @@ DI void load_aw_full(const float* img, int lane, u32x4 (&aw)[2][2]) {
 }
 // SPEC.md §10e: the adjoint's two narrow contractions (6 rows: W1z^T abar1n; 6 + m rows: [W1z; W1u]^T abar1d) take their A operand from COMPACT images
 // [limb][K-half][lane half][ROWS][8 x binary16] whose last row is zero: lanes whose output row does not exist read that row
-// (ZROWS_D / ZROWS_N rows, at sm.A2 + AZD_OFF / AZN_OFF: sdempc_kernels.hip, beside Smem)
+// (ZROWS_D / ZROWS_N rows, at sm.A2 + adj_off(F16).azd / .azn: sdempc_kernels.hip, beside Smem)
 template <int ROWS>
 DI void load_aw_rows(const float* img, int lane, u32x4 (&aw)[2][2]) {
     const int row = lane & 31, hh = lane >> 5, rr = row < ROWS - 1 ? row : ROWS - 1;
@@ -169,6 +169,7 @@ DI void adj_rows_tile(const float* accZ, float inv, float* zb, float* gq) {
 // The density tile's contraction has six rows: registers 0..3 of its result — rows 0..7 — are added to the drift tile's rows (SPEC.md §10e states the sum that
 // way; one float32 addition each). It runs LAST in a pass: by then the pass's second-layer checkpoint and the drift tiles are dead, and pass B's checkpoint, which
 // is in flight since before pass A, keeps its registers (requested a phase earlier this loop spilled it: three synchronous HBM round trips per step).
+template <int F16>
 DI void adj_mp_density(const Smem& sm, int h, int lane, f32x16& hn, float ebraw, float* rows) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -180,7 +181,7 @@ DI void adj_mp_density(const Smem& sm, int h, int lane, f32x16& hn, float ebraw,
     Limbs2 L;
     split2h_tile(hn, L);
     u32x4 aw[2][2];
-    load_aw_rows<ZROWS_N>(sm.A2 + AZN_OFF, lane, aw);
+    load_aw_rows<ZROWS_N>(sm.A2 + adj_off(F16).azn, lane, aw);
     f32x16 accZ;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accZ[r] = 0.0f;
@@ -188,13 +189,13 @@ DI void adj_mp_density(const Smem& sm, int h, int lane, f32x16& hn, float ebraw,
 #pragma unroll
     for (int r = 0; r < 4; ++r) rows[r] = rows[r] + accZ[r];
 }
-template <class H2>
+template <int F16, class H2>
 DI void adj_mp_layer2(const Smem& sm, int lane, const H2& h2_of, const ObLimbs& O, f32x16& accB) {
     // abar2 = ((-2 W3)^T obar') (r2 - r2^2): the K = 6 contraction as four v_mfma_f32_32x32x16_f16 — limb products (w2,o2) (w2,o1) (w1,o2) (w1,o1), k slots 0..5 of the
     // lower lane half; the upper half's A operand is the zero row (its k slots 8..15 do not exist) — straight into the accumulator layout the rest of the pass works in
     const int rr = (lane >> 5) ? A3T_ROWS - 1 : (lane & 31);
-    const u32x4 a1 = *reinterpret_cast<const u32x4*>(sm.A2 + A3T_OFF + (0 * A3T_ROWS + rr) * 4);
-    const u32x4 a2 = *reinterpret_cast<const u32x4*>(sm.A2 + A3T_OFF + (1 * A3T_ROWS + rr) * 4);
+    const u32x4 a1 = *reinterpret_cast<const u32x4*>(sm.A2 + adj_off(F16).a3t + (0 * A3T_ROWS + rr) * 4);
+    const u32x4 a2 = *reinterpret_cast<const u32x4*>(sm.A2 + adj_off(F16).a3t + (1 * A3T_ROWS + rr) * 4);
     u32x4 b1, b2;
     b1[0] = O.r1[0]; b1[1] = O.r1[1]; b1[2] = O.r1[2]; b1[3] = 0u;
     b2[0] = O.r2[0]; b2[1] = O.r2[1]; b2[2] = O.r2[2]; b2[3] = 0u;
@@ -214,18 +215,18 @@ DI void adj_mp_layer2(const Smem& sm, int lane, const H2& h2_of, const ObLimbs& 
     Limbs2 L;
     split2h_tile(a2b, L);
     u32x4 aw[2][2];
-    load_aw_full(sm.A2xT, lane, aw);
+    load_aw_full(sm.A2 + adj_off(F16).xt, lane, aw);
 #pragma unroll
     for (int r = 0; r < 16; ++r) accB[r] = 0.0f;
     mfma_2h(aw, L, accB);
 }
-template <int NR>
+template <int NR, int F16>
 DI void adj_mp_drift(const Smem& sm, int lane, const f32x16& hd, const f32x16& accB, float* rows) {
     u32x4 aw[2][2];
     f32x16 ad;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ad[r] = accB[r] * dact(hd[r]);
-    load_aw_rows<ZROWS_D>(sm.A2 + AZD_OFF, lane, aw);
+    load_aw_rows<ZROWS_D>(sm.A2 + adj_off(F16).azd, lane, aw);
     Limbs2 L;
     split2h_tile(ad, L);
     f32x16 accZ;
@@ -702,37 +703,40 @@ DI void layer1_tile(const Smem& sm, const WaveW& ww, const float* ust, int h, co
 
 // SPEC.md §10e (math_mode fast + f32x3): the same pass with the scaled adjoints and its three contractions on the matrix pipe; leaves the result tile (rows 0..5 zbar,
 // 6.. W1u^T abar1d, still scaled) as the NR accumulator registers that hold existing rows. One hidden tile at a time, like adj_mlp_pass.
-// DENS_FIRST: the density tile before the drift net (pass B of the duo layout: its second-layer checkpoint is requested only once pass A's is consumed — the hook
-// after_l2 of pass A — and arrives under the density phase); otherwise the drift net first (pass A: its checkpoint is already there). The two tiles' rows are added
-// (commutative: the same bits either way).
-template <int NR, bool DENS_FIRST, class Hook>
-DI void adj_mlp_pass_mp(const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, const float4* h2c, float ebraw, const ObLimbs& O, float* rows, const Hook& after_l2) {
+// DENS_FIRST: the density tile before the drift net (pass B of the duo layout); otherwise the drift net first (pass A: its checkpoint is already there). The two tiles'
+// rows are added (commutative: the same bits either way). load_ckpt: called right before the second-layer phase — pass B loads its checkpoint THERE, into registers
+// that live for one phase only: its lines were touched (one dword each) at the top of the step, a pass and a half earlier, so the load is an L2 hit. Holding the tile in
+// registers from before pass A, as the f32 / three-limb forms do, leaves the allocator the choice of what to spill, and it chooses the checkpoint itself: a synchronous
+// HBM round trip per spilled quad and step — 0 to 2 of them, changing with every source line (profiles/r5_ab.txt §2 – §3).
+template <int NR, bool DENS_FIRST, int F16, class Hook>
+DI void adj_mlp_pass_mp(const Smem& sm, const WaveW& ww, const float* ust, int h, int lane, const float* z, const float4* h2c, float ebraw, const ObLimbs& O, float* rows, const Hook& load_ckpt) {
     float rn[4];
     if constexpr (DENS_FIRST) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) rn[r] = 0.0f;
         f32x16 hn;
-        layer1_tile<2, false>(sm, ww, ust, h, z, hn);
-        adj_mp_density(sm, h, lane, hn, ebraw, rn);
+        layer1_tile<F16, false>(sm, ww, ust, h, z, hn);
+        adj_mp_density<F16>(sm, h, lane, hn, ebraw, rn);
         SCHED_PHASE();
     }
+    load_ckpt();
+    SCHED_PHASE();
     f32x16 accB;
-    adj_mp_layer2(sm, lane, [&](int q) { return h2c[q]; }, O, accB);
+    adj_mp_layer2<F16>(sm, lane, [&](int q) { return h2c[q]; }, O, accB);
     SCHED_PHASE();
     {
         f32x16 hd;
-        layer1_tile<2, true>(sm, ww, ust, h, z, hd);
-        adj_mp_drift<NR>(sm, lane, hd, accB, rows);
+        layer1_tile<F16, true>(sm, ww, ust, h, z, hd);
+        adj_mp_drift<NR, F16>(sm, lane, hd, accB, rows);
     }
-    after_l2();
     if constexpr (DENS_FIRST) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) rows[r] = rows[r] + rn[r];
     } else {
         SCHED_PHASE();
         f32x16 hn;
-        layer1_tile<2, false>(sm, ww, ust, h, z, hn);
-        adj_mp_density(sm, h, lane, hn, ebraw, rows);
+        layer1_tile<F16, false>(sm, ww, ust, h, z, hn);
+        adj_mp_density<F16>(sm, h, lane, hn, ebraw, rows);
     }
 }
 
@@ -859,7 +863,7 @@ DI void adj_mlp_pass(const Smem& sm, const WaveW& ww, const float* ust, int h, i
 
 template <int M, int F16 = 0>
 DI void vjp_mlp_tiles(const KArgs& a, const Smem& sm, int h, int lane, const StepAux& A, const VjpTmp& T, float* zb, float* gq) {
-    if constexpr (FAST && F16 == 2) {       // SPEC.md §10e: scaled adjoints, the three contractions on the matrix pipe from binary16 limbs
+    if constexpr (FAST && F16 != 0) {       // SPEC.md §10e: scaled adjoints, every contraction of the sweep on the matrix pipe from binary16 limbs
         const AdjScale S = adj_scale(a, T.ebraw, T.ob);
         float ob[6];
 #pragma unroll
@@ -867,9 +871,9 @@ DI void vjp_mlp_tiles(const KArgs& a, const Smem& sm, int h, int lane, const Ste
         const ObLimbs O = ob_limbs(ob);
         f32x16 accB, hn = A.h1n;
         float rows[AdjRegs<M>::N];
-        adj_mp_layer2(sm, lane, [&](int q) { return make_float4(A.h2[4 * q], A.h2[4 * q + 1], A.h2[4 * q + 2], A.h2[4 * q + 3]); }, O, accB);
-        adj_mp_drift<AdjRegs<M>::N>(sm, lane, A.h1d, accB, rows);
-        adj_mp_density(sm, h, lane, hn, T.ebraw * S.s2, rows);
+        adj_mp_layer2<F16>(sm, lane, [&](int q) { return make_float4(A.h2[4 * q], A.h2[4 * q + 1], A.h2[4 * q + 2], A.h2[4 * q + 3]); }, O, accB);
+        adj_mp_drift<AdjRegs<M>::N, F16>(sm, lane, A.h1d, accB, rows);
+        adj_mp_density<F16>(sm, h, lane, hn, T.ebraw * S.s2, rows);
         adj_rows_tile<M>(rows, S.inv, zb, gq);
         SCHED_PHASE();
         return;

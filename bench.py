@@ -352,9 +352,12 @@ def main():
             "roofline": {"bound": "valu-issue @ power cap", "achieved": ach_tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach_tf / F32_MFMA_PEAK_TF,
                          "peak_scalar_valu_tflops": F32_SCALAR_VALU_PEAK_TF, "frac_of_scalar_valu_peak": ach_tf / F32_SCALAR_VALU_PEAK_TF,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_build": traffic_build, "kernel": kernel_name, "kernel_ms": k_ms,
-                         "binding_resource": ("the package power cap (field power: the firmware holds the shader clock below 2.4 GHz) and, inside it, vector (VALU) instruction issue with its LDS / matrix-chain waits — "
-                                              "math_mode fast: the vector stream alone is 53 % of the launch's cycles at the best rate a SIMD issues this mix (exact: 86 %), the matrix pipe is busy a quarter of them, "
-                                              "HBM moves 3.1 of 8 TB/s; valu_issue has the counters"),
+                         "binding_resource": ("the package power cap (field power: the firmware holds the shader clock below 2.4 GHz) and, inside it, what the three waves of a SIMD wait for: vector (VALU) instruction "
+                                              "issue with its LDS / matrix-chain dependencies"
+                                              + ((" — PMC passes of this build: the vector stream alone is %.0f %% of the launch's cycles at the best rate a SIMD issues this mix, the matrix pipe is busy %.0f %% of them"
+                                                  % (100 * valu_issue["frac_at_best_issue"], 100 * valu_issue["mfma_busy_frac"])) if valu_issue else "")
+                                              + "; per wave half of the cycles are issue stalls (dependent instructions, arbitration among the three waves), 15 % waits for LDS / memory operands; HBM moves 3.1 of 8 TB/s "
+                                                "(profiles/r5_c2_pmc.json). Round 5 showed that the COUNT of vector instructions is not what binds (profiles/r5_ab.txt 2)"),
                          "valu_issue": valu_issue,
                          "note": "algorithmic flops = SURVEY 8d MLP formula x P*H*(2*N_grad+N_ls+2) (N_grad = gradient evaluations actually performed: sdempc_work_counters). `frac` keeps the series of "
                                  "the earlier rounds: against the 157.3 TFLOP/s f32 peak (f32 vector peak = f32-input MFMA peak), which the vector ALUs reach only with packed-f32 instructions throughout — "
@@ -437,7 +440,7 @@ def main():
         if do_cpu:
             if not V.threads:
                 V.start()
-            V.add_baseline(cfg32, blob, range(n_cpu), L.x0_h, L.xref_h, L.keys, L.u0_h, L.s0)
+            V.add_baseline(cfg32, blob, 40, L.x0_h[:n_cpu], L.xref_h[:n_cpu], L.keys[:n_cpu], L.u0_h[:n_cpu], L.s0)
         progress("waiting for the CPU threads (checks of the timed launches, float64 referee, CPU baseline)")
     wall = V.join()
     by_rank, bad_total = all_ranks_verified(V, rank, world, device=dev, force=force_dist)
@@ -496,8 +499,8 @@ def main():
                                              f"{threads_used} threads of the {effective_cores()} usable host cores: os.cpu_count {os.cpu_count()}; the busiest thread spent {busy:.1f} s on them) "
                                              "by the particle-vectorised build of the C oracle (oracle/sde_mpc_oracle.c -DORC_VEC: 16 particles per call, -O3 -march=native, "
                                              "contraction allowed, f32 fma-chain contractions, software activations of SPEC.md 3; CPU restatement of SPEC.md, not the reference JAX path: that cannot run here). "
-                                             "value = sum over the threads of (solves of the thread / the time it spent on them): the baseline solves are queued behind the bit-exact checks of the "
-                                             "timed launches and fill the threads their drain leaves idle, so every core is busy throughout; "
+                                             "value = sum over the threads of (solves of the thread / the time it spent on them): every worker thread solves its own 40 instances once the queue of "
+                                             "bit-exact checks has nothing left for it, so the cores are busy with checks or baseline solves throughout (the tail of the last threads excepted); "
                                              f"|uopt - GPU uopt| over the sample (200-iteration solves; timing build, not the checker): median {mmed:.1e}, max {md:.1e}",
                                    "value_bit_exact_build": (rmain["done"] / rmain["cpu_s"] * 1.0) if rmain and rmain["cpu_s"] > 0 else None,
                                    "value_bit_exact_build_note": "solves per second PER THREAD of the bit-exact checker in the arithmetic of this run (the matrix-instruction model is integer code)",

@@ -87,9 +87,9 @@ class Verifier:
     goes on with the GPU legs; results are collected at the end. Three kinds of jobs share the pool, served in the order they were queued:
       * checks   (add):          an instance of a timed launch solved by the bit-exact checker and compared word for word with the GPU's outputs;
       * referee  (add_referee):  the float64 build of the oracle on instances of the timed batch (bench.py's vs_float64 field);
-      * baseline (add_baseline): instances solved by the particle-vectorised timing build — the reported cpu_baseline. Queued last, they fill the
-        threads the drain of the checks leaves idle: the rate is the sum over the threads of (solves of that thread / the time it spent on them),
-        every core being busy throughout (with checks or with baseline solves).
+      * baseline (add_baseline): instances solved by the particle-vectorised timing build — the reported cpu_baseline. EVERY worker thread solves its own
+        quota of them once the shared queue has nothing left for it: threads whose checks end early start early, the rate is the sum over the threads of
+        (solves of that thread / the time it spent on them), every core being busy throughout (with checks or with baseline solves) except in the tail.
     A worker that dies (an exception inside the oracle or the comparison) is recorded: bench.py exits non-zero when any leg has fewer checked
     instances than it asked for."""
 
@@ -98,6 +98,7 @@ class Verifier:
         self.n_threads, self.threads, self.t0 = max(1, n_threads), [], None
         self.errors = []
         self.referee, self.baseline = {}, {"solves": 0, "busy": {}, "outs": {}}
+        self.baseline_spec = None
 
     def add(self, leg, cfg, blob, idx, x0, xref, keys, u0, s0, got):
         """got: (uopt, xevol, info) host arrays of the WHOLE batch; idx: instances to check"""
@@ -122,12 +123,10 @@ class Verifier:
             if self.threads:
                 self.cv.notify_all()
 
-    def add_baseline(self, cfg, blob, idx, x0, xref, keys, u0, s0):
+    def add_baseline(self, cfg, blob, per_thread, x0, xref, keys, u0, s0):
+        """per_thread solves by every worker thread (thread t: instances t * per_thread ... of the arrays given), behind whatever the shared queue holds"""
         with self.lock:
-            for i in idx:
-                self.jobs.append(("vec", "baseline", cfg, blob, int(i), x0[i], xref[i], keys[i], u0[i], s0, None, None, None))
-            if self.threads:
-                self.cv.notify_all()
+            self.baseline_spec = (cfg, blob, int(per_thread), x0, xref, keys, u0, s0)
 
     def start(self):
         """start the workers; jobs added later are picked up too, until join()"""
@@ -156,7 +155,7 @@ class Verifier:
                     while self.nxt >= len(self.jobs) and not self.closed:
                         self.cv.wait()
                     if self.nxt >= len(self.jobs):
-                        return
+                        break
                     job = self.jobs[self.nxt]; self.nxt += 1
                 kind, leg, cfg, blob, i, x0, xref, key, u0, s0, gu, gx, gi = job
                 try:
@@ -174,15 +173,29 @@ class Verifier:
                         with self.lock:
                             if gu is not None or i not in self.referee:       # (an instance may be asked for twice: with its gradient and as a disputed one)
                                 self.referee[i] = (g64, c64, u64, time.time() - t)
-                    else:
-                        out = O.solve(x0, xref, noise, u0, s0)[:3]
-                        with self.lock:
-                            b = self.baseline
-                            b["solves"] += 1; b["outs"][i] = out
-                            n, busy = b["busy"].get(tid, (0, 0.0)); b["busy"][tid] = (n + 1, busy + time.time() - t)
                 except Exception as e:       # the job stays "not done": bench.py reports the leg as unverified and exits non-zero
                     with self.lock:
                         self.errors.append(f"{leg}[{i}]: {type(e).__name__}: {e}")
+            spec = self.baseline_spec
+            if spec is None:
+                return
+            cfg, blob, per_thread, x0, xref, keys, u0, s0 = spec          # this thread's own share of the cpu_baseline
+            try:
+                O = oracle_of(tid, "vec", "baseline", cfg, blob)
+                for k in range(per_thread):
+                    i = tid * per_thread + k
+                    if i >= len(x0):
+                        break
+                    t = time.time()
+                    noise = orc.noise_from_key(keys[i], cfg.num_particles, cfg.horizon)
+                    out = O.solve(x0[i], xref[i], noise, u0[i], s0)[:3]
+                    with self.lock:
+                        b = self.baseline
+                        b["solves"] += 1; b["outs"][i] = out
+                        n, busy = b["busy"].get(tid, (0, 0.0)); b["busy"][tid] = (n + 1, busy + time.time() - t)
+            except Exception as e:
+                with self.lock:
+                    self.errors.append(f"baseline[thread {tid}]: {type(e).__name__}: {e}")
 
         self.threads = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(self.n_threads)]
         [t.start() for t in self.threads]

@@ -6,7 +6,7 @@ tag=${1:-r04}; B=${2:-12288}; MLP=${3:-f32x3}; MATH=${4:-fast}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
 sha256sum sde4mbrl_px4_amd/csrc/libsdempc.so > $out/lib_sha.txt
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --mlp-dtype $MLP --math-mode $MATH --no-cpu-baseline --no-tolerance-modes --no-other-configs --verify 0 --latency-reps 0 > $out/bench_trace.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --mlp-dtype $MLP --math-mode $MATH --no-cpu-baseline --no-other-math-mode --no-other-configs --verify 0 --latency-reps 0 > $out/bench_trace.log 2>&1
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" \

@@ -147,3 +147,23 @@ def test_bench_four_ranks_one_fails_before_the_rendezvous():
     assert time.time() - t0 < 90
     last = [l for l in r.stderr.splitlines() if l.startswith("bench.py: rank ")][-1]
     assert "rank 2 exited with code" in last and "simulated start-up failure" in last
+
+
+def test_rank_agreement_and_referee_helpers():
+    """benchlib/ranks.py: which ranks hold something else than the others (majority; ties: rank 0's value counts); benchlib/referee.py: error measures and the table"""
+    from benchlib import referee as R
+    from benchlib.ranks import fingerprint, ranks_that_disagree
+    assert ranks_that_disagree([[1, 2], [1, 2], [1, 3], [1, 2]]) == {1: [2]}
+    assert ranks_that_disagree([[5], [1]]) == {0: [1]} and ranks_that_disagree([[7, 7]] * 3) == {}
+    assert ranks_that_disagree([[9], [4], [4], [4]]) == {0: [0]}                       # rank 0 itself can be the odd one
+    assert fingerprint(b"abc") == fingerprint("abc") != fingerprint(b"abd") and -2**63 <= fingerprint(b"x") < 2**63
+    g64 = np.array([[1.0, -4.0], [2.0, 0.5]])
+    e = R.gradient_error(g64 + np.array([[4e-7, 0.0], [0.0, -4e-7]]), g64, 10.0 + 1e-6, 10.0)
+    assert abs(e["max_rel"] - 1e-7) < 1e-12 and abs(e["rms_rel"] - 1e-7 / np.sqrt(2)) < 1e-12 and abs(e["cost_rel"] - 1e-7) < 1e-12
+    u64 = np.full((3, 2), 0.5)
+    assert R.solve_error(u64 + 0.9e-4, u64)["within"] and not R.solve_error(u64 + 2.1e-4, u64)["within"]
+    t = R.summarize({"a": [e, e], "b": [dict(e, rms_rel=2 * e["rms_rel"], max_rel=3 * e["max_rel"])] * 2}, {"a": [R.solve_error(u64, u64)] * 2, "b": [R.solve_error(u64 + 1e-3, u64)] * 2})
+    assert t["a"]["solves_within_1e-4_of_float64"] == 1.0 and t["b"]["solves_within_1e-4_of_float64"] == 0.0
+    r = R.ratios_to(t, base="a")
+    assert abs(r["b"]["grad_rms_rel"] - 2.0) < 1e-12 and abs(r["b"]["grad_max_rel_worst"] - 3.0) < 1e-12
+    assert R.run_threads([lambda i=i: i * i for i in range(7)], 3) == [i * i for i in range(7)]

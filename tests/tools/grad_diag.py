@@ -1,3 +1,5 @@
+"""GPU gradient against the oracle, entry by entry, for the matrix-pipe contraction modes in math_mode fast (how the wrong F16 template argument of round 5 was found:
+the ratio pattern said which part of the adjoint was missing).  usage: python tests/tools/grad_diag.py"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -320,10 +320,10 @@ int noise_from_keys(sdempc_handle* h, int B, const uint32_t* keys, float* out_de
 int coop_timed_out(sdempc_handle* h, bool* timed_out) {
     *timed_out = false;
     if (h->last_coop_B <= 0) return 0;
-    std::vector<unsigned> f(2 * (size_t)h->last_coop_B);
+    std::vector<unsigned> f(COOP_BAR_WORDS * (size_t)h->last_coop_B);
     HIPCHK(h, hipMemcpy(f.data(), h->d_coop_bar.p, sizeof(unsigned) * f.size(), hipMemcpyDeviceToHost));
     for (int b = 0; b < h->last_coop_B; ++b)
-        if (f[2 * b + 1] != 0u) *timed_out = true;
+        if (f[COOP_BAR_WORDS * b + 1] != 0u) *timed_out = true;
     if (*timed_out) {                    // the workgroups were not all resident (GPU shared with other work): no second try on this handle
         h->coop_off = true;
         h->layout_fallbacks += 1;
@@ -730,17 +730,22 @@ int sdempc_solve_batch_dev(sdempc_handle* h, int32_t B, const void* x0_dev, cons
     if (B <= cmax) {
         if (!h->d_coop_bar.p) {
             const int cap = cmax < h->max_batch ? cmax : h->max_batch;
-            if ((rc = dev_alloc(h, h->d_coop_bar, sizeof(unsigned) * 2 * (size_t)cap))) return rc;
+            if ((rc = dev_alloc(h, h->d_coop_bar, sizeof(unsigned) * COOP_BAR_WORDS * (size_t)cap))) return rc;
             if ((rc = dev_alloc(h, h->d_coop_pp, sizeof(float) * coop_pp_floats(h->H, h->G) * cap))) return rc;
             if ((rc = dev_alloc(h, h->d_coop_ck, sizeof(float) * coop_ck_floats(h->H, h->P) * cap))) return rc;
             h->coop_cap = cap;
         }
         if (B <= h->coop_cap) {
-            HIPCHK(h, hipMemsetAsync(h->d_coop_bar.p, 0, sizeof(unsigned) * 2 * (size_t)B, st));
+            HIPCHK(h, hipMemsetAsync(h->d_coop_bar.p, 0, sizeof(unsigned) * COOP_BAR_WORDS * (size_t)B, st));
             a.coop_bar = (unsigned*)h->d_coop_bar.p; a.coop_pp = (float*)h->d_coop_pp.p; a.coop_ck = (float*)h->d_coop_ck.p;
             a.coop_spin = coop_spin_ticks(h);
             h->last_coop_B = B; h->last_ticketed = false;
-            if (B <= smax) return timed_launch(h, st, [&] { return a.fast ? launch_solve_spec_fast(a, B, st) : launch_solve_spec(a, B, st); });
+            if (B <= smax) {
+                // the speculative kernel's outputs are tagged words {value, tag} that readers poll (streamed hand-off, sdempc_spec.inc.h): no tag of an
+                // earlier launch may survive (12 MB per C2 instance, a few microseconds of the 20 ms the launch takes)
+                HIPCHK(h, hipMemsetAsync(h->d_coop_pp.p, 0, sizeof(float) * coop_pp_floats(h->H, h->G) * (size_t)B, st));
+                return timed_launch(h, st, [&] { return a.fast ? launch_solve_spec_fast(a, B, st) : launch_solve_spec(a, B, st); });
+            }
             if (B <= coop_max_instances(h->P, h->H, h->m, a.opt)) return timed_launch(h, st, [&] { return a.fast ? launch_solve_coop_fast(a, B, st) : launch_solve_coop(a, B, st); });
             h->last_coop_B = 0;
         }

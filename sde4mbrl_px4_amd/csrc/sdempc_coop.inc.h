@@ -11,7 +11,7 @@
 // ================================================================================================
 struct CoopCtx {
     int nwg, wgi, Ppad;
-    unsigned* bar;          // this instance's arrival counter (zeroed by the host before the launch), bar[1] = error flag
+    unsigned* bar;          // this instance's COOP_BAR_WORDS words (zeroed by the host before the launch): [0] grid-barrier counter, [1] error flag, [2] arrivals of the streamed hand-off
     unsigned epoch, spin_limit;   // spin_limit: ticks of the 100 MHz s_memrealtime clock one barrier may wait (KArgs::coop_spin)
     int fence;              // KArgs::opt.coop_fence: agent-scope release / acquire fences around the barrier
     float* pp;              // [2][PS][Ppad] per-particle outputs, double-buffered by rollout parity
@@ -76,6 +76,92 @@ DI float tagged_wait(CoopCtx& C, const unsigned long long* p, unsigned tag, uint
     return __uint_as_float((unsigned)v);
 }
 
+// ---- streamed hand-off (speculative kernel): per-particle outputs are 64-bit words {value, tag} too, polled instead of waited for behind a grid barrier ----
+// N tagged words per lane, polled side by side (one round trip per poll for all of them); an absent word (have == false) counts as
+// arrived with the value + 0.0. Bounded like tagged_wait.
+template <int N>
+DI void tagged_wait_n(CoopCtx& C, const unsigned long long* const (&p)[N], const bool (&have)[N], unsigned tag, uint64_t t0w, float (&v)[N]) {
+    unsigned long long w[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i] = (unsigned long long)tag << 32;
+    unsigned polls = 0;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) if (have[i]) w[i] = __hip_atomic_load(p[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool all = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) all = all && (unsigned)(w[i] >> 32) == tag;
+        if (all) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0w >= (uint64_t)C.spin_limit) {
+            __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            C.spin_limit = 0;
+            break;
+        }
+        if ((++polls & 7u) == 0u && __hip_atomic_load(C.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { C.spin_limit = 0; break; }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __uint_as_float((unsigned)w[i]);
+}
+// coop_total of up to TWO quantities at once from tagged words (pq1 may be null, wave-uniformly): the same butterflies, slots and order. Four words per lane and
+// polling round: two quantities x one chunk of four particle groups, or one quantity x two chunks (P > 128 — chunk after chunk cost one more round trip each)
+DI void coop_total_tagged2(CoopCtx& C, const unsigned long long* pq0, const unsigned long long* pq1, int P, int G, int lane, unsigned tag, uint64_t t0w, float& s0, float& s1) {
+    const int hh = lane >> 5, j = lane & 31;
+    const bool second = pq1 != nullptr;
+    float Sa0 = 0.0f, Sb0 = 0.0f, Sa1 = 0.0f, Sb1 = 0.0f;
+    if (second) {
+        for (int g0 = 0; g0 < G; g0 += 4) {
+            const int pa = 32 * (g0 + hh) + j, pb = 32 * (g0 + 2 + hh) + j;
+            const bool ha = (g0 + hh < G) && pa < P, hb = (g0 + 2 + hh < G) && pb < P;
+            const unsigned long long* const pw[4] = {pq0 + pa, pq0 + pb, pq1 + pa, pq1 + pb};
+            const bool have[4] = {ha, hb, ha, hb};
+            float v[4];
+            tagged_wait_n<4>(C, pw, have, tag, t0w, v);
+            Sa0 = Sa0 + group_bfly32(v[0]);
+            Sa1 = Sa1 + group_bfly32(v[2]);
+            if (g0 + 2 < G) { Sb0 = Sb0 + group_bfly32(v[1]); Sb1 = Sb1 + group_bfly32(v[3]); }
+        }
+    } else {
+        for (int g0 = 0; g0 < G; g0 += 8) {
+            const int pa = 32 * (g0 + hh) + j, pb = 32 * (g0 + 2 + hh) + j, pc = 32 * (g0 + 4 + hh) + j, pd = 32 * (g0 + 6 + hh) + j;
+            const unsigned long long* const pw[4] = {pq0 + pa, pq0 + pb, pq0 + pc, pq0 + pd};
+            const bool have[4] = {(g0 + hh < G) && pa < P, (g0 + 2 + hh < G) && pb < P, (g0 + 4 + hh < G) && pc < P, (g0 + 6 + hh < G) && pd < P};
+            float v[4];
+            tagged_wait_n<4>(C, pw, have, tag, t0w, v);
+            Sa0 = Sa0 + group_bfly32(v[0]);
+            if (g0 + 2 < G) Sb0 = Sb0 + group_bfly32(v[1]);
+            if (g0 + 4 < G) {
+                Sa0 = Sa0 + group_bfly32(v[2]);
+                if (g0 + 6 < G) Sb0 = Sb0 + group_bfly32(v[3]);
+            }
+        }
+    }
+    s0 = ((readlane_f(Sa0, 0) + readlane_f(Sa0, 32)) + readlane_f(Sb0, 0)) + readlane_f(Sb0, 32);
+    s1 = ((readlane_f(Sa1, 0) + readlane_f(Sa1, 32)) + readlane_f(Sb1, 0)) + readlane_f(Sb1, 32);
+}
+DI float coop_total_tagged(CoopCtx& C, const unsigned long long* pq, int P, int G, int lane, unsigned tag, uint64_t t0w) {
+    float s0, s1;
+    coop_total_tagged2(C, pq, nullptr, P, G, lane, tag, t0w, s0, s1);
+    return s0;
+}
+// Arrivals: what keeps a slow workgroup's READS of iteration k ahead of a fast one's WRITES of iteration k + 2 into the same (double-buffered) words now
+// that no grid barrier separates them. A workgroup arrives (one fire-and-forget atomic) when it has read everything iteration k produced; before it leaves
+// the parallel phase of iteration k + 1 it makes sure everyone has — a whole phase later, so the word it polls has long had its value (one load, in the
+// shadow of the trial-cost polls of the other waves).
+DI void coop_arrive(CoopCtx& C, int tid) {
+    if (tid == 0) __hip_atomic_fetch_add(C.bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DI void coop_arrived_wait(CoopCtx& C, unsigned target, uint64_t t0w) {
+    unsigned polls = 0;
+    while (__hip_atomic_load(C.bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (__builtin_amdgcn_s_memrealtime() - t0w >= (uint64_t)C.spin_limit) {
+            __hip_atomic_store(C.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            C.spin_limit = 0;
+            break;
+        }
+        if ((++polls & 7u) == 0u && __hip_atomic_load(C.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { C.spin_limit = 0; break; }
+    }
+}
+
 // total of quantity q over the particles: SPEC.md §6.1 (32-particle butterflies, slots g mod 4 in ascending g, ((S0+S1)+S2)+S3);
 // a wave reduces two groups per pass (lanes 0..31 group g, lanes 32..63 group g + 1). Result valid in every lane.
 DI float coop_total(const float* pq, int P, int G, int lane) {
@@ -97,7 +183,7 @@ DI Lane2IO lane_io_coop(const KArgs& a, const CoopCtx& C, int b, int p) {
     Lane2IO io;
     io.x0 = a.x0 + (size_t)b * NX;
     io.ck = C.ck + (size_t)p * (H + 1) * COOP_ROW;
-    io.out = C.pp + (size_t)(C.epoch & 1u) * part_stride(H) * C.Ppad + p; io.os = C.Ppad;
+    io.out = C.pp + (size_t)(C.epoch & 1u) * part_stride(H) * C.Ppad + p; io.os = C.Ppad; io.tag = 0u;
     return io;
 }
 

@@ -59,6 +59,7 @@ struct LaunchOpts {
     int absent_wg;     // fault injection (tests): >= 0: that workgroup of a cooperative-layout grid leaves at once, as if it had never become resident; -1 (default): none
     int hex;           // 1: launches that fill every two-wave team slot of the device run one six-team workgroup per CU (default), 0: two-team workgroups always
 };
+constexpr int COOP_BAR_WORDS = 4;
 struct KArgs {
     int H, P, m, G;
     int B;                     // instances in this launch (set by the launcher)
@@ -92,7 +93,7 @@ struct KArgs {
     // cooperative latency path (one instance over coop_nwg workgroups; workspace owned by the handle, see sdempc_api.cpp)
     int coop_nwg;
     int coop_ngrp;             // speculative variant: groups of coop_nwg workgroups per instance (2..5)
-    unsigned* coop_bar;        // [B][2]: arrival counter, error flag (zeroed before every launch)
+    unsigned* coop_bar;        // [B][COOP_BAR_WORDS]: grid-barrier counter, error flag, arrivals of the streamed hand-off, pad (zeroed before every launch)
     float* ustg;               // [B][H][36] per-step control table in global memory (long horizons: keeps it out of LDS), or NULL
     unsigned coop_spin;        // time one grid barrier may wait before it gives up, in ticks of the 100 MHz s_memrealtime clock (10 ns)
     float* coop_pp;            // [B][2][part_stride(H)][G*32]

@@ -185,10 +185,11 @@ static_assert(adj_off(1).azd + 2 * 2 * 2 * ZROWS_D * 4 <= adj_off(1).azn && adj_
 constexpr int UST = 36;
 constexpr int REC = 64, NZL = 8;                       // cooperative layouts: floats per step record / per noise row in LDS (sdempc_lane2.inc.h)
 constexpr int COOP_ROW = 172;                          // floats per (particle, step) checkpoint row of the cooperative layouts (sdempc_lane2.inc.h)
-// per-instance output workspace of the cooperative layouts (KArgs::coop_pp), floats: 2 x SPEC_SLOTS slots of [part_stride(H)][Ppad] per-particle
-// outputs (the plain cooperative kernel uses the first two), then [2][part_stride(H)] 64-bit tagged totals
+// per-instance output workspace of the cooperative layouts (KArgs::coop_pp): 2 x SPEC_SLOTS slots of [part_stride(H)][Ppad] per-particle outputs — 64-bit
+// tagged words {value, tag} in the speculative kernel (zeroed by the host before each of its launches: coop_pp_tagged_bytes), floats in the first two slots'
+// worth of the region in the plain cooperative kernel — then [2][part_stride(H)] 64-bit tagged totals
 constexpr int SPEC_SLOTS = 9;
-__host__ __device__ inline size_t coop_gtot_offset(int H, int Ppad) { return (size_t)2 * SPEC_SLOTS * part_stride(H) * Ppad; }
+__host__ __device__ inline size_t coop_gtot_offset(int H, int Ppad) { return (size_t)2 * 2 * SPEC_SLOTS * part_stride(H) * Ppad; }
 __host__ __device__ inline size_t coop_pp_stride(int H, int Ppad) { return coop_gtot_offset(H, Ppad) + 4 * (size_t)part_stride(H); }
 
 DI Smem carve(float* base, int H, int m, int team, bool coop = false, bool ust_lds = true) {
@@ -853,7 +854,7 @@ DI void load_common(const KArgs& a, const Smem& sm, int b, int tid) {
     if constexpr (MODE == 2) {                                                       \
         b_ = blockIdx.x / a.coop_nwg;                                                \
         CC.nwg = a.coop_nwg; CC.wgi = blockIdx.x - b_ * a.coop_nwg; CC.Ppad = a.G * 32; CC.epoch = 0u; CC.spin_limit = a.coop_spin; CC.fence = a.opt.coop_fence; \
-        CC.bar = a.coop_bar + 2 * b_;                                                \
+        CC.bar = a.coop_bar + COOP_BAR_WORDS * b_;                                              \
         CC.pp = a.coop_pp + (size_t)b_ * coop_pp_stride(a.H, CC.Ppad);               \
         CC.gtot = reinterpret_cast<unsigned long long*>(CC.pp + coop_gtot_offset(a.H, CC.Ppad)); \
         CC.ck = a.coop_ck + (size_t)b_ * a.P * (a.H + 1) * COOP_ROW;                 \

@@ -41,6 +41,14 @@ DI void store_sc1_masked(unsigned long long mask, float* p, float v) {      // a
     asm volatile("s_and_saveexec_b64 %0, %1\n global_store_dword %2, %3, off sc1\n s_mov_b64 exec, %0"
                  : "=&s"(sv) : "s"(mask), "v"(p), "v"(v) : "memory", "scc");      // (s_and_saveexec writes SCC)
 }
+// the same store of a TAGGED output word {value, tag} (64 bits, one aligned store: the datum is its own hand-off flag — sdempc_spec.inc.h, "streamed hand-off")
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+DI void store_sc1_masked_tagged(unsigned long long mask, float* p, float v, unsigned tag) {
+    unsigned long long sv;
+    const u32x2 w = {__float_as_uint(v), tag};
+    asm volatile("s_and_saveexec_b64 %0, %1\n global_store_dwordx2 %2, %3, off sc1\n s_mov_b64 exec, %0"
+                 : "=&s"(sv) : "s"(mask), "v"(p), "v"(w) : "memory", "scc");
+}
 // the CK_NU float4 of uniform values of a checkpoint row, by lane 0
 DI void store_row_uniform(float* row, const f32x4 (&u)[11]) {
     unsigned long long sv;
@@ -266,10 +274,16 @@ struct Lane2IO {
     float* ck;         // checkpoint rows of this particle: row t at ck + t * COOP_ROW
     float* out;        // per-particle outputs: quantity q at out[q * os] (q: t*12 + k adjoint sums, t*13 + i states, PS - 1 cost)
     int os;
+    unsigned tag;      // TAGGED sweeps (speculative kernel): every output is a 64-bit word {value, tag}, os counts floats (two per word)
 };
+template <bool TAGGED>
+DI void lane2_out(const Lane2IO& io, unsigned long long mask, float* p, float v) {
+    if constexpr (TAGGED) store_sc1_masked_tagged(mask, p, v, io.tag);
+    else store_sc1_masked(mask, p, v);
+}
 
 // one particle: rollout and cost; MEAN: the states go to io.out (the final rollout of a solve)
-template <bool MEAN>
+template <bool MEAN, bool TAGGED = false>
 DI void lane2_rollout(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane2IO& io, int lane) {
     const int H = a.H, PS = part_stride(H), hh = lane >> 5;
     const LaneSel ls = lane_sel(lane);
@@ -280,7 +294,7 @@ DI void lane2_rollout(const KArgs& a, const Smem& sm, const Lane2Lds& L, const L
     for (int i = 0; i < NX; ++i) x[i] = io.x0[i];
     if (MEAN) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) store_sc1_masked(1ull, io.out + (size_t)i * io.os, x[i]);
+        for (int i = 0; i < NX; ++i) lane2_out<TAGGED>(io, 1ull, io.out + (size_t)i * io.os, x[i]);
     }
     float J = 0.0f;
     StepAux A;
@@ -304,11 +318,11 @@ DI void lane2_rollout(const KArgs& a, const Smem& sm, const Lane2Lds& L, const L
         for (int i = 0; i < NX; ++i) x[i] = xn[i];
         if (MEAN) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) store_sc1_masked(1ull, io.out + (size_t)((t + 1) * NX + i) * io.os, x[i]);
+            for (int i = 0; i < NX; ++i) lane2_out<TAGGED>(io, 1ull, io.out + (size_t)((t + 1) * NX + i) * io.os, x[i]);
         }
         rp += REC; rk += REC; rz += REC; np += NZL;
     }
-    store_sc1_masked(1ull, io.out + (size_t)(PS - 1) * io.os, J);
+    lane2_out<TAGGED>(io, 1ull, io.out + (size_t)(PS - 1) * io.os, J);
 }
 
 // what the adjoint step t reads: its checkpoint row
@@ -321,7 +335,7 @@ DI void lane2_request_row(const float* row, int lane, AdjRow& R) {
 }
 
 // one particle: cost, forward sweep with checkpoint, adjoint sweep; per-step adjoint outputs gq[0..M+3] -> io.out
-template <int M>
+template <int M, bool TAGGED = false>
 DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane2IO& io, int lane) {
     const int H = a.H, PS = part_stride(H), hh = lane >> 5;
     constexpr int nq = M + 4;
@@ -363,7 +377,7 @@ DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane
         int t = 0;
         for (; t + 1 < H; t += 2) { fstep(xa, xb); fstep(xb, xa); }
         if (t < H) fstep(xa, xb);
-        store_sc1_masked(1ull, io.out + (size_t)(PS - 1) * io.os, J);
+        lane2_out<TAGGED>(io, 1ull, io.out + (size_t)(PS - 1) * io.os, J);
     }
     // ---- adjoint sweep: two steps per trip over two register sets; the row of step t - 1 is requested while step t is processed ----
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -378,7 +392,7 @@ DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane
     float* op = io.out + (size_t)(olane ? oq : 0) * io.os;      // + t * 12 * os per step
     const size_t ostep = (size_t)12 * io.os;
     const unsigned long long omask = ((1ull << nq) - 1ull) << 16;
-    auto step = [&](int t, const AdjRow& R) {
+    auto step = [&](int t, const AdjRow& R) -> float {
         const float* rp = L.rec + t * REC;
         const float* np = L.nz + t * NZL;
         const float2 d4 = lds2(rp + RC_DT);
@@ -407,17 +421,27 @@ DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane
         // outputs: lane 16 + jj holds gq[jj] (jj < M); lanes 16 + M .. 16 + M + 3 take the thrust / rotor-torque adjoints
         float ov = Pc;
         ov = oq == M ? gq[M] : ov; ov = oq == M + 1 ? gq[M + 1] : ov; ov = oq == M + 2 ? gq[M + 2] : ov; ov = oq == M + 3 ? gq[M + 3] : ov;
-        store_sc1_masked(omask, op + (size_t)t * ostep, ov);
+        return ov;
     };
+    // A step's outputs are stored BEHIND the row request that follows the step. gfx9 has ONE counter for loads and stores, in issue order: the wait for a
+    // checkpoint row also waits for every store issued before that row's request, and the acknowledgement of an agent-scope (write-through, cross-XCD) store
+    // takes longer than a step (~ 1 us). With the store in front of the request every step waited for the store of the step before: 8 us of a 50-step sweep
+    // (C2 parallel phase 101.3 -> 93.4 us, measured with tools/spec_clock.py; single solve 22.6 -> 20.3 ms). Now a store has two steps to complete
+    // (one step more — behind the second request after its step — evens out the last 0.8 us between the gradient groups but costs 0.6 % in moves: not taken).
+    auto out = [&](int t, float ov) { lane2_out<TAGGED>(io, omask, op + (size_t)t * ostep, ov); };
     AdjRow RA, RB;
     const float* rowH = io.ck + (size_t)(H - 1) * COOP_ROW;
     lane2_request_row(rowH, lane, RA);
     int t = H - 1;
+    float ob = 0.0f;
     for (; t >= 1; t -= 2) {
         lane2_request_row(io.ck + (size_t)(t - 1) * COOP_ROW, lane, RB);
-        step(t, RA);
+        if (t != H - 1) out(t + 1, ob);
+        const float oa = step(t, RA);
         lane2_request_row(io.ck + (size_t)(t >= 2 ? t - 2 : 0) * COOP_ROW, lane, RA);      // (t == 1: row 0 once more, never used)
-        step(t - 1, RB);
+        out(t, oa);
+        ob = step(t - 1, RB);
     }
-    if (t == 0) step(0, RA);
+    if (H >= 2) out(t + 1, ob);
+    if (t == 0) out(0, step(0, RA));
 }

@@ -17,21 +17,31 @@ constexpr int SPEC_GROUPS = 7, SPEC_CKS = 4;      // (SPEC_SLOTS = 9: sdempc_ker
 constexpr int SLOT_SEQ = 6, SLOT_GRAD = 5;        // slots 0..4 and 7, 8: the items of a parallel phase
 constexpr int SLOT_T3 = 7, SLOT_Y3 = 8;           // third parallel trial and the candidate gradient behind it (groups 5, 6)
 
-DI Lane2IO lane_io_slot(const KArgs& a, const CoopCtx& C, int b, int p, unsigned par, int slot) {
+// Streamed hand-off: every per-particle output of this kernel is a 64-bit word {value, tag} (tag = number of the phase that wrote it, unique within a
+// launch; the words are zeroed by the host before the launch), written by ONE aligned store — a reader that finds the tag has the value, whatever else
+// the writer still has in flight. So the parallel phase ends WITHOUT a grid barrier: every workgroup polls the (few) trial costs it needs, the reduction
+// phase polls the words of the gradient it reduces, and the only thing a barrier still ordered — a fast workgroup overwriting (two iterations later) words
+// a slow one is still reading — is kept by the arrival counter (coop_arrive / coop_arrived_wait). The sequential phases keep their barrier.
+DI const unsigned long long* spec_words(const CoopCtx& C, int PS, unsigned par, int slot) {
+    return reinterpret_cast<const unsigned long long*>(C.pp) + (size_t)(par * SPEC_SLOTS + slot) * PS * C.Ppad;
+}
+DI Lane2IO lane_io_slot(const KArgs& a, const CoopCtx& C, int b, int p, unsigned par, int slot, unsigned tag) {
     const int H = a.H;
     Lane2IO io;
     io.x0 = a.x0 + (size_t)b * NX;
     io.ck = C.ck + (size_t)p * (H + 1) * COOP_ROW;
-    io.out = C.pp + (size_t)(par * SPEC_SLOTS + slot) * part_stride(H) * C.Ppad + p; io.os = C.Ppad;
+    io.out = C.pp + 2 * ((size_t)(par * SPEC_SLOTS + slot) * part_stride(H) * C.Ppad + p); io.os = 2 * C.Ppad; io.tag = tag;
     return io;
 }
-// after a phase's barrier, in every workgroup: expected cost of control sequence u whose particle outputs sit in (par, slot)
-DI float spec_cost(const KArgs& a, const Smem& sm, const CoopCtx& C, int tid, unsigned par, const float* u, int slot) {
+// in every workgroup: expected cost of control sequence u whose particle outputs sit in (par, slot), written by phase `tag`
+DI float spec_cost(const KArgs& a, const Smem& sm, CoopCtx& C, int tid, unsigned par, const float* u, int slot, unsigned tag) {
     const int lane = tid & 63, wave = tid >> 6, PS = part_stride(a.H);
     const float cu = block_ucost<TeamBlock>(a, sm, u, tid);
-    const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + slot) * PS * C.Ppad;
     __syncthreads();
-    if (wave == 0) { const float t0 = coop_total(pbuf + (size_t)(PS - 1) * C.Ppad, a.P, a.G, lane); if (lane == 0) sm.red[12] = t0; }
+    if (wave == 0) {
+        const float t0 = coop_total_tagged(C, spec_words(C, PS, par, slot) + (size_t)(PS - 1) * C.Ppad, a.P, a.G, lane, tag, __builtin_amdgcn_s_memrealtime());
+        if (lane == 0) sm.red[12] = t0;
+    }
     __syncthreads();
     return FMA(sm.red[12], a.invP, cu);
 }
@@ -72,7 +82,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     const int b = __builtin_amdgcn_readfirstlane(b_);
     CoopCtx C;
     C.nwg = per; C.wgi = r_ - grp * nwg; C.Ppad = a.G * 32; C.epoch = 0u; C.spin_limit = a.coop_spin; C.fence = a.opt.coop_fence;
-    C.bar = a.coop_bar + 2 * b;
+    C.bar = a.coop_bar + COOP_BAR_WORDS * b;
     C.pp = a.coop_pp + (size_t)b * coop_pp_stride(H, C.Ppad);
     C.ck = a.coop_ck + ((size_t)b * SPEC_CKS + (grp == 6 ? 3 : grp >= 2 && grp <= 4 ? grp - 2 : 0)) * a.P * (H + 1) * COOP_ROW;    // gradients run on groups 2..4 and 6 (or 0 when there are only two)
     Smem sm = carve(smem, H, m, 0, true);
@@ -105,7 +115,13 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     // no grid barrier of its own (a barrier costs 5 - 6 us of round trips across the XCDs: 5 % of an iteration), the hand-off is the datum itself
     unsigned long long* gtot_base = reinterpret_cast<unsigned long long*>(C.pp + coop_gtot_offset(H, C.Ppad));
     C.gtot = gtot_base;
-    unsigned red_cnt = 0u, red_par = 0u; int red_slot = 0;
+    unsigned red_cnt = 0u, red_par = 0u, red_tag = 0u; int red_slot = 0;
+    unsigned phc = 0u, par_tag = 0u, arr_cnt = 0u;      // phases so far (the tag of a phase's outputs is its number), tag of the last parallel phase, arrivals of this workgroup
+    // Polling costs the polled (a store whose line hundreds of waves keep reading is acknowledged late, and gfx9 counts loads and stores in one in-order
+    // counter: sdempc_lane2.inc.h, adjoint loop), and 55 us of it per iteration buy nothing. So a reducer SLEEPS (no memory traffic) until shortly before
+    // the time the totals took to arrive in the iteration before, counted from the start of the parallel phase, and polls only then.
+    uint64_t t_par = 0; unsigned d_tot = 0u;            // s_memrealtime at the start of the last parallel phase; ticks from there to the totals, last streamed reduction
+    constexpr unsigned RED_LEAD = 900u;                 // start polling this many 10-ns ticks before the totals are due (reduce + publish + observe: 4 - 5 us)
     // tags of an earlier launch must not be taken for this one's: the instance's first workgroup clears the words (the first reduction phase lies
     // behind at least two grid barriers)
     if (r_ == 0)
@@ -121,6 +137,11 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
 #if SDEMPC_VAR_SPEC_CLK
     // diagnostic build (tools/spec_clock.py): 10 ns ticks by phase kind and section, workgroup (group 3, first) -> over the mean trajectory
     unsigned long long ck_acc[PH_DONE][3] = {}, ck_n[PH_DONE] = {};
+    unsigned long long hw_last = 0, hw_hit = 0, hw_nhit = 0, hw_n = 0; int hw_slot = -1;      // work time of a parallel phase when this group's gradient was the one used / when not
+    unsigned long long hk[6] = {}, hk_t = 0;      // sections of a polled head: control cost of yk | wait for the totals + g + trial points | barrier + arrive | ten reductions | candidate points
+#define SPEC_HK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); hk[i] += t_ - hk_t; hk_t = t_; }
+#else
+#define SPEC_HK(i)
 #endif
     while (phase != PH_DONE) {
 #if SDEMPC_VAR_SPEC_CLK
@@ -130,25 +151,46 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         // ---- this workgroup's work item of the phase ----
         const float* iu = xk; int islot = SLOT_SEQ; bool igrad = false, imean = false, iact = false;
         unsigned par = C.epoch & 1u;
+        const unsigned wtag = ++phc;
         if (phase == PH_RED) {
             constexpr int nq = M + 4;
-            const float* pbuf = C.pp + (size_t)(red_par * SPEC_SLOTS + red_slot) * PS * C.Ppad;
+            const unsigned long long* pw = spec_words(C, PS, red_par, red_slot);
             unsigned long long* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
             const unsigned long long tag = (unsigned long long)(red_cnt + 1u) << 32;
-            // one total per wave, spread over every wave of the instance's workgroups (H * nq + 1 totals on up to 7 x 32 x 4 waves: a wave
-            // that reduced several of them paid one cross-XCD round trip after the other)
-            for (int item = r_ * 4 + wave; item <= H * nq; item += per * 4) {
-                const int t = item / nq, q = item < H * nq ? t * 12 + (item - t * nq) : PS - 1;       // the last item: the cost total
-                const float sv = coop_total(pbuf + (size_t)q * C.Ppad, a.P, a.G, lane);
-                if (lane == 0) __hip_atomic_store(gt + q, tag | (unsigned long long)__float_as_uint(sv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // H * nq + 1 totals (the last item: the cost total), at most two per wave and those two polled side by side (a wave that reduced several of
+            // them one after the other paid one cross-XCD round trip per item). The waves of the TRIAL groups reduce when they can take it all: their rollouts
+            // end long before the gradient sweeps do (42 of 100 us at C2), so they have read the trial costs, know which candidate gradient the optimiser
+            // will use and are already polling its words when the last of them is written — the gradient groups, which end the phase, only wait for the totals.
+            const int items = H * nq + 1, nt = have_t3 ? 3 : 2, tw = nt * nwg * 4;
+            const bool trial_grp = grp < 2 || grp == 5;
+            const int gi = trial_grp ? (grp == 5 ? 2 : grp) : nt + (grp == 6 ? 3 : grp - 2);
+            const int rank = __builtin_amdgcn_readfirstlane((gi * nwg + C.wgi) * 4 + wave);
+            const int nredw = 2 * tw >= items ? tw : per * 4;
+            if (rank < nredw && red_tag == par_tag && d_tot > RED_LEAD) {
+                const uint64_t due = t_par + (uint64_t)(d_tot - RED_LEAD);
+                while (__builtin_amdgcn_s_memrealtime() < due) __builtin_amdgcn_s_sleep(8);
             }
+            const uint64_t t0r = __builtin_amdgcn_s_memrealtime();
+            if (rank < nredw)
+                for (int i0 = rank; i0 < items; i0 += 2 * nredw) {
+                    const int i1 = i0 + nredw;
+                    const int t0 = i0 / nq, q0 = i0 < H * nq ? t0 * 12 + (i0 - t0 * nq) : PS - 1;
+                    const int t1 = i1 / nq, q1 = i1 < H * nq ? t1 * 12 + (i1 - t1 * nq) : PS - 1;
+                    float s0, s1;
+                    coop_total_tagged2(C, pw + (size_t)q0 * C.Ppad, i1 < items ? pw + (size_t)q1 * C.Ppad : nullptr, a.P, a.G, lane, red_tag, t0r, s0, s1);
+                    if (lane == 0) {
+                        __hip_atomic_store(gt + q0, tag | (unsigned long long)__float_as_uint(s0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (i1 < items) __hip_atomic_store(gt + q1, tag | (unsigned long long)__float_as_uint(s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
         }
         else if (phase == PH_INIT) { iact = grp == 0; }
         else if (phase == PH_GRAD) { iact = grp == grad_grp; iu = yk; islot = SLOT_GRAD; igrad = true; }
         else if (phase == PH_SEQ) { iact = grp == 0; iu = xn; }
         else if (phase == PH_FINAL) { iact = grp == 0; imean = true; }
         else {   // PH_PAR
-            par = par_cnt & 1u; par_spec = par; par_cnt += 1u;
+            par = par_cnt & 1u; par_spec = par; par_cnt += 1u; par_tag = wtag;
+            t_par = __builtin_amdgcn_s_memrealtime();
             if (grp == 0) { iact = true; iu = xn1; islot = 0; }
             else if (grp == 1) { iact = two; iu = xn2; islot = 1; }
             else if (grp == 2) { iact = spec && two; iu = y2; igrad = true; islot = 3; }     // when there is one trial only, y1 takes this group
@@ -172,55 +214,44 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             __syncthreads();
             const int p = C.wgi * 4 + wave;
             if (p < a.P) {
-                const Lane2IO io = lane_io_slot(a, C, b, p, par, islot);
+                const Lane2IO io = lane_io_slot(a, C, b, p, par, islot, wtag);
                 const Lane2Lds L = lane2_lds(a, sm, wave);
-                if (igrad) lane2_grad<M>(a, sm, L, io, lane);
-                else if (imean) lane2_rollout<true>(a, sm, L, io, lane);
-                else lane2_rollout<false>(a, sm, L, io, lane);
+                if (igrad) lane2_grad<M, true>(a, sm, L, io, lane);
+                else if (imean) lane2_rollout<true, true>(a, sm, L, io, lane);
+                else lane2_rollout<false, true>(a, sm, L, io, lane);
             }
         }
 #if SDEMPC_VAR_SPEC_CLK
         const unsigned long long ck_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (phase != PH_RED) coop_barrier(C, tid);      // (the totals of a reduction phase carry their own tag)
+        if (phase != PH_RED && phase != PH_PAR) coop_barrier(C, tid);      // (the outputs of a parallel phase and the totals of a reduction phase are their own hand-off)
 #if SDEMPC_VAR_SPEC_CLK
         const unsigned long long ck_t2 = __builtin_amdgcn_s_memrealtime();
 #endif
         // ---- the optimiser (SPEC.md §8), advanced as far as the data of this phase allows ----
-        bool head = false, tail = false, fin = false;
+        bool head = false, tail = false, fin = false, head_poll = false;
         if (phase == PH_INIT) {
-            c_init = uni_f(spec_cost(a, sm, C, tid, par, xk, SLOT_SEQ));
+            c_init = uni_f(spec_cost(a, sm, C, tid, par, xk, SLOT_SEQ, wtag));
             c_x = c_init;
             phase = a.A.max_iter > 0 ? PH_GRAD : PH_FINAL;
         } else if (phase == PH_GRAD) {
-            red_slot = SLOT_GRAD; red_par = par;
+            red_slot = SLOT_GRAD; red_par = par; red_tag = wtag;
             if constexpr (DIRECT) fin = true;
             else phase = PH_RED;
         } else if (phase == PH_RED) {
-            constexpr int nq = M + 4;
-            const unsigned long long* gt = gtot_base + (size_t)(red_cnt & 1u) * PS;
             red_cnt += 1u;
-            const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
-            auto tagged = [&](const unsigned long long* p) {        // wait (bounded like a grid barrier) until the word carries this phase's tag
-                return tagged_wait(C, p, red_cnt, t0w);
-            };
-            for (int q = tid; q < H * 12; q += Team::NT)
-                if ((q % 12) < nq) sm.tot[q] = tagged(gt + q);
-            if (tid == 0) sm.red[12] = tagged(gt + PS - 1);
-            const float cu = block_ucost<Team>(a, sm, yk, tid);        // (contains the barriers that publish sm.tot / sm.red)
-            __syncthreads();
-            c_y = uni_f(FMA(sm.red[12], a.invP, cu));
-            assemble_gradient<Team, M>(a, sm, yk, g, tid, [&](int q) { return sm.tot[q]; });
-            __syncthreads();
-            head = true;
+            head = true; head_poll = true;      // the totals are polled in the head, by the thread that needs them
         } else if (phase == PH_PAR) {
-            // both trial costs at once: particle totals by waves 0 / 1, control costs and g.d known since the head of the iteration
+            // the trial costs at once: particle totals by waves 0 .. 2 (polled: no barrier behind this phase), control costs and g.d known since the
+            // head of the iteration; the last wave makes sure every workgroup has left the iteration before (coop_arrive)
             const int PSs = part_stride(H);
             __syncthreads();
-            if (wave < (three ? 3 : two ? 2 : 1)) {
-                const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + (wave == 2 ? SLOT_T3 : wave)) * PSs * C.Ppad;
-                const float t0 = coop_total(pbuf + (size_t)(PSs - 1) * C.Ppad, a.P, a.G, lane);
-                if (lane == 0) sm.red[12 + wave] = t0;
+            {
+                const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
+                if (wave < (three ? 3 : two ? 2 : 1)) {
+                    const float t0 = coop_total_tagged(C, spec_words(C, PSs, par, wave == 2 ? SLOT_T3 : wave) + (size_t)(PSs - 1) * C.Ppad, a.P, a.G, lane, wtag, t0w);
+                    if (lane == 0) sm.red[12 + wave] = t0;
+                } else if (tid == 255) coop_arrived_wait(C, arr_cnt * (unsigned)per, t0w);
             }
             __syncthreads();
             c_n = uni_f(FMA(sm.red[12], a.invP, cu_1));
@@ -259,7 +290,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 phase = PH_SEQ;
             } else tail = true;
         } else if (phase == PH_SEQ) {
-            c_n = uni_f(spec_cost(a, sm, C, tid, par, xn, SLOT_SEQ));
+            c_n = uni_f(spec_cost(a, sm, C, tid, par, xn, SLOT_SEQ, wtag));
             const float gd = uni_f(block_dot<Team>(sm, g, d1, N, tid));
             nls = jl + 1; jsel = 0;
             bool done = c_n <= FMA(a.A.coef, gd, c_y);
@@ -276,12 +307,14 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             } else tail = true;
         } else {   // PH_FINAL
             if (grp == 0 && C.wgi == 0) {
-                const float* pbuf = C.pp + (size_t)(par * SPEC_SLOTS + SLOT_SEQ) * PS * C.Ppad;
+                const unsigned long long* pw = spec_words(C, PS, par, SLOT_SEQ);
                 float* xmean_out = a.xmean + (size_t)b * (H + 1) * NX;
 #if !SDEMPC_VAR_SPEC_CLK
-                for (int q = wave; q < (H + 1) * NX; q += 4) {
-                    const float sv = coop_total(pbuf + (size_t)q * C.Ppad, a.P, a.G, lane);
-                    if (lane == 0) xmean_out[q] = sv * a.invP;
+                const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
+                for (int q = wave; q < (H + 1) * NX; q += 8) {
+                    float s0, s1;
+                    coop_total_tagged2(C, pw + (size_t)q * C.Ppad, q + 4 < (H + 1) * NX ? pw + (size_t)(q + 4) * C.Ppad : nullptr, a.P, a.G, lane, wtag, t0w, s0, s1);
+                    if (lane == 0) { xmean_out[q] = s0 * a.invP; if (q + 4 < (H + 1) * NX) xmean_out[q + 4] = s1 * a.invP; }
                 }
 #endif
                 for (int e = tid; e < N; e += Team::NT) a.uopt[(size_t)b * N + e] = xk[e];
@@ -327,11 +360,14 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 noimp = noimp + 1;
                 if (spec && have_xk) hit_slot = 4;               // the new yk is xk, unchanged since the parallel phase
             }
+#if SDEMPC_VAR_SPEC_CLK
+            if (hw_slot >= 0) { if (hit_slot == hw_slot) { hw_hit += hw_last; hw_n += 1; } else hw_nhit += hw_last; }
+#endif
             if (noimp >= a.A.max_noimp) stop = 1;
             k += 1;
             if (stop || k >= a.A.max_iter) phase = PH_FINAL;
             else if (hit_slot >= 0) {
-                red_slot = hit_slot; red_par = par_spec;
+                red_slot = hit_slot; red_par = par_spec; red_tag = par_tag;
                 if constexpr (DIRECT) fin = true;
                 else phase = PH_RED;
             }
@@ -341,10 +377,11 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             if (fin) {   // (c_y, g) straight from the particle's outputs in (red_par, red_slot): v + 0 is what the butterflies and the slot
                          // order of SPEC.md §6.1 make of one value and zeros, so no reduction phase and no barrier for it
                 constexpr int nq = M + 4;
-                const float* pbuf = C.pp + (size_t)(red_par * SPEC_SLOTS + red_slot) * PS * C.Ppad;
+                const unsigned long long* pw = spec_words(C, PS, red_par, red_slot);
+                const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
                 for (int q = tid; q < H * 12; q += Team::NT)
-                    if ((q % 12) < nq) sm.tot[q] = coop_load(pbuf + (size_t)q * C.Ppad) + 0.0f;
-                if (tid == 0) sm.red[12] = coop_load(pbuf + (size_t)(PS - 1) * C.Ppad) + 0.0f;
+                    if ((q % 12) < nq) sm.tot[q] = tagged_wait(C, pw + (size_t)q * C.Ppad, red_tag, t0w) + 0.0f;
+                if (tid == 0) sm.red[12] = tagged_wait(C, pw + (size_t)(PS - 1) * C.Ppad, red_tag, t0w) + 0.0f;
                 const float cu = block_ucost<Team>(a, sm, yk, tid);
                 __syncthreads();
                 c_y = uni_f(FMA(sm.red[12], a.invP, cu));
@@ -362,14 +399,51 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 sn = a.A.stepsize;
             }
             const float s1 = sn, s2 = sn * a.A.dec, s3 = s2 * a.A.dec;
-            __syncthreads();
-            for (int e = tid; e < N; e += Team::NT) {
-                int jj = e % m;
-                xn1[e] = clampf(FMA(-s1, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
-                xn2[e] = clampf(FMA(-s2, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
-                xn3[e] = clampf(FMA(-s3, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+            if (head_poll) {
+                // (c_y, g) from the published totals: every thread polls the five sums its element of the gradient is made of (and the cost total) itself and
+                // goes on to the trial points of that element — no staging of the totals in LDS, no barrier between totals, gradient and trial points; the
+                // control cost of yk needs no totals and is reduced BEFORE the wait (its barriers also order this iteration's writes of g / xn_j behind the last reads)
+                const unsigned long long* gt = gtot_base + (size_t)((red_cnt - 1u) & 1u) * PS;
+#if SDEMPC_VAR_SPEC_CLK
+                hk_t = __builtin_amdgcn_s_memrealtime();
+#endif
+                const float cu = block_ucost<Team>(a, sm, yk, tid);
+                SPEC_HK(0)
+                const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
+                float ctot = 0.0f;
+                for (int e0 = 0; e0 < N; e0 += Team::NT) {
+                    const int e = e0 + tid;
+                    const bool he = e < N;
+                    const int t = he ? e / m : 0, jj = he ? e - t * m : 0;
+                    const unsigned long long* const pw[6] = {gt + t * 12 + jj, gt + t * 12 + M, gt + t * 12 + M + 1, gt + t * 12 + M + 2, gt + t * 12 + M + 3, gt + PS - 1};
+                    const bool have[6] = {he, he, he, he, he, e0 == 0};
+                    float v[6];
+                    tagged_wait_n<6>(C, pw, have, red_cnt, t0w, v);
+                    if (e0 == 0) ctot = v[5];
+                    if (he) {
+                        const float S[5] = {v[0], v[1], v[2], v[3], v[4]};
+                        const float ge = assemble_elem(a, sm, yk, e, t, jj, S);
+                        g[e] = ge;
+                        xn1[e] = clampf(FMA(-s1, ge, yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                        xn2[e] = clampf(FMA(-s2, ge, yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                        xn3[e] = clampf(FMA(-s3, ge, yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                    }
+                }
+                if (red_tag == par_tag) d_tot = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_par);
+                c_y = uni_f(FMA(ctot, a.invP, cu));
+                SPEC_HK(1)
+            } else {
+                __syncthreads();
+                for (int e = tid; e < N; e += Team::NT) {
+                    int jj = e % m;
+                    xn1[e] = clampf(FMA(-s1, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                    xn2[e] = clampf(FMA(-s2, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                    xn3[e] = clampf(FMA(-s3, g[e], yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                }
             }
             __syncthreads();
+            arr_cnt += 1u; coop_arrive(C, tid);      // everything the iteration before produced has been read by this workgroup
+            SPEC_HK(2)
             // everything the optimiser will ask about the two parallel trials except their particle costs, in one reduction:
             // |g|^2; g.(xn_j - yk) of the Armijo tests; the restart tests (yk - xn_j).(xn_j - xk); the control costs of xn_j
             float r7[10];
@@ -387,6 +461,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 acc[9] = FMA(ucost_elem(a, sm, xn3, e, m), 1.0f, acc[9]);
             });
             gsq = uni_f(r7[0]);
+            SPEC_HK(3)
             if (!(gsq < __builtin_inff())) { phase = PH_FINAL; continue; }      // (s keeps the value of the last completed iteration)
             s = sn;
             gd_1 = uni_f(r7[1]); gd_2 = uni_f(r7[2]); rs_1 = uni_f(r7[3]); rs_2 = uni_f(r7[4]); cu_1 = uni_f(r7[5]); cu_2 = uni_f(r7[6]);
@@ -404,11 +479,13 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 if (three) y3[e] = (rs_3 > 0.0f) ? x3 : clampf(FMA(bt, x3 - xe, x3), a.C.ulo[jj], a.C.uhi[jj]);
             }
             __syncthreads();
+            SPEC_HK(4)
             phase = PH_PAR;
         }
 #if SDEMPC_VAR_SPEC_CLK
         {
             const unsigned long long ck_t3 = __builtin_amdgcn_s_memrealtime();
+            if (ck_phase == PH_PAR) { hw_last = ck_t1 - ck_t0; hw_slot = grp >= 2 && grp != 5 ? (grp == 2 ? 3 : grp == 3 ? 4 : grp == 4 ? 2 : SLOT_Y3) : -1; }
             ck_acc[ck_phase][0] += ck_t1 - ck_t0; ck_acc[ck_phase][1] += ck_t2 - ck_t1; ck_acc[ck_phase][2] += ck_t3 - ck_t2; ck_n[ck_phase] += 1;
         }
 #endif
@@ -419,9 +496,15 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         o[2 * r_] = (float)ck_acc[PH_PAR][0] * 0.01f / (float)(ck_n[PH_PAR] ? ck_n[PH_PAR] : 1);
         o[2 * r_ + 1] = (float)((__builtin_amdgcn_s_getreg(63508) & 15) * 100 + grp);      // HW_REG_XCC_ID
     }
+    if (grp >= 2 && grp != 5 && C.wgi == 0 && tid == 0 && ng == 7) {      // per gradient group: mean work time (us) when hit / when not, and how often it was hit
+        float* o = a.xmean + (size_t)b * (H + 1) * NX + 560 + 4 * (grp == 6 ? 3 : grp - 2);
+        const unsigned long long nn = ck_n[PH_PAR] - hw_n;
+        o[0] = hw_n ? (float)hw_hit * 0.01f / (float)hw_n : 0.0f; o[1] = nn ? (float)hw_nhit * 0.01f / (float)nn : 0.0f; o[2] = (float)hw_n; o[3] = (float)nn;
+    }
     if (grp == (ng > 3 ? 3 : 0) && C.wgi == 0 && tid == 0) {
         float* o = a.xmean + (size_t)b * (H + 1) * NX + 64;
         for (int ph = 0; ph < PH_DONE; ++ph) { for (int k = 0; k < 3; ++k) o[ph * 4 + k] = (float)ck_acc[ph][k]; o[ph * 4 + 3] = (float)ck_n[ph]; }
+        for (int i = 0; i < 5; ++i) o[PH_DONE * 4 + i] = (float)hk[i];
     }
 #endif
 }

@@ -29,6 +29,13 @@ for ph in range(6):
     w, b, o, n = c[ph]
     if n:
         print(f"  {names[ph]:38s} x {n:4.0f}: work {w * 1e-5:7.2f} ms ({w / n * 1e-2:7.1f} us each)  barrier {b * 1e-5:6.2f} ms ({b / n * 1e-2:5.1f} us)  optimiser {o * 1e-5:6.2f} ms ({o / n * 1e-2:5.1f} us)")
+hk = xevol.reshape(-1)[64 + 24:64 + 29].astype(np.float64)
+nred = c[4, 3]
+if nred:
+    print("  a polled head (behind a reduction phase), us each: " + ", ".join(f"{n} {v / nred * 1e-2:.2f}" for n, v in zip(
+        ["control cost of yk", "wait for the totals + gradient + trial points", "barrier + arrive", "ten reductions", "candidate points + barrier"], hk)))
+hw = xevol.reshape(-1)[560:576].astype(np.float64).reshape(4, 4)
+print("  gradient groups (y2, xk, y1, y3): work when their gradient was the one used / when not, us: " + "; ".join(f"{r[0]:.1f} (x{r[2]:.0f}) / {r[1]:.1f} (x{r[3]:.0f})" for r in hw))
 w = xevol.reshape(-1)[100:100 + 2 * 224].astype(np.float64).reshape(-1, 2)
 w = w[w[:, 0] > 0]
 xcc, grp = (w[:, 1] // 100).astype(int), (w[:, 1] % 100).astype(int)

@@ -147,8 +147,13 @@ DI float coop_total_tagged(CoopCtx& C, const unsigned long long* pq, int P, int 
 // that no grid barrier separates them. A workgroup arrives (one fire-and-forget atomic) when it has read everything iteration k produced; before it leaves
 // the parallel phase of iteration k + 1 it makes sure everyone has — a whole phase later, so the word it polls has long had its value (one load, in the
 // shadow of the trial-cost polls of the other waves).
+// (The tagged words themselves need no fence under any memory model: value and flag are ONE atomic location. The arrival counter orders accesses to
+// OTHER locations — reads before the add, writes behind the wait — so SDEMPC_OPT_COOP_FENCE puts its release / acquire pair here as well.)
 DI void coop_arrive(CoopCtx& C, int tid) {
-    if (tid == 0) __hip_atomic_fetch_add(C.bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        if (C.fence) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __hip_atomic_fetch_add(C.bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 DI void coop_arrived_wait(CoopCtx& C, unsigned target, uint64_t t0w) {
     unsigned polls = 0;
@@ -160,6 +165,7 @@ DI void coop_arrived_wait(CoopCtx& C, unsigned target, uint64_t t0w) {
         }
         if ((++polls & 7u) == 0u && __hip_atomic_load(C.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { C.spin_limit = 0; break; }
     }
+    if (C.fence) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 }
 
 // total of quantity q over the particles: SPEC.md §6.1 (32-particle butterflies, slots g mod 4 in ascending g, ((S0+S1)+S2)+S3);

@@ -413,26 +413,6 @@ DI void assemble_gradient(const KArgs& a, const Smem& sm, const float* y, float*
     }
 }
 
-// the same element e = t * m + jj from the five particle sums it depends on — S(t, jj) and the thrust / torque sums S(t, M .. M + 3) — handed in by a caller that
-// fetched them itself (speculative kernel: every thread polls the published totals of its own element; the statements of assemble_gradient, kept apart so that
-// the throughput kernels compile to the same code as before)
-DI float assemble_elem(const KArgs& a, const Smem& sm, const float* y, int e, int t, int jj, const float (&S)[5]) {
-    const int H = a.H, m = a.m;
-    float uj = y[e];
-    float dT = FMA(2.0f * a.M.ct2, uj, a.M.ct1);
-    float dM = a.M.dir[jj] * FMA(2.0f * a.M.cm2, uj, a.M.cm1);
-    float acc = S[0];
-    acc = FMA(S[1], dT, acc);
-    acc = FMA(S[2], a.M.ry[jj] * dT, acc);
-    acc = FMA(S[3], -(a.M.rx[jj] * dT), acc);
-    acc = FMA(S[4], dM, acc);
-    float du = uj - a.C.uref[jj];
-    float dw = 0.0f, ctmp;
-    if (t >= 1) dw = slew_dw(a, y, t, jj, m, ctmp);
-    float gcu = sm.disc[t] * FMA(2.0f * a.C.uerr, du, dw);
-    if (t + 1 < H) { float dwn = slew_dw(a, y, t + 1, jj, m, ctmp); gcu = FMA(-sm.disc[t + 1], dwn, gcu); }
-    return FMA(acc, a.invP, gcu);
-}
 // ---- P == 1 team: one wave per instance ----
 DI LaneIO lane_io_p1(const KArgs& a, int b) {
     const int H = a.H, PS = part_stride(H);

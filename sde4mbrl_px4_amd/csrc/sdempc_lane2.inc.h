@@ -36,18 +36,21 @@ static_assert(COOP_ROW == CK_X + 4 * CK_NU, "checkpoint row");
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SDEMPC_STR2(x) #x
 #define SDEMPC_STR(x) SDEMPC_STR2(x)
-DI void store_sc1_masked(unsigned long long mask, float* p, float v) {      // agent-scope (write-through) store, as __hip_atomic_store(relaxed, agent) emits it
+// (the lane mask is a compile-time 32-bit literal of the instruction, not a pair of scalar registers held across the sweep)
+template <unsigned MASK>
+DI void store_sc1_masked(float* p, float v) {      // agent-scope (write-through) store, as __hip_atomic_store(relaxed, agent) emits it
     unsigned long long sv;
     asm volatile("s_and_saveexec_b64 %0, %1\n global_store_dword %2, %3, off sc1\n s_mov_b64 exec, %0"
-                 : "=&s"(sv) : "s"(mask), "v"(p), "v"(v) : "memory", "scc");      // (s_and_saveexec writes SCC)
+                 : "=&s"(sv) : "i"(MASK), "v"(p), "v"(v) : "memory", "scc");      // (s_and_saveexec writes SCC)
 }
 // the same store of a TAGGED output word {value, tag} (64 bits, one aligned store: the datum is its own hand-off flag — sdempc_spec.inc.h, "streamed hand-off")
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-DI void store_sc1_masked_tagged(unsigned long long mask, float* p, float v, unsigned tag) {
+template <unsigned MASK>
+DI void store_sc1_masked_tagged(float* p, float v, unsigned tag) {
     unsigned long long sv;
     const u32x2 w = {__float_as_uint(v), tag};
     asm volatile("s_and_saveexec_b64 %0, %1\n global_store_dwordx2 %2, %3, off sc1\n s_mov_b64 exec, %0"
-                 : "=&s"(sv) : "s"(mask), "v"(p), "v"(w) : "memory", "scc");
+                 : "=&s"(sv) : "i"(MASK), "v"(p), "v"(w) : "memory", "scc");
 }
 // the CK_NU float4 of uniform values of a checkpoint row, by lane 0
 DI void store_row_uniform(float* row, const f32x4 (&u)[11]) {
@@ -276,10 +279,10 @@ struct Lane2IO {
     int os;
     unsigned tag;      // TAGGED sweeps (speculative kernel): every output is a 64-bit word {value, tag}, os counts floats (two per word)
 };
-template <bool TAGGED>
-DI void lane2_out(const Lane2IO& io, unsigned long long mask, float* p, float v) {
-    if constexpr (TAGGED) store_sc1_masked_tagged(mask, p, v, io.tag);
-    else store_sc1_masked(mask, p, v);
+template <bool TAGGED, unsigned MASK>
+DI void lane2_out(const Lane2IO& io, float* p, float v) {
+    if constexpr (TAGGED) store_sc1_masked_tagged<MASK>(p, v, io.tag);
+    else store_sc1_masked<MASK>(p, v);
 }
 
 // one particle: rollout and cost; MEAN: the states go to io.out (the final rollout of a solve)
@@ -294,7 +297,7 @@ DI void lane2_rollout(const KArgs& a, const Smem& sm, const Lane2Lds& L, const L
     for (int i = 0; i < NX; ++i) x[i] = io.x0[i];
     if (MEAN) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) lane2_out<TAGGED>(io, 1ull, io.out + (size_t)i * io.os, x[i]);
+        for (int i = 0; i < NX; ++i) lane2_out<TAGGED, 1u>(io, io.out + (size_t)i * io.os, x[i]);
     }
     float J = 0.0f;
     StepAux A;
@@ -318,11 +321,11 @@ DI void lane2_rollout(const KArgs& a, const Smem& sm, const Lane2Lds& L, const L
         for (int i = 0; i < NX; ++i) x[i] = xn[i];
         if (MEAN) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) lane2_out<TAGGED>(io, 1ull, io.out + (size_t)((t + 1) * NX + i) * io.os, x[i]);
+            for (int i = 0; i < NX; ++i) lane2_out<TAGGED, 1u>(io, io.out + (size_t)((t + 1) * NX + i) * io.os, x[i]);
         }
         rp += REC; rk += REC; rz += REC; np += NZL;
     }
-    lane2_out<TAGGED>(io, 1ull, io.out + (size_t)(PS - 1) * io.os, J);
+    lane2_out<TAGGED, 1u>(io, io.out + (size_t)(PS - 1) * io.os, J);
 }
 
 // what the adjoint step t reads: its checkpoint row
@@ -377,7 +380,7 @@ DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane
         int t = 0;
         for (; t + 1 < H; t += 2) { fstep(xa, xb); fstep(xb, xa); }
         if (t < H) fstep(xa, xb);
-        lane2_out<TAGGED>(io, 1ull, io.out + (size_t)(PS - 1) * io.os, J);
+        lane2_out<TAGGED, 1u>(io, io.out + (size_t)(PS - 1) * io.os, J);
     }
     // ---- adjoint sweep: two steps per trip over two register sets; the row of step t - 1 is requested while step t is processed ----
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -391,7 +394,7 @@ DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane
     const bool olane = oq >= 0 && oq < nq;
     float* op = io.out + (size_t)(olane ? oq : 0) * io.os;      // + t * 12 * os per step
     const size_t ostep = (size_t)12 * io.os;
-    const unsigned long long omask = ((1ull << nq) - 1ull) << 16;
+    constexpr unsigned omask = ((1u << nq) - 1u) << 16;
     auto step = [&](int t, const AdjRow& R) -> float {
         const float* rp = L.rec + t * REC;
         const float* np = L.nz + t * NZL;
@@ -428,7 +431,8 @@ DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane
     // takes longer than a step (~ 1 us). With the store in front of the request every step waited for the store of the step before: 8 us of a 50-step sweep
     // (C2 parallel phase 101.3 -> 93.4 us, measured with tools/spec_clock.py; single solve 22.6 -> 20.3 ms). Now a store has two steps to complete
     // (one step more — behind the second request after its step — evens out the last 0.8 us between the gradient groups but costs 0.6 % in moves: not taken).
-    auto out = [&](int t, float ov) { lane2_out<TAGGED>(io, omask, op + (size_t)t * ostep, ov); };
+    float* ow = op + (size_t)(H - 1) * ostep;      // the stores leave in step order H - 1, H - 2, ...: one running pointer
+    auto out = [&](float ov) { lane2_out<TAGGED, omask>(io, ow, ov); ow -= ostep; };
     AdjRow RA, RB;
     const float* rowH = io.ck + (size_t)(H - 1) * COOP_ROW;
     lane2_request_row(rowH, lane, RA);
@@ -436,12 +440,12 @@ DI void lane2_grad(const KArgs& a, const Smem& sm, const Lane2Lds& L, const Lane
     float ob = 0.0f;
     for (; t >= 1; t -= 2) {
         lane2_request_row(io.ck + (size_t)(t - 1) * COOP_ROW, lane, RB);
-        if (t != H - 1) out(t + 1, ob);
+        if (t != H - 1) out(ob);
         const float oa = step(t, RA);
         lane2_request_row(io.ck + (size_t)(t >= 2 ? t - 2 : 0) * COOP_ROW, lane, RA);      // (t == 1: row 0 once more, never used)
-        out(t, oa);
+        out(oa);
         ob = step(t - 1, RB);
     }
-    if (H >= 2) out(t + 1, ob);
-    if (t == 0) out(0, step(0, RA));
+    if (H >= 2) out(ob);
+    if (t == 0) out(step(0, RA));
 }

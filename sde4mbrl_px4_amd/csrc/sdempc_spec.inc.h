@@ -64,7 +64,53 @@ DI void spec_reduce_n(float* mred, int N, int tid, float (&out)[K], F&& elem) {
 #pragma unroll
     for (int k = 0; k < K; ++k) out[k] = ((mred[4 * k] + mred[4 * k + 1]) + mred[4 * k + 2]) + mred[4 * k + 3];
 }
-constexpr int SPEC_MRED = 48, SPEC_XV = 6;       // extra control vectors xn1..3, y1..3      // floats of reduction scratch behind the four extra control vectors
+constexpr int SPEC_MRED = 48 + 64, SPEC_XV = 6;  // extra control vectors xn1..3, y1..3; floats of reduction scratch (40 used) + the per-motor constants (SpecMot) behind them
+// The per-motor constants of KArgs the head of an iteration indexes by motor, copied to LDS once: indexed reads of the kernel argument are memory loads the
+// compiler cannot hoist out of the state machine's loop, and they sat in the dependent chain of the ten reductions between the totals and the next phase.
+// The functions below are the statements of ucost_elem / slew_dw / assemble_gradient (sdempc_kernels.hip, sdempc_lane.inc.h) on those copies.
+struct SpecMot { const float *uref, *ulo, *uhi, *shi, *slo, *dir, *ry, *rx; };
+DI float ucost_elem_k(const KArgs& a, const Smem& sm, const SpecMot& K, const float* u, int e, int t, int j, int m) {
+    float du = u[e] - K.uref[j];
+    float c = (a.C.uerr * du) * du;
+    if (t >= 1) {
+        float ds = u[e] - u[e - m];
+        c = FMA(a.C.slew * ds, ds, c);
+        if (a.C.has_sc) {
+            float hi = ds - K.shi[j]; hi = hi < 0.0f ? 0.0f : hi;
+            float lo = K.slo[j] - ds; lo = lo < 0.0f ? 0.0f : lo;
+            c = FMA(a.C.slew_cc * hi, hi, c);
+            c = FMA(a.C.slew_cc * lo, lo, c);
+        }
+    }
+    return sm.disc[t] * c;
+}
+DI float slew_dw_k(const KArgs& a, const SpecMot& K, const float* u, int t, int j, int m) {
+    float ds = u[t * m + j] - u[(t - 1) * m + j];
+    float d = (2.0f * a.C.slew) * ds;
+    if (a.C.has_sc) {
+        float hi = ds - K.shi[j]; hi = hi < 0.0f ? 0.0f : hi;
+        float lo = K.slo[j] - ds; lo = lo < 0.0f ? 0.0f : lo;
+        d = FMA(2.0f * a.C.slew_cc, hi - lo, d);
+    }
+    return d;
+}
+DI float assemble_elem_k(const KArgs& a, const Smem& sm, const SpecMot& K, const float* y, int e, int t, int jj, int m, const float* S) {
+    const int H = a.H;
+    float uj = y[e];
+    float dT = FMA(2.0f * a.M.ct2, uj, a.M.ct1);
+    float dM = K.dir[jj] * FMA(2.0f * a.M.cm2, uj, a.M.cm1);
+    float acc = S[0];
+    acc = FMA(S[1], dT, acc);
+    acc = FMA(S[2], K.ry[jj] * dT, acc);
+    acc = FMA(S[3], -(K.rx[jj] * dT), acc);
+    acc = FMA(S[4], dM, acc);
+    float du = uj - K.uref[jj];
+    float dw = 0.0f;
+    if (t >= 1) dw = slew_dw_k(a, K, y, t, jj, m);
+    float gcu = sm.disc[t] * FMA(2.0f * a.C.uerr, du, dw);
+    if (t + 1 < H) { float dwn = slew_dw_k(a, K, y, t + 1, jj, m); gcu = FMA(-sm.disc[t + 1], dwn, gcu); }
+    return FMA(acc, a.invP, gcu);
+}
 // one workgroup per CU (512 registers per lane: what does not fit the 256 VGPRs spills to AGPRs, not to scratch memory — with two
 // workgroups per CU the adjoint loop carried 43 scratch accesses per step and ran 3x slower)
 // DIRECT: single-particle instances (P == 1, every MPC YAML the reference ships): a particle is its own total, no reduction phase
@@ -75,7 +121,9 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // a.coop_ngrp groups (2..7) per instance take the roles T1, T2, S(y2), S(xk), S(y1), T3, S(y3) in this order of usefulness
     // (measured at C2: the line search ends on trial 2 in 60 %, there is no improvement in 31 %, it ends on trial 1 in 28 % of the iterations)
-    const int nwg = a.coop_nwg, ng = a.coop_ngrp, per = ng * nwg, H = a.H, m = a.m, N = H * m, PS = part_stride(H);
+    // (the instantiations for four and six motors are launched for exactly those counts: sdempc_kernels.hip, launch_solve_spec — a compile-time m turns the
+    // e / m, e % m of every elementwise loop of the optimiser into multiplications)
+    const int nwg = a.coop_nwg, ng = a.coop_ngrp, per = ng * nwg, H = a.H, m = M == 8 ? a.m : M, N = H * m, PS = part_stride(H);
     const int b_ = blockIdx.x / per, r_ = blockIdx.x - b_ * per, grp = r_ / nwg;
     const bool have_y2 = ng >= 3, have_xk = ng >= 4, have_y1 = ng >= 5, have_t3 = ng >= 6, have_y3 = ng >= 7;
     const int grad_grp = ng >= 3 ? 2 : 0;          // who evaluates a gradient outside the parallel phase
@@ -98,6 +146,15 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     float* ex = sm.cend;
     float *xn1 = ex, *xn2 = ex + nv, *y1 = ex + 2 * nv, *y2 = ex + 3 * nv, *xn3 = ex + 4 * nv, *y3 = ex + 5 * nv, *mred = ex + SPEC_XV * nv;
     float *xk = sm.v[0], *yk = sm.v[1], *xn = sm.v[2], *g = sm.v[3], *d1 = sm.v[4], *d2 = sm.v[5];
+    SpecMot MK;
+    {
+        float* kc = mred + 48;
+        MK.uref = kc; MK.ulo = kc + 8; MK.uhi = kc + 16; MK.shi = kc + 24; MK.slo = kc + 32; MK.dir = kc + 40; MK.ry = kc + 48; MK.rx = kc + 56;
+        if (tid < 8) {
+            kc[tid] = a.C.uref[tid]; kc[8 + tid] = a.C.ulo[tid]; kc[16 + tid] = a.C.uhi[tid]; kc[24 + tid] = a.C.slew_hi[tid]; kc[32 + tid] = a.C.slew_lo[tid];
+            kc[40 + tid] = a.M.dir[tid]; kc[48 + tid] = a.M.ry[tid]; kc[56 + tid] = a.M.rx[tid];
+        }
+    }
     for (int e = tid; e < N; e += Team::NT) {
         int jj = e % m;
         float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
@@ -411,22 +468,26 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 SPEC_HK(0)
                 const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
                 float ctot = 0.0f;
-                for (int e0 = 0; e0 < N; e0 += Team::NT) {
-                    const int e = e0 + tid;
-                    const bool he = e < N;
-                    const int t = he ? e / m : 0, jj = he ? e - t * m : 0;
-                    const unsigned long long* const pw[6] = {gt + t * 12 + jj, gt + t * 12 + M, gt + t * 12 + M + 1, gt + t * 12 + M + 2, gt + t * 12 + M + 3, gt + PS - 1};
-                    const bool have[6] = {he, he, he, he, he, e0 == 0};
-                    float v[6];
-                    tagged_wait_n<6>(C, pw, have, red_cnt, t0w, v);
-                    if (e0 == 0) ctot = v[5];
-                    if (he) {
-                        const float S[5] = {v[0], v[1], v[2], v[3], v[4]};
-                        const float ge = assemble_elem(a, sm, yk, e, t, jj, S);
-                        g[e] = ge;
-                        xn1[e] = clampf(FMA(-s1, ge, yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
-                        xn2[e] = clampf(FMA(-s2, ge, yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
-                        xn3[e] = clampf(FMA(-s3, ge, yk[e]), a.C.ulo[jj], a.C.uhi[jj]);
+                for (int e0 = 0; e0 < N; e0 += 2 * Team::NT) {      // two elements per thread and polling round (N > 256: a second round would be a second round trip)
+                    const int ea = e0 + tid, eb = ea + Team::NT;
+                    const bool ha = ea < N, hb = eb < N;
+                    const int ta = ha ? ea / m : 0, ja = ha ? ea - ta * m : 0, tb = hb ? eb / m : 0, jb = hb ? eb - tb * m : 0;
+                    const unsigned long long *ga = gt + ta * 12, *gb = gt + tb * 12;
+                    const unsigned long long* const pw[11] = {ga + ja, ga + M, ga + M + 1, ga + M + 2, ga + M + 3, gb + jb, gb + M, gb + M + 1, gb + M + 2, gb + M + 3, gt + PS - 1};
+                    const bool have[11] = {ha, ha, ha, ha, ha, hb, hb, hb, hb, hb, e0 == 0};
+                    float v[11];
+                    tagged_wait_n<11>(C, pw, have, red_cnt, t0w, v);
+                    if (e0 == 0) ctot = v[10];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int e = half ? eb : ea, t = half ? tb : ta, jj = half ? jb : ja;
+                        if (half ? hb : ha) {
+                            const float ge = assemble_elem_k(a, sm, MK, yk, e, t, jj, m, v + 5 * half);
+                            g[e] = ge;
+                            xn1[e] = clampf(FMA(-s1, ge, yk[e]), MK.ulo[jj], MK.uhi[jj]);
+                            xn2[e] = clampf(FMA(-s2, ge, yk[e]), MK.ulo[jj], MK.uhi[jj]);
+                            xn3[e] = clampf(FMA(-s3, ge, yk[e]), MK.ulo[jj], MK.uhi[jj]);
+                        }
                     }
                 }
                 if (red_tag == par_tag) d_tot = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_par);
@@ -454,11 +515,12 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 acc[2] = FMA(ge, x2 - ye, acc[2]);
                 acc[3] = FMA(ye - x1, x1 - xe, acc[3]);
                 acc[4] = FMA(ye - x2, x2 - xe, acc[4]);
-                acc[5] = FMA(ucost_elem(a, sm, xn1, e, m), 1.0f, acc[5]);
-                acc[6] = FMA(ucost_elem(a, sm, xn2, e, m), 1.0f, acc[6]);
+                const int t = e / m, j = e - t * m;
+                acc[5] = FMA(ucost_elem_k(a, sm, MK, xn1, e, t, j, m), 1.0f, acc[5]);
+                acc[6] = FMA(ucost_elem_k(a, sm, MK, xn2, e, t, j, m), 1.0f, acc[6]);
                 acc[7] = FMA(ge, x3 - ye, acc[7]);
                 acc[8] = FMA(ye - x3, x3 - xe, acc[8]);
-                acc[9] = FMA(ucost_elem(a, sm, xn3, e, m), 1.0f, acc[9]);
+                acc[9] = FMA(ucost_elem_k(a, sm, MK, xn3, e, t, j, m), 1.0f, acc[9]);
             });
             gsq = uni_f(r7[0]);
             SPEC_HK(3)
@@ -474,9 +536,9 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             for (int e = tid; e < N; e += Team::NT) {
                 int jj = e % m;
                 const float x1 = xn1[e], x2 = xn2[e], x3 = xn3[e], xe = xk[e];
-                y1[e] = (rs_1 > 0.0f) ? x1 : clampf(FMA(bt, x1 - xe, x1), a.C.ulo[jj], a.C.uhi[jj]);
-                if (two) y2[e] = (rs_2 > 0.0f) ? x2 : clampf(FMA(bt, x2 - xe, x2), a.C.ulo[jj], a.C.uhi[jj]);
-                if (three) y3[e] = (rs_3 > 0.0f) ? x3 : clampf(FMA(bt, x3 - xe, x3), a.C.ulo[jj], a.C.uhi[jj]);
+                y1[e] = (rs_1 > 0.0f) ? x1 : clampf(FMA(bt, x1 - xe, x1), MK.ulo[jj], MK.uhi[jj]);
+                if (two) y2[e] = (rs_2 > 0.0f) ? x2 : clampf(FMA(bt, x2 - xe, x2), MK.ulo[jj], MK.uhi[jj]);
+                if (three) y3[e] = (rs_3 > 0.0f) ? x3 : clampf(FMA(bt, x3 - xe, x3), MK.ulo[jj], MK.uhi[jj]);
             }
             __syncthreads();
             SPEC_HK(4)

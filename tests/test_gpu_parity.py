@@ -643,6 +643,31 @@ def test_single_instance_full_length_solve_bit_exact(cfg_name, iters, layout):
     S.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("math_mode", ["fast", "exact"])
+def test_c3_single_instance_speculative_kernel_bit_exact(math_mode):
+    """C3 (hexarotor, P = 256, H = 50: 300 controls) in the speculative kernel's streamed hand-off: eight particle groups (both four-group chunks of a particle
+    total polled in one round), two gradient elements per thread in the head, four groups of 64 workgroups (trials 1 / 2, gradients at y2 / xk: every
+    line search that ends on trial 1 is a miss and takes the sequential phases) — a full-length solve against the oracle, both math modes."""
+    cfg = load_mpc_config(os.path.join(CDIR, "c3_hexa_traj_h50_p256.yaml")).replace(math_mode=math_mode)
+    model = synthetic_hexa()
+    x0, xref, _, _ = _problem(cfg, 1, 33)
+    key = orc.split([0, 12], 2)[1][None].astype(np.uint32)
+    S = _solver(cfg, model, 1)
+    yk, i0 = S.reset()
+    s0 = np.array([i0["stepsize"]], np.float32)
+    uopt, xevol, info = S.solve_keys(x0, xref, key, yk[None], s0)
+    assert "spec" in S.last_kernel_name(), S.last_kernel_name()
+    noise = orc.noise_from_key(key[0], cfg.num_particles, cfg.horizon)
+    orc.set_threads(min(os.cpu_count() or 1, 8))          # (the oracle's particle loops on every core: same bits)
+    try:
+        uo, xe, io, _ = orc.Oracle(cfg, model).solve(x0[0], xref[0], noise, yk, float(s0[0]))
+    finally:
+        orc.set_threads(1)
+    assert io[2] > 50 and bits_differ(uopt[0], uo) == 0 and bits_differ(xevol[0], xe) == 0 and bits_differ(info[0], io) == 0
+    S.close()
+
+
 # ---- cooperative layouts on a GPU they cannot have to themselves: bounded barrier, fallback to the tile layout ----------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("spec", ["1", "0"])

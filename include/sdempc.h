@@ -160,8 +160,8 @@ int sdempc_device_ready(const sdempc_handle* h);
  *   SDEMPC_OPT_HEX            0 / 1                          1        SDEMPC_HEX           launches that fill every two-wave team slot of the device: one six-team
  *                                                                                          workgroup per CU (weights staged once per CU) instead of three two-team ones
  *   SDEMPC_OPT_COOP_LAUNCH    0 / 1                          0        SDEMPC_COOP_LAUNCH   hipLaunchCooperativeKernel for the cooperative layouts
- *   SDEMPC_OPT_COOP_FENCE     0 / 1                          0        SDEMPC_COOP_FENCE    agent-scope release / acquire fences around the grid barrier
- *   SDEMPC_OPT_COOP_SPIN_US   -1 derived / >= 0 microseconds -1       SDEMPC_COOP_SPIN_US  how long one grid barrier of a cooperative layout may wait
+ *   SDEMPC_OPT_COOP_FENCE     0 / 1                          0        SDEMPC_COOP_FENCE    agent-scope release / acquire fences around the grid barrier and the arrival counter
+ *   SDEMPC_OPT_COOP_SPIN_US   -1 derived / >= 0 microseconds -1       SDEMPC_COOP_SPIN_US  how long one grid barrier / polled hand-off of a cooperative layout may wait
  *                                                                                          before the launch gives up (derived: 5 x the handle's last completed
  *                                                                                          cooperative solve, clamped to 2..100 ms; 100 ms before the first)
  *   SDEMPC_OPT_TEST_ABSENT_WG -1 none / >= 0 workgroup index -1       (none)               FAULT INJECTION for the tests of the bounded waits: that workgroup of a
@@ -202,7 +202,8 @@ int sdempc_grad_batch(sdempc_handle* h, int32_t B, const float* x0, const float*
  * Execution layout is chosen per call and never changes a bit of the result: P = 1 instances (all YAMLs the reference ships) run in a
  * single-particle layout; batches small enough that all workgroups are resident at once (C2: up to 15 instances) are spread over many
  * workgroups, one particle per wave, with one bounded grid barrier per rollout, and for the smallest batches additionally evaluate up to three
- * line-search trials and the candidate gradients of the next iteration at once (C2 single solve: 31 ms instead of 158 ms); larger
+ * line-search trials and the candidate gradients of the next iteration at once, handing the per-particle outputs over as tagged words that the
+ * workgroups poll (bounded like the barrier) instead of through a barrier (C2 single solve: 20 ms instead of 158 ms); larger
  * batches run one workgroup per instance in the 32-particle MFMA tile layout (throughput). The cooperative layouts assume that no other
  * kernel occupies the GPU while they run; if their workgroups cannot all become resident the barrier gives up after a bounded time
  * (SDEMPC_OPT_COOP_SPIN_US) and the telemetry of the launch is NaN. The host-pointer entry points then run the same batch once more in the

@@ -176,9 +176,13 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     unsigned phc = 0u, par_tag = 0u, arr_cnt = 0u;      // phases so far (the tag of a phase's outputs is its number), tag of the last parallel phase, arrivals of this workgroup
     // Polling costs the polled (a store whose line hundreds of waves keep reading is acknowledged late, and gfx9 counts loads and stores in one in-order
     // counter: sdempc_lane2.inc.h, adjoint loop), and 55 us of it per iteration buy nothing. So a reducer SLEEPS (no memory traffic) until shortly before
-    // the time the totals took to arrive in the iteration before, counted from the start of the parallel phase, and polls only then.
-    uint64_t t_par = 0; unsigned d_tot = 0u;            // s_memrealtime at the start of the last parallel phase; ticks from there to the totals, last streamed reduction
-    constexpr unsigned RED_LEAD = 900u;                 // start polling this many 10-ns ticks before the totals are due (reduce + publish + observe: 4 - 5 us)
+    // the time the totals took to arrive in the iteration before, counted from the start of the parallel phase, and polls only then (measured, C2 single solve:
+    // 19.9 ms; reducers polling from the moment they can 21.1 ms; a wave waking when ITS words were last seen arriving 20.8 ms — the early ones then poll the
+    // TOTALS for the rest of the phase). That time contains the sleepers' own lateness: were the chain from the words to the totals (4.5 us at C2, 7 at C3) ever
+    // longer than the lead, every iteration would start later than the one before. Hence the guard: the shortest time seen in this solve is remembered, and an
+    // iteration whose predecessor took an eighth longer than that does not sleep (it polls from the start, re-measures, and the lateness is gone).
+    uint64_t t_par = 0; unsigned d_tot = 0u, d_min = 0u;      // s_memrealtime at the start of the last parallel phase; ticks from there to the totals: last streamed reduction, shortest so far
+    constexpr unsigned RED_LEAD = 900u;                 // start polling this many 10-ns ticks before the totals are due
     // tags of an earlier launch must not be taken for this one's: the instance's first workgroup clears the words (the first reduction phase lies
     // behind at least two grid barriers)
     if (r_ == 0)
@@ -223,7 +227,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             const int gi = trial_grp ? (grp == 5 ? 2 : grp) : nt + (grp == 6 ? 3 : grp - 2);
             const int rank = __builtin_amdgcn_readfirstlane((gi * nwg + C.wgi) * 4 + wave);
             const int nredw = 2 * tw >= items ? tw : per * 4;
-            if (rank < nredw && red_tag == par_tag && d_tot > RED_LEAD) {
+            if (rank < nredw && red_tag == par_tag && d_tot > RED_LEAD && d_tot <= d_min + (d_min >> 3)) {
                 const uint64_t due = t_par + (uint64_t)(d_tot - RED_LEAD);
                 while (__builtin_amdgcn_s_memrealtime() < due) __builtin_amdgcn_s_sleep(8);
             }
@@ -490,7 +494,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                         }
                     }
                 }
-                if (red_tag == par_tag) d_tot = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_par);
+                if (red_tag == par_tag) { d_tot = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_par); if (d_min == 0u || d_tot < d_min) d_min = d_tot; }
                 c_y = uni_f(FMA(ctot, a.invP, cu));
                 SPEC_HK(1)
             } else {

@@ -150,6 +150,11 @@ DI float coop_total_tagged(CoopCtx& C, const unsigned long long* pq, int P, int 
 // (The tagged words themselves need no fence under any memory model: value and flag are ONE atomic location. The arrival counter orders accesses to
 // OTHER locations — reads before the add, writes behind the wait — so SDEMPC_OPT_COOP_FENCE puts its release / acquire pair here as well.)
 DI void coop_arrive(CoopCtx& C, int tid) {
+    // The compiler's wait-count model still carries the polling loops' loads as "maybe outstanding" (their timeout exits leave without waiting), and the first
+    // write to one of their registers behind the atomic then gets a vmcnt(0) — which on gfx9 also waits for the ATOMIC (one counter, in order): a 2 us round
+    // trip across the XCDs in one wave, with the other three waiting for it at the next barrier. Those loads returned long ago: a wait the compiler can see,
+    // in front of the atomic, costs nothing and clears its books, so that nothing behind the atomic waits for the counter until real loads are due.
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), the other counters untouched (gfx9 encoding)
     if (tid == 0) {
         if (C.fence) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __hip_atomic_fetch_add(C.bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

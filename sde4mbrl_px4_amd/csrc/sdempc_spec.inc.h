@@ -7,7 +7,7 @@
 // by side, groups 2, 3 and 4 already evaluate the gradient of
 // iteration k+1 at the three points the optimiser can move to: where it goes if it ends on trial 1 resp. trial 2 with an
 // improvement, and xk (no improvement). The step sizes of the trials are known before any of them is evaluated (s, s*dec, ...),
-// so are the restart tests. One grid barrier per phase. The optimiser itself is unchanged and runs redundantly in every
+// so are the restart tests. One grid barrier per SEQUENTIAL phase; the parallel and the reduction phases hand over through tagged words (below). The optimiser itself is unchanged and runs redundantly in every
 // workgroup: a gradient is a pure function of its point, so using the pre-computed one (when the speculation hits — the trial
 // costs decide that) gives the same bits as computing it afterwards; on a miss the iteration falls back to the sequential order.
 // Written as a state machine with ONE call site of the particle work, so that the rollout and the gradient sweep are each
@@ -160,9 +160,8 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
         float v = clampf(a.u[(size_t)b * N + e], a.C.ulo[jj], a.C.uhi[jj]);
         xk[e] = v; yk[e] = v;
     }
-    // PH_RED: the particle sums of a gradient (H*nq totals + the cost total) are reduced ONCE, spread over all workgroups of the
-    // instance (one step each), published and read back after one more barrier — every workgroup reducing everything itself took
-    // ~45 us per iteration, a third of the time of an iteration
+    // PH_RED: the particle sums of a gradient (H*nq totals + the cost total) are reduced ONCE, by the waves of the trial groups (two totals each),
+    // published as tagged words and polled by every workgroup — every workgroup reducing everything itself took ~45 us per iteration
     enum { PH_INIT, PH_GRAD, PH_PAR, PH_SEQ, PH_RED, PH_FINAL, PH_DONE };
 #ifndef SDEMPC_VAR_SPEC_CLK
 #define SDEMPC_VAR_SPEC_CLK 0
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
     uint64_t t_par = 0; unsigned d_tot = 0u, d_min = 0u;      // s_memrealtime at the start of the last parallel phase; ticks from there to the totals: last streamed reduction, shortest so far
     constexpr unsigned RED_LEAD = 900u;                 // start polling this many 10-ns ticks before the totals are due
     // tags of an earlier launch must not be taken for this one's: the instance's first workgroup clears the words (the first reduction phase lies
-    // behind at least two grid barriers)
+    // behind at least two grid barriers; since the streamed hand-off the host zeroes the whole workspace before the launch as well)
     if (r_ == 0)
         for (int i = tid; i < 2 * PS; i += Team::NT) __hip_atomic_store(gtot_base + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int phase = PH_INIT;

@@ -189,6 +189,12 @@ def other_config_legs(root, main_mlp, math_mode, B, dev, dev_ord, cfg_of, V, ver
         rec = {"config": os.path.basename(path), "mlp_dtype": mlp, "math_mode": math_mode, "instances": Bl, "launches_timed": reps, "value": Bl / (km * 1e-3), "unit": "solves/s",
                "kernel_ms": km, "kernel": kn, "roofline_frac": tf / F32_MFMA_PEAK_TF, "roofline_hbm_frac": gbs / HBM_PEAK_GBS,
                "N_it_mean": float(io[:, 2].mean()), "N_grad_evaluated_mean": ng, "N_forward_rollouts_mean": nf}
+        if name == "c3":
+            # a lone C3 instance (P = 256, 300 controls) in the f32 latency layouts, as the headline's p50 is for C2: four groups of 64 workgroups
+            s1 = SdeMpcSolver(cfg_of(path, "f32"), bl, max_batch=1, device=dev_ord)
+            lat, kn1, _ = latency_of(Lg, s1, 40, 4)
+            rec.update({"p50_solve_latency_ms": float(np.median(lat)), "p95_solve_latency_ms": float(np.percentile(lat, 95)), "latency_kernel": kn1, "latency_mlp_dtype": "f32"})
+            s1.close()
         if mlp == "f16":
             f16_tf = f16_contraction_flops(c2, ng, nf) * Bl / (km * 1e-3) / 1e12
             rec["matrix_pipe_use_f16"] = {"achieved": f16_tf, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": f16_tf / F16_MFMA_PEAK_TF,

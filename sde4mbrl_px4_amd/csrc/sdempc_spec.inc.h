@@ -434,21 +434,9 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
             else phase = PH_GRAD;
         }
         if constexpr (DIRECT) {
-            if (fin) {   // (c_y, g) straight from the particle's outputs in (red_par, red_slot): v + 0 is what the butterflies and the slot
-                         // order of SPEC.md §6.1 make of one value and zeros, so no reduction phase and no barrier for it
-                constexpr int nq = M + 4;
-                const unsigned long long* pw = spec_words(C, PS, red_par, red_slot);
-                const uint64_t t0w = __builtin_amdgcn_s_memrealtime();
-                for (int q = tid; q < H * 12; q += Team::NT)
-                    if ((q % 12) < nq) sm.tot[q] = tagged_wait(C, pw + (size_t)q * C.Ppad, red_tag, t0w) + 0.0f;
-                if (tid == 0) sm.red[12] = tagged_wait(C, pw + (size_t)(PS - 1) * C.Ppad, red_tag, t0w) + 0.0f;
-                const float cu = block_ucost<Team>(a, sm, yk, tid);
-                __syncthreads();
-                c_y = uni_f(FMA(sm.red[12], a.invP, cu));
-                assemble_gradient<Team, M>(a, sm, yk, g, tid, [&](int q) { return sm.tot[q]; });
-                __syncthreads();
-                head = true;
-            }
+            // (c_y, g) straight from the particle's outputs in (red_par, red_slot): v + 0 is what the butterflies and the slot order of SPEC.md §6.1 make of
+            // one value and zeros, so no reduction phase and no barrier for it — the head polls the particle's words as it polls the totals otherwise
+            if (fin) { head = true; head_poll = true; }
         }
         if (head) {      // start of iteration k with (c_y, g) in hand
             float sn = s;
@@ -463,7 +451,9 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                 // (c_y, g) from the published totals: every thread polls the five sums its element of the gradient is made of (and the cost total) itself and
                 // goes on to the trial points of that element — no staging of the totals in LDS, no barrier between totals, gradient and trial points; the
                 // control cost of yk needs no totals and is reduced BEFORE the wait (its barriers also order this iteration's writes of g / xn_j behind the last reads)
-                const unsigned long long* gt = gtot_base + (size_t)((red_cnt - 1u) & 1u) * PS;
+                const unsigned long long* gt = DIRECT ? spec_words(C, PS, red_par, red_slot) : gtot_base + (size_t)((red_cnt - 1u) & 1u) * PS;
+                const int ws = DIRECT ? C.Ppad : 1;                        // words from one quantity to the next (P == 1: the particle's own outputs, particle-minor rows)
+                const unsigned ptag = DIRECT ? red_tag : red_cnt;
 #if SDEMPC_VAR_SPEC_CLK
                 hk_t = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -475,11 +465,16 @@ __global__ void __launch_bounds__(256, 1) sdempc_solve_spec_kernel(KArgs a) {
                     const int ea = e0 + tid, eb = ea + Team::NT;
                     const bool ha = ea < N, hb = eb < N;
                     const int ta = ha ? ea / m : 0, ja = ha ? ea - ta * m : 0, tb = hb ? eb / m : 0, jb = hb ? eb - tb * m : 0;
-                    const unsigned long long *ga = gt + ta * 12, *gb = gt + tb * 12;
-                    const unsigned long long* const pw[11] = {ga + ja, ga + M, ga + M + 1, ga + M + 2, ga + M + 3, gb + jb, gb + M, gb + M + 1, gb + M + 2, gb + M + 3, gt + PS - 1};
+                    const unsigned long long *ga = gt + (size_t)(ta * 12) * ws, *gb = gt + (size_t)(tb * 12) * ws;
+                    const unsigned long long* const pw[11] = {ga + ja * ws, ga + M * ws, ga + (M + 1) * ws, ga + (M + 2) * ws, ga + (M + 3) * ws,
+                                                              gb + jb * ws, gb + M * ws, gb + (M + 1) * ws, gb + (M + 2) * ws, gb + (M + 3) * ws, gt + (size_t)(PS - 1) * ws};
                     const bool have[11] = {ha, ha, ha, ha, ha, hb, hb, hb, hb, hb, e0 == 0};
                     float v[11];
-                    tagged_wait_n<11>(C, pw, have, red_cnt, t0w, v);
+                    tagged_wait_n<11>(C, pw, have, ptag, t0w, v);
+                    if constexpr (DIRECT) {
+#pragma unroll
+                        for (int i = 0; i < 11; ++i) v[i] = v[i] + 0.0f;
+                    }
                     if (e0 == 0) ctot = v[10];
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {

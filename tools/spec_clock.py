@@ -11,6 +11,7 @@ from sde4mbrl_px4_amd.solver import SdeMpcSolver
 torch.cuda.init()
 name = sys.argv[1] if len(sys.argv) > 1 else "c2_iris_traj_h50_p128"
 cfg = load_mpc_config(os.path.join(ROOT, "configs", name + ".yaml"))
+if len(sys.argv) > 2: cfg = cfg.replace(math_mode=sys.argv[2])       # (a clock build of the fast-mode translation unit: -DSDEMPC_FAST=1 -DSDEMPC_VAR_SPEC_CLK=1)
 H, m = cfg.horizon, cfg.num_motors
 S = SdeMpcSolver(cfg, synthetic_iris() if m == 4 else synthetic_hexa(), max_batch=1)
 x0 = W.random_initial_states(1, 0)
